@@ -1,0 +1,125 @@
+"""ctypes loader for libanorag_hip.so (the C ABI declared in include/anorag.h).
+
+There is no CPU fallback: if the shared library is missing or a HIP call fails the caller gets an
+exception (``AnoragError``), never a silently different code path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_NAME = "libanorag_hip.so"
+LIB_PATH = os.path.join(_HERE, LIB_NAME)
+
+ANR_OK = 0
+METRIC_IP = 0
+METRIC_L2 = 1
+
+OPT_FORCE_EXACT = 1
+OPT_OVERFETCH = 2
+OPT_SAMPLE_ROWS = 3
+OPT_CAND_CAP = 4
+OPT_TIMING = 5
+
+
+class AnoragError(RuntimeError):
+    """A call into libanorag_hip.so failed (message from anr_last_error())."""
+
+
+class SearchStats(C.Structure):
+    _fields_ = [
+        ("n_queries", C.c_int64),
+        ("n_fallback", C.c_int64),
+        ("n_candidates", C.c_int64),
+        ("n_overflow", C.c_int64),
+        ("scan_bytes", C.c_int64),
+        ("overfetch", C.c_int32),
+        ("sample_rows", C.c_int32),
+        ("scan_ms", C.c_float),
+        ("total_ms", C.c_float),
+    ]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+_f32p = C.POINTER(C.c_float)
+_i64p = C.POINTER(C.c_int64)
+_i32p = C.POINTER(C.c_int32)
+
+# name -> (restype, argtypes); every symbol include/anorag.h declares must appear here
+SIGNATURES = {
+    "anr_last_error": (C.c_char_p, []),
+    "anr_version": (C.c_char_p, []),
+    "anr_device_count": (C.c_int, []),
+    "anr_index_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "anr_index_destroy": (C.c_int, [C.c_void_p]),
+    "anr_index_reserve": (C.c_int, [C.c_void_p, C.c_int64]),
+    "anr_index_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "anr_index_add_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "anr_index_ntotal": (C.c_int64, [C.c_void_p]),
+    "anr_index_dim": (C.c_int32, [C.c_void_p]),
+    "anr_index_reset": (C.c_int, [C.c_void_p]),
+    "anr_index_reconstruct": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    "anr_index_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "anr_index_search_dev": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],
+    ),
+    "anr_index_set_option": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64]),
+    "anr_index_last_stats": (C.c_int, [C.c_void_p, C.POINTER(SearchStats)]),
+    "anr_normalize_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32]),
+    "anr_merge_topk_dev": (
+        C.c_int,
+        [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+         C.c_void_p],
+    ),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load():
+    """Load the shared library once and bind the argument types."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise AnoragError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C ano-rag_amd/csrc`; there is no CPU fallback"
+            )
+        # PyTorch ships its own libamdhip64.so.7; when both live in one process the HIP runtime must be
+        # the same object, so let torch (if it is going to be used at all) load its copy first.
+        if os.environ.get("ANORAG_NO_TORCH_PRELOAD", "0") != "1":
+            try:
+                import torch  # noqa: F401
+            except Exception:  # pragma: no cover - torch absent is fine
+                pass
+        lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def last_error() -> str:
+    msg = load().anr_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != ANR_OK:
+        raise AnoragError(f"{what or 'libanorag_hip'} failed (code {rc}): {last_error()}")
+
+
+def device_count() -> int:
+    return int(load().anr_device_count())

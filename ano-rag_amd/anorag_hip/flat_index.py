@@ -1,0 +1,104 @@
+"""Thin object wrapper over the anr_index_* C ABI.
+
+``FlatIndex`` is what the drop-in ``vector_store.VectorIndex`` puts where the reference holds a
+``faiss.IndexFlatIP`` / ``IndexFlatL2`` object (reference vector_store/vector_index.py:77-80): the same
+``add`` / ``search`` / ``reset`` / ``ntotal`` surface, exact results, device-resident corpus.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import METRIC_IP, METRIC_L2, AnoragError, SearchStats
+
+
+def _f32_matrix(a, d, what):
+    a = np.asarray(a)
+    if a.ndim != 2 or a.shape[1] != d:
+        raise ValueError(f"{what}: expected a 2-D array with {d} columns, got shape {a.shape}")
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class FlatIndex:
+    """Exact inner-product / squared-L2 index resident on one MI355X."""
+
+    def __init__(self, d: int, metric: int = METRIC_IP, normalize: bool = False, device: int = 0):
+        self._lib = _lib.load()
+        self.d = int(d)
+        self.metric = int(metric)
+        self.normalize = bool(normalize)
+        self.device = int(device)
+        self.is_trained = True
+        h = C.c_void_p()
+        _lib.check(self._lib.anr_index_create(self.d, self.metric, int(self.normalize), self.device, C.byref(h)),
+                   "anr_index_create")
+        self._h = h
+
+    # -- faiss-like surface -------------------------------------------------------------------
+    @property
+    def ntotal(self) -> int:
+        return int(self._lib.anr_index_ntotal(self._h)) if self._h else 0
+
+    def add(self, x) -> None:
+        x = _f32_matrix(x, self.d, "add")
+        _lib.check(self._lib.anr_index_add(self._h, x.ctypes.data_as(C.c_void_p), x.shape[0]), "anr_index_add")
+
+    def search(self, q, k: int):
+        q = _f32_matrix(q, self.d, "search")
+        nq = q.shape[0]
+        D = np.empty((nq, k), dtype=np.float32)
+        I = np.empty((nq, k), dtype=np.int64)
+        _lib.check(
+            self._lib.anr_index_search(self._h, q.ctypes.data_as(C.c_void_p), nq, int(k),
+                                       D.ctypes.data_as(C.c_void_p), I.ctypes.data_as(C.c_void_p)),
+            "anr_index_search",
+        )
+        return D, I
+
+    def reset(self) -> None:
+        _lib.check(self._lib.anr_index_reset(self._h), "anr_index_reset")
+
+    def reconstruct_n(self, i0: int, n: int):
+        out = np.empty((n, self.d), dtype=np.float32)
+        _lib.check(self._lib.anr_index_reconstruct(self._h, int(i0), int(n), out.ctypes.data_as(C.c_void_p)),
+                   "anr_index_reconstruct")
+        return out
+
+    # -- device-pointer surface (torch tensors are only carriers of device memory) --------------
+    def reserve(self, n: int) -> None:
+        _lib.check(self._lib.anr_index_reserve(self._h, int(n)), "anr_index_reserve")
+
+    def add_device(self, x_ptr: int, n: int, stream: int = 0) -> None:
+        _lib.check(self._lib.anr_index_add_dev(self._h, C.c_void_p(x_ptr), int(n), C.c_void_p(stream)),
+                   "anr_index_add_dev")
+
+    def search_device(self, q_ptr: int, nq: int, k: int, d_ptr: int, i_ptr: int, stream: int = 0) -> None:
+        _lib.check(
+            self._lib.anr_index_search_dev(self._h, C.c_void_p(q_ptr), int(nq), int(k), C.c_void_p(d_ptr),
+                                           C.c_void_p(i_ptr), C.c_void_p(stream)),
+            "anr_index_search_dev",
+        )
+
+    def set_option(self, opt: int, value: int) -> None:
+        _lib.check(self._lib.anr_index_set_option(self._h, int(opt), int(value)), "anr_index_set_option")
+
+    def last_stats(self) -> dict:
+        st = SearchStats()
+        _lib.check(self._lib.anr_index_last_stats(self._h, C.byref(st)), "anr_index_last_stats")
+        return st.as_dict()
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.anr_index_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover - best effort
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+__all__ = ["FlatIndex", "METRIC_IP", "METRIC_L2", "AnoragError"]

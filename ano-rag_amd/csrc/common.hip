@@ -1,0 +1,45 @@
+// Error plumbing + trivial introspection entry points of the C ABI (include/anorag.h).
+#include "common.hpp"
+
+namespace anr {
+
+std::string &last_error_ref() {
+  static thread_local std::string s;
+  return s;
+}
+
+int fail(int code, const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  last_error_ref() = buf;
+  return code;
+}
+
+int device_cu_count(int device) {
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || n <= 0)
+    n = 256;  // MI355X
+  return n;
+}
+
+}  // namespace anr
+
+extern "C" {
+
+const char *anr_last_error(void) { return anr::last_error_ref().c_str(); }
+
+const char *anr_version(void) { return "anorag-hip 0.1 (gfx950)"; }
+
+int anr_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,711 @@
+// Exact flat index behind anr_index_* (include/anorag.h): host orchestration of the kernels in
+// index_kernels.hpp.  Replaces faiss.IndexFlatIP / IndexFlatL2 at the call sites of the reference's
+// vector_store/vector_index.py (:77-80 create, :196 add, :223 search, :415-426 reset).
+//
+// Search pipeline for one batch of <= 64 queries:
+//   prepq -> [sample: scan<DENSE> on a strided tile sample -> select -> threshold ladder]
+//         -> scan (f16 MFMA, threshold-gated candidate append) -> select top-K' -> rescore (f32 rows,
+//         f64 accumulate) -> finalize (sort, write top-k, certificate)
+//   queries whose certificate fails are answered by the dense exact path (k_exact_dense + select).
+#include <mutex>
+#include <vector>
+
+#include "common.hpp"
+#include "index_kernels.hpp"
+
+using namespace anr;
+
+struct anr_index {
+  int dim = 0, dimp = 0, kb = 0;
+  int metric = 0, normalize = 0, device = 0;
+  int n_cu = 256;
+  int64_t ntotal = 0, cap = 0;  // cap: rows allocated, multiple of 32
+  float *x32 = nullptr;
+  _Float16 *x16 = nullptr;
+  float *rowbias = nullptr;
+  unsigned *xstat = nullptr;  // [4]
+  hipStream_t stream = nullptr;
+  std::mutex mu;
+
+  // options
+  int force_exact = 0;
+  int overfetch = 0;
+  int sample_rows = 0;
+  int64_t cand_cap = 8192;
+  int timing = 0;
+
+  // workspace (one batch)
+  float *q32 = nullptr;
+  _Float16 *q16 = nullptr;
+  float *qstat = nullptr;
+  float *qstage = nullptr;   // device staging of host queries [64][dim]
+  float *dense = nullptr;
+  int64_t dense_ld = 0;
+  float *ladder = nullptr;
+  unsigned *lhist = nullptr;  // [64][kLadder] followed by cnt [64]
+  unsigned *cnt = nullptr;
+  uint2 *cand = nullptr;
+  int64_t cand_alloc = 0;
+  float *sel_rank = nullptr;
+  unsigned *sel_row = nullptr;
+  int *sel_m = nullptr;
+  unsigned *overflow = nullptr;
+  float *exact = nullptr;
+  int *flags = nullptr;
+  int *flags_host = nullptr;   // pinned
+  unsigned *cnt_host = nullptr;  // pinned [64]
+  float *xdense = nullptr;      // exact dense path [4][xdense_ld]
+  int64_t xdense_ld = 0;
+  float *d_out = nullptr;       // staging for host-pointer searches
+  int64_t *i_out = nullptr;
+  int64_t out_alloc = 0;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+
+  anr_search_stats stats{};
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(T **p, int64_t count, bool zero) {
+  *p = nullptr;
+  if (count <= 0) count = 1;
+  ANR_HIP(hipMalloc(reinterpret_cast<void **>(p), (size_t)count * sizeof(T)));
+  if (zero) ANR_HIP(hipMemset(*p, 0, (size_t)count * sizeof(T)));
+  return ANR_OK;
+}
+
+template <typename T>
+void dev_free(T *&p) {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+}
+
+int grow_storage(anr_index *h, int64_t need_rows) {
+  if (need_rows <= h->cap) return ANR_OK;
+  int64_t ncap = h->cap ? h->cap : 1024;
+  while (ncap < need_rows) ncap = ncap + ncap / 2 + 1024;
+  ncap = round_up(ncap, kTileRows);
+  if (need_rows > (int64_t)0xfffffff0ll) return fail(ANR_EINVAL, "index holds at most 2^32-16 rows per device");
+  float *nx32 = nullptr;
+  _Float16 *nx16 = nullptr;
+  float *nbias = nullptr;
+  ANR_TRY(dev_alloc(&nx32, ncap * h->dim, false));
+  ANR_TRY(dev_alloc(&nx16, ncap * h->dimp, true));
+  if (h->metric == ANR_METRIC_L2) ANR_TRY(dev_alloc(&nbias, ncap, true));
+  if (h->ntotal > 0) {
+    const int64_t used = round_up(h->ntotal, kTileRows);
+    ANR_HIP(hipMemcpyAsync(nx32, h->x32, (size_t)h->ntotal * h->dim * sizeof(float), hipMemcpyDeviceToDevice,
+                           h->stream));
+    ANR_HIP(hipMemcpyAsync(nx16, h->x16, (size_t)used * h->dimp * sizeof(_Float16), hipMemcpyDeviceToDevice,
+                           h->stream));
+    if (nbias)
+      ANR_HIP(hipMemcpyAsync(nbias, h->rowbias, (size_t)h->ntotal * sizeof(float), hipMemcpyDeviceToDevice,
+                             h->stream));
+    ANR_HIP(hipStreamSynchronize(h->stream));
+  }
+  dev_free(h->x32);
+  dev_free(h->x16);
+  dev_free(h->rowbias);
+  h->x32 = nx32;
+  h->x16 = nx16;
+  h->rowbias = nbias;
+  h->cap = ncap;
+  return ANR_OK;
+}
+
+int ensure_workspace(anr_index *h) {
+  if (h->q32) return ANR_OK;
+  ANR_TRY(dev_alloc(&h->q32, (int64_t)kQB * h->dimp, true));
+  ANR_TRY(dev_alloc(&h->q16, (int64_t)kQB * h->dimp, true));
+  ANR_TRY(dev_alloc(&h->qstat, kQB * 4, true));
+  ANR_TRY(dev_alloc(&h->qstage, (int64_t)kQB * h->dim, true));
+  ANR_TRY(dev_alloc(&h->ladder, kQB * kLadder, true));
+  ANR_TRY(dev_alloc(&h->lhist, kQB * kLadder + kQB, true));
+  h->cnt = h->lhist + kQB * kLadder;
+  ANR_TRY(dev_alloc(&h->sel_rank, kQB * kMaxSel, true));
+  ANR_TRY(dev_alloc(&h->sel_row, kQB * kMaxSel, true));
+  ANR_TRY(dev_alloc(&h->sel_m, kQB, true));
+  ANR_TRY(dev_alloc(&h->overflow, kQB, true));
+  ANR_TRY(dev_alloc(&h->exact, kQB * kMaxSel, true));
+  ANR_TRY(dev_alloc(&h->flags, kQB, true));
+  ANR_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->flags_host), kQB * sizeof(int), hipHostMallocDefault));
+  ANR_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->cnt_host), kQB * sizeof(unsigned), hipHostMallocDefault));
+  for (auto &e : h->ev) ANR_HIP(hipEventCreate(&e));
+  return ANR_OK;
+}
+
+int ensure_cand(anr_index *h) {
+  if (h->cand && h->cand_alloc == h->cand_cap) return ANR_OK;
+  dev_free(h->cand);
+  ANR_TRY(dev_alloc(&h->cand, (int64_t)kQB * h->cand_cap, false));
+  h->cand_alloc = h->cand_cap;
+  return ANR_OK;
+}
+
+int ensure_dense(anr_index *h, int64_t ld) {
+  if (h->dense && h->dense_ld >= ld) return ANR_OK;
+  dev_free(h->dense);
+  h->dense_ld = round_up(ld, 32);
+  return dev_alloc(&h->dense, (int64_t)kQB * h->dense_ld, false);
+}
+
+template <bool DENSE>
+int launch_scan(anr_index *h, const ScanParams &p, hipStream_t st) {
+  if (p.n_tiles <= 0) return ANR_OK;
+  const size_t lds = (size_t)2 * p.kb * 64 * 16 + kQB * kLadder * sizeof(float);
+  // 16 waves per block when there is enough work for every CU, else smaller blocks on more CUs
+  int nwaves = 16;
+  while (nwaves > 4 && ceil_div(p.n_tiles, nwaves) < h->n_cu) nwaves >>= 1;
+  const int nt = nwaves * 64;
+  int64_t grid = ceil_div(p.n_tiles, nwaves);
+  if (grid > h->n_cu) grid = h->n_cu;
+  if (p.kb % 16 == 0) {
+    auto kern = k_scan<DENSE, 8, 1024>;
+    ANR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(nt), lds, st, p);
+  } else {
+    auto kern = k_scan<DENSE, 4, 1024>;
+    ANR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(nt), lds, st, p);
+  }
+  ANR_HIP(hipGetLastError());
+  return ANR_OK;
+}
+
+int auto_overfetch(const anr_index *h, int k) {
+  if (h->overfetch > 0) {
+    int m = h->overfetch < k ? k : h->overfetch;
+    return m > kMaxSel ? kMaxSel : m;
+  }
+  int extra = k / 2 > 32 ? k / 2 : 32;
+  int m = (int)round_up(k + extra, 64);
+  return m > kMaxSel ? kMaxSel : m;
+}
+
+// dense exact path for the listed batch-local query slots
+int run_exact(anr_index *h, const std::vector<int> &slots, int64_t out_off, int k, float *D_dev, int64_t *I_dev,
+              hipStream_t st) {
+  const int64_t ld = round_up(h->ntotal, 32);
+  if (!h->xdense || h->xdense_ld < ld) {
+    dev_free(h->xdense);
+    h->xdense_ld = ld;
+    ANR_TRY(dev_alloc(&h->xdense, 4 * ld, false));
+  }
+  for (size_t b = 0; b < slots.size(); b += 4) {
+    const int nf = (int)std::min<size_t>(4, slots.size() - b);
+    ExactParams ep{};
+    ep.x32 = h->x32;
+    ep.q32 = h->q32;
+    ep.dim = h->dim;
+    ep.dimp = h->dimp;
+    ep.metric = h->metric;
+    ep.n_rows = h->ntotal;
+    ep.nf = nf;
+    for (int f = 0; f < nf; ++f) ep.qidx[f] = slots[b + f];
+    ep.dense = h->xdense;
+    ep.ld = h->xdense_ld;
+    int64_t grid = ceil_div(h->ntotal, 4);
+    if (grid > (int64_t)h->n_cu * 16) grid = (int64_t)h->n_cu * 16;
+    hipLaunchKernelGGL(k_exact_dense, dim3((unsigned)grid), dim3(256), 0, st, ep);
+    // select straight from the exact values; slots f of the select output are reused (0..nf-1)
+    SelParams sp{};
+    sp.dense = h->xdense;
+    sp.dense_ld = h->xdense_ld;
+    sp.n = h->ntotal;
+    sp.row0 = 0;
+    sp.row_tile_stride = 1;
+    sp.negate = h->metric == ANR_METRIC_L2;
+    sp.M = k;
+    sp.out_rank = h->sel_rank;
+    sp.out_row = h->sel_row;
+    sp.out_m = h->sel_m;
+    hipLaunchKernelGGL(k_select, dim3(nf), dim3(1024), 0, st, sp);
+    EmitParams mp{};
+    mp.rank = h->sel_rank;
+    mp.row = h->sel_row;
+    mp.m = h->sel_m;
+    mp.nf = nf;
+    for (int f = 0; f < nf; ++f) {
+      mp.slot[f] = f;
+      mp.outq[f] = out_off + slots[b + f];
+    }
+    mp.k = k;
+    mp.metric = h->metric;
+    mp.D = D_dev;
+    mp.I = I_dev;
+    mp.id_offset = 0;
+    hipLaunchKernelGGL(k_emit, dim3(nf), dim3(256), 0, st, mp);
+    ANR_HIP(hipGetLastError());
+  }
+  return ANR_OK;
+}
+
+// one batch of nq <= 64 queries already on the device
+int search_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_off, float *D_dev, int64_t *I_dev,
+                 hipStream_t st) {
+  PrepQParams qp{};
+  qp.qin = q_dev;
+  qp.nq = nq;
+  qp.dim = h->dim;
+  qp.dimp = h->dimp;
+  qp.kb = h->kb;
+  qp.normalize = h->normalize;
+  qp.q32 = h->q32;
+  qp.q16 = h->q16;
+  qp.qstat = h->qstat;
+  hipLaunchKernelGGL(k_prepq, dim3(kQB), dim3(256), 0, st, qp);
+
+  unsigned xstat_host[4] = {0, 0, 0, 0};
+  bool exact_all = h->force_exact != 0;
+  if (!exact_all && h->metric == ANR_METRIC_L2) {
+    // f16 image unusable when a stored value left the f16 range
+    ANR_HIP(hipMemcpyAsync(xstat_host, h->xstat, sizeof xstat_host, hipMemcpyDeviceToHost, st));
+    ANR_HIP(hipStreamSynchronize(st));
+    if (xstat_host[2]) exact_all = true;
+  }
+  std::vector<int> fallback;
+  if (exact_all) {
+    for (int q = 0; q < nq; ++q) fallback.push_back(q);
+    h->stats.n_fallback += nq;
+    return run_exact(h, fallback, out_off, k, D_dev, I_dev, st);
+  }
+
+  const int M = auto_overfetch(h, k);
+  const int64_t n_tiles = ceil_div(h->ntotal, kTileRows);
+  const int64_t full_tiles = h->ntotal / kTileRows;
+  int64_t sample_tiles = (h->sample_rows > 0 ? h->sample_rows : 4096) / kTileRows;
+  if (sample_tiles * kTileRows < 2 * M) sample_tiles = ceil_div(2 * M, kTileRows);
+  const bool sparse = full_tiles >= 8 * sample_tiles;
+
+  ScanParams sc{};
+  sc.x16 = reinterpret_cast<const uint4 *>(h->x16);
+  sc.q16 = reinterpret_cast<const uint4 *>(h->q16);
+  sc.kb = h->kb;
+  sc.n_rows = h->ntotal;
+  sc.rowbias = h->rowbias;
+
+  SelParams sp{};
+  sp.M = M;
+  sp.out_rank = h->sel_rank;
+  sp.out_row = h->sel_row;
+  sp.out_m = h->sel_m;
+
+  if (!sparse) {
+    // small corpus: dense scores of every row, select the candidates from them
+    ANR_TRY(ensure_dense(h, n_tiles * kTileRows));
+    sc.tile0 = 0;
+    sc.tile_stride = 1;
+    sc.n_tiles = n_tiles;
+    sc.dense = h->dense;
+    sc.dense_ld = h->dense_ld;
+    if (h->timing) ANR_HIP(hipEventRecord(h->ev[0], st));
+    ANR_TRY(launch_scan<true>(h, sc, st));
+    if (h->timing) ANR_HIP(hipEventRecord(h->ev[1], st));
+    h->stats.scan_bytes += n_tiles * kTileRows * (int64_t)h->dimp * 2;
+    sp.dense = h->dense;
+    sp.dense_ld = h->dense_ld;
+    sp.n = h->ntotal;
+    sp.row0 = 0;
+    sp.row_tile_stride = 1;
+    sp.overflow = nullptr;
+    hipLaunchKernelGGL(k_select, dim3(nq), dim3(1024), 0, st, sp);
+  } else {
+    ANR_TRY(ensure_dense(h, sample_tiles * kTileRows));
+    ANR_TRY(ensure_cand(h));
+    // 1) strided sample -> ladder of valid thresholds
+    sc.tile0 = 0;
+    sc.tile_stride = full_tiles / sample_tiles;
+    sc.n_tiles = sample_tiles;
+    sc.dense = h->dense;
+    sc.dense_ld = h->dense_ld;
+    ANR_TRY(launch_scan<true>(h, sc, st));
+    SelParams ss = sp;
+    ss.dense = h->dense;
+    ss.dense_ld = h->dense_ld;
+    ss.n = sample_tiles * kTileRows;
+    ss.row0 = 0;
+    ss.row_tile_stride = sc.tile_stride;
+    ss.ladder = h->ladder;
+    hipLaunchKernelGGL(k_select, dim3(kQB), dim3(1024), 0, st, ss);
+    ANR_HIP(hipMemsetAsync(h->lhist, 0, (kQB * kLadder + kQB) * sizeof(unsigned), st));
+    // 2) the full scan
+    sc.tile0 = 0;
+    sc.tile_stride = 1;
+    sc.n_tiles = n_tiles;
+    sc.dense = nullptr;
+    sc.ladder = h->ladder;
+    sc.lhist = h->lhist;
+    sc.cnt = h->cnt;
+    sc.cand = h->cand;
+    sc.cap = (unsigned)h->cand_cap;
+    sc.kprime = (unsigned)M;
+    if (h->timing) ANR_HIP(hipEventRecord(h->ev[0], st));
+    ANR_TRY(launch_scan<false>(h, sc, st));
+    if (h->timing) ANR_HIP(hipEventRecord(h->ev[1], st));
+    h->stats.scan_bytes += n_tiles * kTileRows * (int64_t)h->dimp * 2;
+    // 3) top-M of the candidates
+    sp.cand = h->cand;
+    sp.cnt = h->cnt;
+    sp.cap = (unsigned)h->cand_cap;
+    sp.overflow = h->overflow;
+    hipLaunchKernelGGL(k_select, dim3(nq), dim3(1024), 0, st, sp);
+    ANR_HIP(hipMemcpyAsync(h->cnt_host, h->cnt, kQB * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+  }
+
+  RescoreParams rp{};
+  rp.x32 = h->x32;
+  rp.q32 = h->q32;
+  rp.dim = h->dim;
+  rp.dimp = h->dimp;
+  rp.metric = h->metric;
+  rp.sel_row = h->sel_row;
+  rp.sel_m = h->sel_m;
+  rp.exact = h->exact;
+  rp.M = M;
+  hipLaunchKernelGGL(k_rescore, dim3((unsigned)ceil_div((int64_t)nq * M, 4)), dim3(256), 0, st, rp);
+
+  FinalParams fp{};
+  fp.exact = h->exact;
+  fp.approx = h->sel_rank;
+  fp.sel_row = h->sel_row;
+  fp.sel_m = h->sel_m;
+  fp.overflow = sparse ? h->overflow : nullptr;
+  fp.qstat = h->qstat;
+  fp.xstat = h->xstat;
+  fp.metric = h->metric;
+  fp.dimp = h->dimp;
+  fp.n_rows = h->ntotal;
+  fp.M = M;
+  fp.k = k;
+  fp.nq = nq;
+  fp.out_off = out_off;
+  fp.D = D_dev;
+  fp.I = I_dev;
+  fp.flags = h->flags;
+  fp.id_offset = 0;
+  hipLaunchKernelGGL(k_finalize, dim3(nq), dim3(256), 0, st, fp);
+  ANR_HIP(hipGetLastError());
+
+  ANR_HIP(hipMemcpyAsync(h->flags_host, h->flags, kQB * sizeof(int), hipMemcpyDeviceToHost, st));
+  ANR_HIP(hipStreamSynchronize(st));
+  if (h->timing) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, h->ev[0], h->ev[1]) == hipSuccess) h->stats.scan_ms += ms;
+  }
+  h->stats.overfetch = M;
+  h->stats.sample_rows = sparse ? (int)(sample_tiles * kTileRows) : 0;
+  if (sparse)
+    for (int q = 0; q < nq; ++q) {
+      h->stats.n_candidates += h->cnt_host[q];
+      if (h->cnt_host[q] > (unsigned)h->cand_cap) h->stats.n_overflow += 1;
+    }
+  for (int q = 0; q < nq; ++q)
+    if (h->flags_host[q]) fallback.push_back(q);
+  if (!fallback.empty()) {
+    h->stats.n_fallback += (int64_t)fallback.size();
+    ANR_TRY(run_exact(h, fallback, out_off, k, D_dev, I_dev, st));
+    ANR_HIP(hipStreamSynchronize(st));
+  }
+  return ANR_OK;
+}
+
+int search_impl(anr_index *h, const float *q, bool q_on_host, int64_t nq, int32_t k, float *D, int64_t *I,
+                bool out_on_host, hipStream_t st) {
+  if (!h || !q || !D || !I) return fail(ANR_EINVAL, "null argument");
+  if (nq < 0 || k <= 0) return fail(ANR_EINVAL, "nq must be >= 0 and k > 0");
+  if (k > kMaxSel) return fail(ANR_EINVAL, "k = %d exceeds the supported maximum %d", k, kMaxSel);
+  DeviceGuard g(h->device);
+  if (!g.ok) return fail(ANR_EHIP, "hipSetDevice(%d) failed", h->device);
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (!st) st = h->stream;
+  h->stats = anr_search_stats{};
+  h->stats.n_queries = nq;
+  if (nq == 0) return ANR_OK;
+  if (h->ntotal == 0) {
+    // faiss returns -1 ids and the neutral score for an empty index
+    std::vector<float> dd((size_t)nq * k, h->metric == 0 ? -3.402823466e+38f : 3.402823466e+38f);
+    std::vector<int64_t> ii((size_t)nq * k, -1);
+    if (out_on_host) {
+      memcpy(D, dd.data(), dd.size() * sizeof(float));
+      memcpy(I, ii.data(), ii.size() * sizeof(int64_t));
+    } else {
+      ANR_HIP(hipMemcpy(D, dd.data(), dd.size() * sizeof(float), hipMemcpyHostToDevice));
+      ANR_HIP(hipMemcpy(I, ii.data(), ii.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    }
+    return ANR_OK;
+  }
+  ANR_TRY(ensure_workspace(h));
+  float *Dd = D;
+  int64_t *Id = I;
+  if (out_on_host) {
+    if (h->out_alloc < nq * k) {
+      dev_free(h->d_out);
+      dev_free(h->i_out);
+      ANR_TRY(dev_alloc(&h->d_out, nq * k, false));
+      ANR_TRY(dev_alloc(&h->i_out, nq * k, false));
+      h->out_alloc = nq * k;
+    }
+    Dd = h->d_out;
+    Id = h->i_out;
+  }
+  if (h->timing) ANR_HIP(hipEventRecord(h->ev[2], st));
+  for (int64_t q0 = 0; q0 < nq; q0 += kQB) {
+    const int nb = (int)std::min<int64_t>(kQB, nq - q0);
+    const float *qd = q + q0 * h->dim;
+    if (q_on_host) {
+      ANR_HIP(hipMemcpyAsync(h->qstage, qd, (size_t)nb * h->dim * sizeof(float), hipMemcpyHostToDevice, st));
+      qd = h->qstage;
+    }
+    ANR_TRY(search_batch(h, qd, nb, k, q0, Dd, Id, st));
+  }
+  if (h->timing) {
+    ANR_HIP(hipEventRecord(h->ev[3], st));
+    ANR_HIP(hipEventSynchronize(h->ev[3]));
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, h->ev[2], h->ev[3]) == hipSuccess) h->stats.total_ms = ms;
+  }
+  if (out_on_host) {
+    ANR_HIP(hipMemcpyAsync(D, Dd, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, st));
+    ANR_HIP(hipMemcpyAsync(I, Id, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    ANR_HIP(hipStreamSynchronize(st));
+  }
+  return ANR_OK;
+}
+
+int add_impl(anr_index *h, const float *x_dev, int64_t n, hipStream_t st) {
+  ANR_TRY(grow_storage(h, h->ntotal + n));
+  AddParams ap{};
+  ap.xin = x_dev;
+  ap.n = n;
+  ap.row0 = h->ntotal;
+  ap.dim = h->dim;
+  ap.dimp = h->dimp;
+  ap.kb = h->kb;
+  ap.normalize = h->normalize;
+  ap.x32 = h->x32;
+  ap.x16 = h->x16;
+  ap.rowbias = h->rowbias;
+  ap.stat = h->xstat;
+  const int64_t t0 = h->ntotal / kTileRows, t1 = ceil_div(h->ntotal + n, kTileRows);
+  hipLaunchKernelGGL(k_add, dim3((unsigned)(t1 - t0)), dim3(256), 0, st, ap);
+  ANR_HIP(hipGetLastError());
+  h->ntotal += n;
+  return ANR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int anr_index_create(int32_t dim, int32_t metric, int32_t normalize, int32_t device, anr_index **out) {
+  if (!out) return fail(ANR_EINVAL, "out is null");
+  *out = nullptr;
+  if (dim <= 0 || dim > 4096) return fail(ANR_EINVAL, "dim must be in 1..4096 (got %d)", dim);
+  if (metric != ANR_METRIC_IP && metric != ANR_METRIC_L2) return fail(ANR_EINVAL, "unknown metric %d", metric);
+  int ndev = anr_device_count();
+  if (ndev <= 0) return fail(ANR_EHIP, "no HIP device is visible");
+  if (device < 0 || device >= ndev) return fail(ANR_EINVAL, "device %d out of range (0..%d)", device, ndev - 1);
+  DeviceGuard g(device);
+  if (!g.ok) return fail(ANR_EHIP, "hipSetDevice(%d) failed", device);
+  anr_index *h = new anr_index();
+  h->dim = dim;
+  h->dimp = (int)round_up(dim, 128);
+  h->kb = h->dimp / 16;
+  if ((size_t)2 * h->kb * 64 * 16 + kQB * kLadder * sizeof(float) > 160 * 1024) {
+    delete h;
+    return fail(ANR_EINVAL, "dim %d needs more than 160 KiB of LDS for the query operand", dim);
+  }
+  h->metric = metric;
+  h->normalize = normalize ? 1 : 0;
+  h->device = device;
+  h->n_cu = device_cu_count(device);
+  hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete h;
+    return fail(ANR_EHIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+  }
+  int r = dev_alloc(&h->xstat, 4, true);
+  if (r != ANR_OK) {
+    (void)hipStreamDestroy(h->stream);
+    delete h;
+    return r;
+  }
+  *out = h;
+  return ANR_OK;
+}
+
+int anr_index_destroy(anr_index *h) {
+  if (!h) return ANR_OK;
+  DeviceGuard g(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  dev_free(h->x32);
+  dev_free(h->x16);
+  dev_free(h->rowbias);
+  dev_free(h->xstat);
+  dev_free(h->q32);
+  dev_free(h->q16);
+  dev_free(h->qstat);
+  dev_free(h->qstage);
+  dev_free(h->dense);
+  dev_free(h->ladder);
+  dev_free(h->lhist);
+  dev_free(h->cand);
+  dev_free(h->sel_rank);
+  dev_free(h->sel_row);
+  dev_free(h->sel_m);
+  dev_free(h->overflow);
+  dev_free(h->exact);
+  dev_free(h->flags);
+  dev_free(h->xdense);
+  dev_free(h->d_out);
+  dev_free(h->i_out);
+  if (h->flags_host) (void)hipHostFree(h->flags_host);
+  if (h->cnt_host) (void)hipHostFree(h->cnt_host);
+  for (auto &e : h->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return ANR_OK;
+}
+
+int anr_index_reserve(anr_index *h, int64_t n) {
+  if (!h || n < 0) return fail(ANR_EINVAL, "bad argument");
+  DeviceGuard g(h->device);
+  std::lock_guard<std::mutex> lk(h->mu);
+  return grow_storage(h, n);
+}
+
+int anr_index_add_dev(anr_index *h, const float *x_dev, int64_t n, void *stream) {
+  if (!h || (!x_dev && n > 0) || n < 0) return fail(ANR_EINVAL, "bad argument");
+  if (n == 0) return ANR_OK;
+  DeviceGuard g(h->device);
+  std::lock_guard<std::mutex> lk(h->mu);
+  hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : h->stream;
+  ANR_TRY(add_impl(h, x_dev, n, st));
+  ANR_HIP(hipStreamSynchronize(st));
+  return ANR_OK;
+}
+
+int anr_index_add(anr_index *h, const float *x_host, int64_t n) {
+  if (!h || (!x_host && n > 0) || n < 0) return fail(ANR_EINVAL, "bad argument");
+  if (n == 0) return ANR_OK;
+  DeviceGuard g(h->device);
+  std::lock_guard<std::mutex> lk(h->mu);
+  ANR_TRY(grow_storage(h, h->ntotal + n));
+  // stream the host rows through a bounded device staging buffer
+  const int64_t chunk = std::max<int64_t>(kTileRows, std::min<int64_t>(n, (int64_t)(256ll << 20) / (h->dim * 4)));
+  float *stage = nullptr;
+  ANR_TRY(dev_alloc(&stage, chunk * h->dim, false));
+  int rc = ANR_OK;
+  for (int64_t i = 0; i < n && rc == ANR_OK; i += chunk) {
+    const int64_t m = std::min(chunk, n - i);
+    hipError_t e = hipMemcpyAsync(stage, x_host + i * h->dim, (size_t)m * h->dim * sizeof(float),
+                                  hipMemcpyHostToDevice, h->stream);
+    if (e != hipSuccess) {
+      rc = fail(ANR_EHIP, "hipMemcpyAsync failed: %s", hipGetErrorString(e));
+      break;
+    }
+    rc = add_impl(h, stage, m, h->stream);
+    if (rc == ANR_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(ANR_EHIP, "add kernel failed");
+  }
+  (void)hipFree(stage);
+  return rc;
+}
+
+int64_t anr_index_ntotal(const anr_index *h) { return h ? h->ntotal : 0; }
+int32_t anr_index_dim(const anr_index *h) { return h ? h->dim : 0; }
+
+int anr_index_reset(anr_index *h) {
+  if (!h) return fail(ANR_EINVAL, "null handle");
+  DeviceGuard g(h->device);
+  std::lock_guard<std::mutex> lk(h->mu);
+  ANR_HIP(hipStreamSynchronize(h->stream));
+  if (h->x16) ANR_HIP(hipMemset(h->x16, 0, (size_t)h->cap * h->dimp * sizeof(_Float16)));
+  if (h->rowbias) ANR_HIP(hipMemset(h->rowbias, 0, (size_t)h->cap * sizeof(float)));
+  ANR_HIP(hipMemset(h->xstat, 0, 4 * sizeof(unsigned)));
+  h->ntotal = 0;
+  return ANR_OK;
+}
+
+int anr_index_reconstruct(anr_index *h, int64_t i0, int64_t n, float *out_host) {
+  if (!h || !out_host || i0 < 0 || n < 0 || i0 + n > h->ntotal) return fail(ANR_EINVAL, "row range out of bounds");
+  if (n == 0) return ANR_OK;
+  DeviceGuard g(h->device);
+  std::lock_guard<std::mutex> lk(h->mu);
+  ANR_HIP(hipStreamSynchronize(h->stream));
+  ANR_HIP(hipMemcpy(out_host, h->x32 + i0 * h->dim, (size_t)n * h->dim * sizeof(float), hipMemcpyDeviceToHost));
+  return ANR_OK;
+}
+
+int anr_index_search(anr_index *h, const float *q_host, int64_t nq, int32_t k, float *D, int64_t *I) {
+  return search_impl(h, q_host, true, nq, k, D, I, true, nullptr);
+}
+
+int anr_index_search_dev(anr_index *h, const float *q_dev, int64_t nq, int32_t k, float *D_dev, int64_t *I_dev,
+                         void *stream) {
+  return search_impl(h, q_dev, false, nq, k, D_dev, I_dev, false, reinterpret_cast<hipStream_t>(stream));
+}
+
+int anr_index_set_option(anr_index *h, int32_t opt, int64_t value) {
+  if (!h) return fail(ANR_EINVAL, "null handle");
+  std::lock_guard<std::mutex> lk(h->mu);
+  switch (opt) {
+    case ANR_OPT_FORCE_EXACT: h->force_exact = value != 0; break;
+    case ANR_OPT_OVERFETCH:
+      if (value < 0 || value > kMaxSel) return fail(ANR_EINVAL, "overfetch must be in 0..%d", kMaxSel);
+      h->overfetch = (int)value;
+      break;
+    case ANR_OPT_SAMPLE_ROWS:
+      if (value < 0 || value > (1 << 20)) return fail(ANR_EINVAL, "sample rows must be in 0..2^20");
+      h->sample_rows = (int)round_up(value, kTileRows);
+      break;
+    case ANR_OPT_CAND_CAP:
+      if (value < 1024 || value > (1 << 22)) return fail(ANR_EINVAL, "candidate capacity must be in 1024..2^22");
+      h->cand_cap = value;
+      break;
+    case ANR_OPT_TIMING: h->timing = value != 0; break;
+    default: return fail(ANR_EINVAL, "unknown option %d", opt);
+  }
+  return ANR_OK;
+}
+
+int anr_index_last_stats(anr_index *h, anr_search_stats *out) {
+  if (!h || !out) return fail(ANR_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(h->mu);
+  *out = h->stats;
+  return ANR_OK;
+}
+
+int anr_normalize_rows(float *x_host, int64_t n, int32_t d, int32_t device) {
+  if (!x_host || n < 0 || d <= 0) return fail(ANR_EINVAL, "bad argument");
+  if (n == 0) return ANR_OK;
+  anr_index *h = nullptr;
+  ANR_TRY(anr_index_create(d, ANR_METRIC_IP, 1, device, &h));
+  int rc = ANR_OK;
+  const int64_t chunk = std::max<int64_t>(1, (int64_t)(256ll << 20) / ((int64_t)d * 4));
+  for (int64_t i = 0; i < n && rc == ANR_OK; i += chunk) {
+    const int64_t m = std::min(chunk, n - i);
+    rc = anr_index_reset(h);
+    if (rc == ANR_OK) rc = anr_index_add(h, x_host + i * d, m);
+    if (rc == ANR_OK) rc = anr_index_reconstruct(h, 0, m, x_host + i * d);
+  }
+  anr_index_destroy(h);
+  return rc;
+}
+
+int anr_merge_topk_dev(int32_t device, const float *Dp_dev, const int64_t *Ip_dev, int32_t P, int64_t nq, int32_t k,
+                       int32_t larger_is_better, float *D_dev, int64_t *I_dev, void *stream) {
+  if (!Dp_dev || !Ip_dev || !D_dev || !I_dev || P <= 0 || nq < 0 || k <= 0) return fail(ANR_EINVAL, "bad argument");
+  if (nq == 0) return ANR_OK;
+  DeviceGuard g(device);
+  if (!g.ok) return fail(ANR_EHIP, "hipSetDevice(%d) failed", device);
+  MergeParams mp{Dp_dev, Ip_dev, P, nq, k, larger_is_better, D_dev, I_dev};
+  hipLaunchKernelGGL(k_merge, dim3((unsigned)nq), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), mp);
+  ANR_HIP(hipGetLastError());
+  return ANR_OK;
+}
+
+}  // extern "C"

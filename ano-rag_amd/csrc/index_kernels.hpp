@@ -1,0 +1,788 @@
+// Device kernels of the exact flat index (CDNA4 / gfx950 only).
+//
+// Data layout in HBM:
+//   x32  [cap][dim]                    float32 row-major — the stored (normalised) corpus, used for the
+//                                      exact re-score and for reconstruct;
+//   x16  [cap/32][KB][64 lanes][8]     f16, "MFMA-blocked": one 1-KiB block is exactly the A operand of
+//                                      one v_mfma_f32_32x32x16_f16 for 32 rows x 16 dims, so a wave's
+//                                      16-B/lane load is one contiguous KiB and lands in operand layout;
+//   q16  [2][KB][64 lanes][8]          f16, the 64 queries of a batch in the B-operand layout.
+// KB = dimp/16 with dimp = dim rounded up to 128.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace anr {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int kTileRows = 32;    // corpus rows per MFMA tile
+constexpr int kQB = 64;          // queries per scan batch
+constexpr int kLadder = 8;       // threshold ladder levels
+constexpr int kMaxSel = 1024;    // max entries a select can return
+
+__device__ __forceinline__ unsigned f2ord(float f) {
+  // monotone float -> uint (NaN maps below everything)
+  if (f != f) return 0u;
+  unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned o) {
+  unsigned u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+  return __uint_as_float(u);
+}
+__device__ __forceinline__ unsigned long long make_key(float rank, unsigned row) {
+  // descending key order == (rank desc, row asc)
+  return ((unsigned long long)f2ord(rank) << 32) | (unsigned long long)(0xffffffffu - row);
+}
+
+// ------------------------------------------------------------------------------------------------
+// add: normalise (optional), store x32, convert to the blocked f16 image, track norm / error maxima
+// ------------------------------------------------------------------------------------------------
+struct AddParams {
+  const float *xin;   // [n][dim] rows being appended
+  int64_t n;
+  int64_t row0;       // global index of xin row 0 (== ntotal before the add)
+  int dim, dimp, kb;
+  int normalize;
+  float *x32;
+  _Float16 *x16;
+  float *rowbias;     // [cap] -0.5*||x||^2 of the stored row (L2 metric) or nullptr
+  unsigned *stat;     // [0] max ||x|| bits, [1] max ||x16 - x|| bits (floats >= 0, so uint order == float
+                      // order), [2] != 0 when some |x| exceeds the f16 range (scan disabled)
+};
+
+// one block (256 threads) per 32-row tile that receives rows
+__global__ __launch_bounds__(256) void k_add(AddParams p) {
+  __shared__ float s_scale[kTileRows];
+  __shared__ float s_err[kTileRows];
+  __shared__ float s_n2[kTileRows];
+  __shared__ float s_x[kTileRows][132];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t tile = p.row0 / kTileRows + blockIdx.x;
+  const int64_t trow0 = tile * kTileRows;
+
+  // per-row norms: wave w handles rows w, w+4, ...
+  for (int r = wave; r < kTileRows; r += 4) {
+    const int64_t grow = trow0 + r;
+    const int64_t src = grow - p.row0;
+    double acc = 0.0;
+    if (src >= 0 && src < p.n) {
+      const float *x = p.xin + src * p.dim;
+      for (int k = lane; k < p.dim; k += 64) {
+        double v = (double)x[k];
+        acc += v * v;
+      }
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (lane == 0) {
+      float nrm = (float)sqrt(acc);  // correctly rounded ||x|| in f32
+      float scale = 1.0f;
+      if (p.normalize && nrm != 0.0f) scale = nrm;  // divide by the norm (vector_index.py:277-280)
+      s_scale[r] = scale;
+      s_err[r] = 0.0f;
+      s_n2[r] = 0.0f;
+    }
+  }
+  __syncthreads();
+
+  for (int k0 = 0; k0 < p.dimp; k0 += 128) {
+    // stage 32 x 128 floats (normalised) through LDS, writing x32 on the way
+    for (int i = tid; i < kTileRows * 128; i += 256) {
+      const int r = i >> 7, c = i & 127;
+      const int64_t grow = trow0 + r;
+      const int64_t src = grow - p.row0;
+      const int k = k0 + c;
+      float v = 0.0f;
+      const bool live = (src >= 0 && src < p.n);
+      if (live && k < p.dim) {
+        v = p.xin[src * p.dim + k] / s_scale[r];
+        p.x32[grow * p.dim + k] = v;
+      }
+      s_x[r][c] = v;
+    }
+    __syncthreads();
+    // 8 k-blocks x 64 lanes x 16 B
+    for (int i = tid; i < 8 * 64; i += 256) {
+      const int kbl = i >> 6, l = i & 63;
+      const int r = l & 31, h = l >> 5;
+      const int64_t grow = trow0 + r;
+      const int64_t src = grow - p.row0;
+      if (src >= 0 && src < p.n) {
+        half8 hv;
+        float e2 = 0.0f, n2 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float v = s_x[r][kbl * 16 + h * 8 + j];
+          _Float16 q = (_Float16)v;
+          hv[j] = q;
+          float d = (float)q - v;
+          if (fabsf(v) > 65504.0f) atomicOr(&p.stat[2], 1u);
+          e2 += d * d;
+          n2 += v * v;
+        }
+        const int64_t blk = tile * p.kb + (k0 >> 4) + kbl;
+        *reinterpret_cast<half8 *>(p.x16 + (blk * 64 + l) * 8) = hv;
+        atomicAdd(&s_err[r], e2);
+        atomicAdd(&s_n2[r], n2);
+      }
+    }
+    __syncthreads();
+  }
+  if (tid < kTileRows) {
+    const int64_t grow = trow0 + tid;
+    const int64_t src = grow - p.row0;
+    if (src >= 0 && src < p.n) {
+      // 1.0001: slack for the f32 accumulation of the partial sums above
+      atomicMax(&p.stat[0], __float_as_uint(sqrtf(s_n2[tid]) * 1.0001f));
+      atomicMax(&p.stat[1], __float_as_uint(sqrtf(s_err[tid]) * 1.0001f));
+      if (p.rowbias) p.rowbias[grow] = -0.5f * s_n2[tid];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// prepq: one block per query slot: normalise, keep f32 copy, build the blocked f16 B operand
+// ------------------------------------------------------------------------------------------------
+struct PrepQParams {
+  const float *qin;  // [nq][dim]
+  int nq, dim, dimp, kb, normalize;
+  float *q32;        // [64][dimp]
+  _Float16 *q16;     // [2][kb][64][8]
+  float *qstat;      // [64][4]: ||q||, ||q16||, ||q16 - q||, ||q||^2
+};
+
+__global__ __launch_bounds__(256) void k_prepq(PrepQParams p) {
+  __shared__ double s_red[4];
+  __shared__ float s_scale;
+  const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool live = q < p.nq;
+  double acc = 0.0;
+  if (live)
+    for (int k = tid; k < p.dim; k += 256) {
+      double v = (double)p.qin[(int64_t)q * p.dim + k];
+      acc += v * v;
+    }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if (lane == 0) s_red[wave] = acc;
+  __syncthreads();
+  if (tid == 0) {
+    float nrm = (float)sqrt(s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+    s_scale = (p.normalize && nrm != 0.0f) ? nrm : 1.0f;
+  }
+  __syncthreads();
+  const float scale = s_scale;
+  double n2 = 0.0, h2 = 0.0, e2 = 0.0;
+  const int qb = q >> 5, col = q & 31;
+  for (int k = tid; k < p.dimp; k += 256) {
+    float v = (live && k < p.dim) ? p.qin[(int64_t)q * p.dim + k] / scale : 0.0f;
+    p.q32[(int64_t)q * p.dimp + k] = v;
+    _Float16 hq = (_Float16)v;
+    const int kbl = k >> 4, h = (k >> 3) & 1, j = k & 7;
+    p.q16[(((int64_t)qb * p.kb + kbl) * 64 + col + 32 * h) * 8 + j] = hq;
+    double dv = v, dh = (double)(float)hq;
+    n2 += dv * dv;
+    h2 += dh * dh;
+    e2 += (dh - dv) * (dh - dv);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    n2 += __shfl_xor(n2, off);
+    h2 += __shfl_xor(h2, off);
+    e2 += __shfl_xor(e2, off);
+  }
+  __shared__ double s_r3[4][3];
+  if (lane == 0) {
+    s_r3[wave][0] = n2;
+    s_r3[wave][1] = h2;
+    s_r3[wave][2] = e2;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double a = 0, b = 0, c = 0;
+    for (int w = 0; w < 4; ++w) {
+      a += s_r3[w][0];
+      b += s_r3[w][1];
+      c += s_r3[w][2];
+    }
+    p.qstat[q * 4 + 0] = (float)sqrt(a) * 1.0001f;
+    p.qstat[q * 4 + 1] = (float)sqrt(b) * 1.0001f;
+    p.qstat[q * 4 + 2] = (float)sqrt(c) * 1.0001f;
+    p.qstat[q * 4 + 3] = (float)a;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// scan: the dominant kernel.  Streams the blocked f16 corpus once; per 32-row tile a wave runs
+// KB x 2 MFMAs (32 rows x 64 queries), then either writes the score tile densely (DENSE) or appends
+// the scores that pass the per-query running threshold to the per-query candidate lists.
+// ------------------------------------------------------------------------------------------------
+struct ScanParams {
+  const uint4 *x16;
+  const uint4 *q16;
+  int kb;
+  int64_t n_rows;
+  int64_t tile0, tile_stride, n_tiles;  // tiles visited: tile0 + i*tile_stride, i < n_tiles
+  const float *rowbias;                 // L2: rank = q.x - 0.5*||x||^2 ; nullptr for IP
+  // DENSE
+  float *dense;      // [64][dense_ld], column = i*32 + row-in-tile
+  int64_t dense_ld;
+  // sparse
+  const float *ladder;   // [64][kLadder] ascending thresholds from the sample
+  unsigned *lhist;       // [64][kLadder] emitted-candidate histogram over the ladder levels
+  unsigned *cnt;         // [64]
+  uint2 *cand;           // [64][cap] (rank-score bits, row)
+  unsigned cap;
+  unsigned kprime;
+};
+
+__device__ __forceinline__ uint4 ld16(const uint4 *p) { return *p; }
+
+template <int CH>
+__device__ __forceinline__ void scan_load(uint4 (&a)[CH], const uint4 *xa, int kbase) {
+#pragma unroll
+  for (int j = 0; j < CH; ++j) a[j] = ld16(xa + (int64_t)(kbase + j) * 64);
+}
+
+template <int CH>
+__device__ __forceinline__ void scan_mfma(const uint4 (&a)[CH], const uint4 *ldsq0, const uint4 *ldsq1,
+                                          int kbase, floatx16 &acc0, floatx16 &acc1) {
+#pragma unroll
+  for (int j = 0; j < CH; ++j) {
+    const uint4 b0 = ldsq0[(kbase + j) * 64];
+    const uint4 b1 = ldsq1[(kbase + j) * 64];
+    const half8 av = __builtin_bit_cast(half8, a[j]);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(half8, b0), acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(half8, b1), acc1, 0, 0, 0);
+  }
+}
+
+__device__ __forceinline__ unsigned ld_relaxed(const unsigned *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <bool DENSE, int CH, int NT>
+__global__ __launch_bounds__(NT) void k_scan(ScanParams p) {
+  extern __shared__ uint4 lds[];  // Q operand image [2][kb][64] then the ladder [64][kLadder]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nthreads = blockDim.x, nwaves = nthreads >> 6;
+  const int nq16 = 2 * p.kb * 64;
+  for (int i = tid; i < nq16; i += nthreads) lds[i] = p.q16[i];
+  float *lad = reinterpret_cast<float *>(lds + nq16);
+  if (!DENSE)
+    for (int i = tid; i < kQB * kLadder; i += nthreads) lad[i] = p.ladder[i];
+  __syncthreads();
+
+  const uint4 *ldsq0 = lds + lane;
+  const uint4 *ldsq1 = lds + p.kb * 64 + lane;
+  const int q0 = lane & 31, half = lane >> 5;
+  const int64_t wglobal = (int64_t)blockIdx.x * nwaves + wave;
+  const int64_t wtotal = (int64_t)gridDim.x * nwaves;
+  const int nch = p.kb / CH;  // even by construction (kb % (2*CH) == 0)
+
+  for (int64_t i = wglobal; i < p.n_tiles; i += wtotal) {
+    const int64_t tile = p.tile0 + i * p.tile_stride;
+    const uint4 *xa = p.x16 + tile * p.kb * 64 + lane;
+    floatx16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc0[r] = 0.0f;
+      acc1[r] = 0.0f;
+    }
+    uint4 aA[CH], aB[CH];
+    scan_load<CH>(aA, xa, 0);
+    for (int c = 0; c < nch; c += 2) {
+      scan_load<CH>(aB, xa, (c + 1) * CH);
+      scan_mfma<CH>(aA, ldsq0, ldsq1, c * CH, acc0, acc1);
+      if (c + 2 < nch) scan_load<CH>(aA, xa, (c + 2) * CH);
+      scan_mfma<CH>(aB, ldsq0, ldsq1, (c + 1) * CH, acc0, acc1);
+    }
+
+    const int64_t row_base = tile * kTileRows + 4 * half;
+    if (p.rowbias) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 b = *reinterpret_cast<const float4 *>(p.rowbias + row_base + 8 * g);
+        acc0[4 * g + 0] += b.x; acc0[4 * g + 1] += b.y; acc0[4 * g + 2] += b.z; acc0[4 * g + 3] += b.w;
+        acc1[4 * g + 0] += b.x; acc1[4 * g + 1] += b.y; acc1[4 * g + 2] += b.z; acc1[4 * g + 3] += b.w;
+      }
+    }
+
+    if (DENSE) {
+      const float ninf = -__builtin_inff();
+      float *d0 = p.dense + (int64_t)q0 * p.dense_ld + i * kTileRows + 4 * half;
+      float *d1 = d0 + 32 * p.dense_ld;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int64_t r0 = row_base + 8 * g;
+        float4 v0, v1;
+        v0.x = (r0 + 0 < p.n_rows) ? acc0[4 * g + 0] : ninf;
+        v0.y = (r0 + 1 < p.n_rows) ? acc0[4 * g + 1] : ninf;
+        v0.z = (r0 + 2 < p.n_rows) ? acc0[4 * g + 2] : ninf;
+        v0.w = (r0 + 3 < p.n_rows) ? acc0[4 * g + 3] : ninf;
+        v1.x = (r0 + 0 < p.n_rows) ? acc1[4 * g + 0] : ninf;
+        v1.y = (r0 + 1 < p.n_rows) ? acc1[4 * g + 1] : ninf;
+        v1.z = (r0 + 2 < p.n_rows) ? acc1[4 * g + 2] : ninf;
+        v1.w = (r0 + 3 < p.n_rows) ? acc1[4 * g + 3] : ninf;
+        *reinterpret_cast<float4 *>(d0 + 8 * g) = v0;
+        *reinterpret_cast<float4 *>(d1 + 8 * g) = v1;
+      }
+    } else {
+      // running thresholds of this lane's two queries: highest ladder level already reached by
+      // >= kprime emitted rows (each row is scored once, so the count is of distinct rows)
+      float tau0 = lad[q0 * kLadder], tau1 = lad[(q0 + 32) * kLadder];
+      {
+        unsigned c0 = 0, c1 = 0;
+        bool f0 = false, f1 = false;
+#pragma unroll
+        for (int j = kLadder - 1; j >= 1; --j) {
+          c0 += ld_relaxed(p.lhist + q0 * kLadder + j);
+          c1 += ld_relaxed(p.lhist + (q0 + 32) * kLadder + j);
+          if (!f0 && c0 >= p.kprime) { tau0 = lad[q0 * kLadder + j]; f0 = true; }
+          if (!f1 && c1 >= p.kprime) { tau1 = lad[(q0 + 32) * kLadder + j]; f1 = true; }
+        }
+      }
+      float m0 = acc0[0], m1 = acc1[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) {
+        m0 = fmaxf(m0, acc0[r]);
+        m1 = fmaxf(m1, acc1[r]);
+      }
+      if (__any((m0 >= tau0) || (m1 >= tau1))) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = row_base + (r & 3) + 8 * (r >> 2);
+          const bool live = row < p.n_rows;
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const float s = b ? acc1[r] : acc0[r];
+            const float tau = b ? tau1 : tau0;
+            if (live && s >= tau) {
+              const int q = q0 + 32 * b;
+              const unsigned pos = atomicAdd(p.cnt + q, 1u);
+              if (pos < p.cap) p.cand[(int64_t)q * p.cap + pos] = make_uint2(__float_as_uint(s), (unsigned)row);
+              int lvl = 0;
+#pragma unroll
+              for (int j = 1; j < kLadder; ++j) lvl += (s >= lad[q * kLadder + j]) ? 1 : 0;
+              if (lvl > 0) atomicAdd(p.lhist + q * kLadder + lvl, 1u);
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// select: one block per query; radix-select the M largest 64-bit keys (rank desc, row asc) from a
+// dense score row or a candidate list, sort them, write (rank, row) and optionally the ladder.
+// ------------------------------------------------------------------------------------------------
+struct SelParams {
+  // dense input (dense != nullptr): n entries per query, entry i -> row = (i/32)*row_tile_stride*32 + row0 + i%32
+  const float *dense;
+  int64_t dense_ld;
+  int64_t n;
+  int64_t row0, row_tile_stride;
+  int negate;            // rank = -value (ascending select, L2 distances)
+  // list input
+  const uint2 *cand;
+  const unsigned *cnt;
+  unsigned cap;
+  int M;                 // entries wanted (<= kMaxSel)
+  const int *qmap;       // optional: block b handles query slot qmap[b]
+  // outputs, [64][kMaxSel]
+  float *out_rank;
+  unsigned *out_row;
+  int *out_m;            // entries written per query
+  float *ladder;         // optional [64][kLadder]
+  unsigned *overflow;    // optional [64]: set when cnt > cap
+};
+
+__device__ __forceinline__ unsigned long long sel_key(const SelParams &p, int q, int64_t i) {
+  if (p.dense) {
+    float v = p.dense[(int64_t)q * p.dense_ld + i];
+    if (p.negate) v = -v;
+    const int64_t row = (i >> 5) * p.row_tile_stride * 32 + p.row0 + (i & 31);
+    return make_key(v, (unsigned)row);
+  }
+  const uint2 c = p.cand[(int64_t)q * p.cap + i];
+  return make_key(__uint_as_float(c.x), c.y);
+}
+
+__global__ __launch_bounds__(1024) void k_select(SelParams p) {
+  __shared__ unsigned hist[256];
+  __shared__ unsigned long long sel[kMaxSel];
+  __shared__ unsigned long long s_red[16][2];
+  __shared__ unsigned s_cnt;
+  __shared__ int s_d;
+  __shared__ unsigned s_above, s_h;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = p.qmap ? p.qmap[blockIdx.x] : blockIdx.x;
+  int64_t n;
+  if (p.dense) {
+    n = p.n;
+  } else {
+    const unsigned c = p.cnt[q];
+    n = c < p.cap ? c : p.cap;
+    if (p.overflow && tid == 0) p.overflow[q] = (c > p.cap) ? 1u : 0u;
+  }
+  const int M = (int)((int64_t)p.M < n ? (int64_t)p.M : n);
+  if (tid == 0) p.out_m[q] = M;
+  if (M == 0) {
+    if (p.ladder && tid < kLadder) p.ladder[q * kLadder + tid] = -__builtin_inff();
+    return;
+  }
+
+  // common leading bytes of all keys -> skip those passes (also avoids one-bin LDS atomic storms)
+  unsigned long long kmin = ~0ull, kmax = 0ull;
+  for (int64_t i = tid; i < n; i += 1024) {
+    const unsigned long long k = sel_key(p, q, i);
+    kmin = k < kmin ? k : kmin;
+    kmax = k > kmax ? k : kmax;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long a = __shfl_xor(kmin, off), b = __shfl_xor(kmax, off);
+    kmin = a < kmin ? a : kmin;
+    kmax = b > kmax ? b : kmax;
+  }
+  if (lane == 0) {
+    s_red[wave][0] = kmin;
+    s_red[wave][1] = kmax;
+  }
+  __syncthreads();
+  kmin = s_red[0][0];
+  kmax = s_red[0][1];
+  for (int w = 1; w < 16; ++w) {
+    kmin = s_red[w][0] < kmin ? s_red[w][0] : kmin;
+    kmax = s_red[w][1] > kmax ? s_red[w][1] : kmax;
+  }
+  int bits = 0;
+  while (bits < 64 && (kmin >> (56 - bits)) == (kmax >> (56 - bits))) bits += 8;
+  unsigned long long prefix = bits ? (kmax >> (64 - bits)) : 0ull;
+  unsigned need = (unsigned)M;
+  bool whole = (bits == 64);  // all keys equal cannot happen (rows differ) unless n == 1
+  while (!whole && bits < 64) {
+    for (int i = tid; i < 256; i += 1024) hist[i] = 0;
+    __syncthreads();
+    for (int64_t i = tid; i < n; i += 1024) {
+      const unsigned long long k = sel_key(p, q, i);
+      if (bits == 0 || (k >> (64 - bits)) == prefix) atomicAdd(&hist[(unsigned)(k >> (56 - bits)) & 255u], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned c = 0;
+      int d = 255;
+      for (; d > 0; --d) {
+        if (c + hist[d] >= need) break;
+        c += hist[d];
+      }
+      s_d = d;
+      s_above = c;
+      s_h = hist[d];
+    }
+    __syncthreads();
+    need -= s_above;
+    prefix = (prefix << 8) | (unsigned long long)s_d;
+    bits += 8;
+    if (s_h == need) whole = true;  // every key under this prefix is wanted
+    __syncthreads();
+  }
+  // gather keys whose leading `bits` bits are >= prefix: exactly M of them
+  if (tid == 0) s_cnt = 0;
+  __syncthreads();
+  for (int64_t i = tid; i < n; i += 1024) {
+    const unsigned long long k = sel_key(p, q, i);
+    if (bits == 0 || (k >> (64 - bits)) >= prefix) {
+      const unsigned pos = atomicAdd(&s_cnt, 1u);
+      if (pos < (unsigned)kMaxSel) sel[pos] = k;
+    }
+  }
+  __syncthreads();
+  int Mp = 1;
+  while (Mp < M) Mp <<= 1;
+  for (int i = M + tid; i < Mp; i += 1024) sel[i] = 0ull;
+  __syncthreads();
+  // bitonic sort, descending
+  for (int k2 = 2; k2 <= Mp; k2 <<= 1) {
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < Mp; i += 1024) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long a = sel[i], b = sel[ixj];
+          const bool desc = ((i & k2) == 0);
+          if (desc ? (a < b) : (a > b)) {
+            sel[i] = b;
+            sel[ixj] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = tid; i < M; i += 1024) {
+    const unsigned long long k = sel[i];
+    float v = ord2f((unsigned)(k >> 32));
+    p.out_rank[q * kMaxSel + i] = p.negate ? -v : v;
+    p.out_row[q * kMaxSel + i] = 0xffffffffu - (unsigned)(k & 0xffffffffu);
+  }
+  if (p.ladder && tid < kLadder) {
+    // level j = value of rank max(1, M >> j) (1-based) of the sample: ascending in j
+    int rk = M >> tid;
+    if (rk < 1 || tid == kLadder - 1) rk = 1;
+    p.ladder[q * kLadder + tid] = ord2f((unsigned)(sel[rk - 1] >> 32));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// rescore: one wave per (query, candidate): exact value from the f32 rows, f64 accumulation
+// ------------------------------------------------------------------------------------------------
+struct RescoreParams {
+  const float *x32;
+  const float *q32;   // [64][dimp]
+  int dim, dimp;
+  int metric;         // ANR_METRIC_*
+  const unsigned *sel_row;  // [64][kMaxSel]
+  const int *sel_m;
+  float *exact;       // [64][kMaxSel]
+  int M;
+};
+
+__global__ __launch_bounds__(256) void k_rescore(RescoreParams p) {
+  const int lane = threadIdx.x & 63;
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int q = w / p.M, j = w % p.M;
+  if (q >= kQB || j >= p.sel_m[q]) return;
+  const unsigned row = p.sel_row[q * kMaxSel + j];
+  const float *x = p.x32 + (int64_t)row * p.dim;
+  const float *qv = p.q32 + (int64_t)q * p.dimp;
+  double acc = 0.0;
+  if (p.metric == 0) {
+    for (int k = lane; k < p.dim; k += 64) acc += (double)x[k] * (double)qv[k];
+  } else {
+    for (int k = lane; k < p.dim; k += 64) {
+      const double d = (double)qv[k] - (double)x[k];
+      acc += d * d;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if (lane == 0) p.exact[q * kMaxSel + j] = (float)acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// finalize: per query sort the re-scored candidates, write the top-k, decide the certificate
+// ------------------------------------------------------------------------------------------------
+struct FinalParams {
+  const float *exact;        // [64][kMaxSel]
+  const float *approx;       // [64][kMaxSel] approximate rank score, sorted desc
+  const unsigned *sel_row;
+  const int *sel_m;
+  const unsigned *overflow;  // may be null
+  const float *qstat;        // [64][4]
+  const unsigned *xstat;     // [2] bits of max ||x||, max ||x16-x||
+  int metric, dimp;
+  int64_t n_rows;
+  int M;                     // overfetch requested of the select
+  int k;
+  int nq;
+  int64_t out_off;           // first query of this batch in D/I
+  float *D;
+  int64_t *I;
+  int *flags;                // [64] 0 = certified, 1 = needs the exact path
+  int64_t id_offset;
+};
+
+__global__ __launch_bounds__(256) void k_finalize(FinalParams p) {
+  __shared__ unsigned long long sel[kMaxSel];
+  const int q = blockIdx.x, tid = threadIdx.x;
+  if (q >= p.nq) return;
+  const int m = p.sel_m[q];
+  int Mp = 1;
+  while (Mp < m) Mp <<= 1;
+  for (int i = tid; i < Mp; i += 256) {
+    unsigned long long k = 0ull;
+    if (i < m) {
+      const float e = p.exact[q * kMaxSel + i];
+      k = make_key(p.metric == 0 ? e : -e, p.sel_row[q * kMaxSel + i]);
+    }
+    sel[i] = k;
+  }
+  __syncthreads();
+  for (int k2 = 2; k2 <= Mp; k2 <<= 1) {
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < Mp; i += 256) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long a = sel[i], b = sel[ixj];
+          const bool desc = ((i & k2) == 0);
+          if (desc ? (a < b) : (a > b)) {
+            sel[i] = b;
+            sel[ixj] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  const int kk = p.k < m ? p.k : m;
+  float *D = p.D + (p.out_off + q) * (int64_t)p.k;
+  int64_t *I = p.I + (p.out_off + q) * (int64_t)p.k;
+  for (int i = tid; i < p.k; i += 256) {
+    if (i < kk) {
+      const unsigned long long k = sel[i];
+      const float v = ord2f((unsigned)(k >> 32));
+      D[i] = p.metric == 0 ? v : -v;
+      I[i] = (int64_t)(0xffffffffu - (unsigned)(k & 0xffffffffu)) + p.id_offset;
+    } else {
+      D[i] = p.metric == 0 ? -3.402823466e+38f : 3.402823466e+38f;
+      I[i] = -1;
+    }
+  }
+  if (tid == 0) {
+    int flag = 0;
+    if (p.overflow && p.overflow[q]) flag = 1;
+    if (kk > 0 && (int64_t)m < p.n_rows) {
+      // rows outside the candidate set have approx rank <= approx[m-1]; their exact rank is at most
+      // that + eps.  Certified when even that cannot reach the k-th exact rank.
+      const float xmax = __uint_as_float(p.xstat[0]), xerr = __uint_as_float(p.xstat[1]);
+      const float qn = p.qstat[q * 4 + 0], qh = p.qstat[q * 4 + 1], qe = p.qstat[q * 4 + 2];
+      double eps = (double)xerr * qh + (double)xmax * qe + 2.0 * p.dimp * 5.9604645e-8 * (double)xmax * qn;
+      if (p.metric != 0) eps += 1e-6 * (double)xmax * (double)xmax;  // f32 rounding of the stored -0.5||x||^2
+      const double bound = (double)p.approx[q * kMaxSel + m - 1] + eps;
+      double kth = (double)ord2f((unsigned)(sel[kk - 1] >> 32));  // exact rank score of the k-th result
+      if (p.metric != 0) kth = 0.5 * (kth + (double)p.qstat[q * 4 + 3]);  // -dist -> q.x - 0.5||x||^2
+      if (m < p.M || !(bound < kth)) flag = 1;
+      if (m >= p.M && kk < p.k) flag = 1;
+    }
+    p.flags[q] = flag;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// exact dense path: exact values of up to 4 queries against every row (f32 rows, f64 accumulate)
+// ------------------------------------------------------------------------------------------------
+struct ExactParams {
+  const float *x32;
+  const float *q32;    // [64][dimp]
+  int dim, dimp, metric;
+  int64_t n_rows;
+  int nf;              // 1..4 queries
+  int qidx[4];
+  float *dense;        // [4][ld]
+  int64_t ld;
+};
+
+__global__ __launch_bounds__(256) void k_exact_dense(ExactParams p) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t wt = (int64_t)gridDim.x * 4;
+  for (int64_t row = w0; row < p.n_rows; row += wt) {
+    const float *x = p.x32 + row * p.dim;
+    double acc[4] = {0, 0, 0, 0};
+    for (int k = lane; k < p.dim; k += 64) {
+      const double xv = (double)x[k];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        if (f < p.nf) {
+          const double qv = (double)p.q32[(int64_t)p.qidx[f] * p.dimp + k];
+          if (p.metric == 0) acc[f] += xv * qv;
+          else acc[f] += (qv - xv) * (qv - xv);
+        }
+      }
+    }
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+      for (int off = 32; off > 0; off >>= 1) acc[f] += __shfl_xor(acc[f], off);
+    if (lane == 0)
+      for (int f = 0; f < p.nf; ++f) p.dense[(int64_t)f * p.ld + row] = (float)acc[f];
+  }
+}
+
+// write a select result (already exact values) as final output rows
+struct EmitParams {
+  const float *rank;       // [64][kMaxSel] (values as stored, i.e. distances for L2)
+  const unsigned *row;
+  const int *m;
+  int nf;
+  int slot[4];             // select slot of each query
+  int64_t outq[4];         // output row of each query
+  int k, metric;
+  float *D;
+  int64_t *I;
+  int64_t id_offset;
+};
+
+__global__ __launch_bounds__(256) void k_emit(EmitParams p) {
+  const int f = blockIdx.x;
+  if (f >= p.nf) return;
+  const int s = p.slot[f];
+  const int m = p.m[s];
+  for (int i = threadIdx.x; i < p.k; i += 256) {
+    float *D = p.D + p.outq[f] * (int64_t)p.k;
+    int64_t *I = p.I + p.outq[f] * (int64_t)p.k;
+    if (i < m) {
+      D[i] = p.rank[s * kMaxSel + i];
+      I[i] = (int64_t)p.row[s * kMaxSel + i] + p.id_offset;
+    } else {
+      D[i] = p.metric == 0 ? -3.402823466e+38f : 3.402823466e+38f;
+      I[i] = -1;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// merge of P sorted partial lists per query (row-sharded corpus)
+// ------------------------------------------------------------------------------------------------
+struct MergeParams {
+  const float *Dp;
+  const int64_t *Ip;
+  int P;
+  int64_t nq;
+  int k;
+  int larger;
+  float *D;
+  int64_t *I;
+};
+
+__device__ __forceinline__ bool merge_before(float sa, int64_t ia, float sb, int64_t ib, int larger) {
+  // true when (sa, ia) is ordered strictly before (sb, ib); padding (-1) goes last
+  if (ia < 0) return false;
+  if (ib < 0) return true;
+  if (sa != sb) return larger ? (sa > sb) : (sa < sb);
+  return ia < ib;
+}
+
+__global__ __launch_bounds__(256) void k_merge(MergeParams p) {
+  const int64_t q = blockIdx.x;
+  const int total = p.P * p.k;
+  for (int i = threadIdx.x; i < p.k; i += 256) {
+    p.D[q * p.k + i] = p.larger ? -3.402823466e+38f : 3.402823466e+38f;
+    p.I[q * p.k + i] = -1;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < total; e += 256) {
+    const int pe = e / p.k, je = e % p.k;
+    const float s = p.Dp[((int64_t)pe * p.nq + q) * p.k + je];
+    const int64_t id = p.Ip[((int64_t)pe * p.nq + q) * p.k + je];
+    if (id < 0) continue;
+    int rank = je;  // entries of its own list that precede it
+    for (int po = 0; po < p.P; ++po) {
+      if (po == pe) continue;
+      const float *Do = p.Dp + ((int64_t)po * p.nq + q) * p.k;
+      const int64_t *Io = p.Ip + ((int64_t)po * p.nq + q) * p.k;
+      int lo = 0, hi = p.k;  // count entries of list po ordered before (s, id)
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (merge_before(Do[mid], Io[mid], s, id, p.larger)) lo = mid + 1;
+        else hi = mid;
+      }
+      rank += lo;
+    }
+    if (rank < p.k) {
+      p.D[q * p.k + rank] = s;
+      p.I[q * p.k + rank] = id;
+    }
+  }
+}
+
+}  // namespace anr

@@ -1,0 +1,105 @@
+/*
+ * anorag.h — C ABI of libanorag_hip.so, the MI355X (gfx950) dense-retrieval hot path of AnoRAG.
+ *
+ * The reference (Kevinwu901113/ano-rag) is pure Python and has no FFI of its own; its hot path leaves
+ * the repo at three third-party calls.  Every entry point below replaces one of those call sites (cited
+ * per function as <reference file>:<line>).  The Python classes under ano-rag_amd/ (same names as the
+ * reference's: EmbeddingManager / VectorIndex / VectorRetriever / HybridSearcher) are the only callers.
+ *
+ * Conventions
+ *   - plain C types only; row-major float32 in/out, int64 ids, every buffer caller-allocated;
+ *   - every function returns 0 on success and a negative ANR_E* code on failure; the message for the
+ *     calling thread's last failure is anr_last_error();
+ *   - "host" pointers are ordinary process memory, "_dev" pointers are HIP device memory of the handle's
+ *     device; `stream` is a hipStream_t passed as void* (NULL = the handle's own stream);
+ *   - a handle serialises its own calls internally (searches on one handle may be issued from several
+ *     threads: reference query/query_processor.py:2761-2766 does exactly that).
+ */
+#ifndef ANORAG_H
+#define ANORAG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ANR_OK 0
+#define ANR_EINVAL (-1)   /* bad argument                                   */
+#define ANR_EHIP (-2)     /* a HIP runtime call failed (no device, OOM, …)  */
+#define ANR_ESTATE (-3)   /* call not valid in the handle's current state   */
+#define ANR_EINTERNAL (-4)
+
+#define ANR_METRIC_IP 0 /* larger is better; cosine == IP on rows normalised at add time */
+#define ANR_METRIC_L2 1 /* squared L2, smaller is better (faiss IndexFlatL2 convention)   */
+
+const char *anr_last_error(void);
+const char *anr_version(void);
+/* number of visible HIP devices (0 when there is none); never fails */
+int anr_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Exact flat index: replaces faiss.IndexFlatIP / IndexFlatL2 as used by
+ * vector_store/vector_index.py:77-80 (create), :187-196 (add), :223 (search), :415-426 (reset).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct anr_index anr_index;
+
+/* dim: embedding dimension; metric: ANR_METRIC_*; normalize != 0 → rows and queries are L2-normalised
+ * exactly as vector_index.py:265-282 does (zero-norm rows stay zero); device: HIP ordinal. */
+int anr_index_create(int32_t dim, int32_t metric, int32_t normalize, int32_t device, anr_index **out);
+int anr_index_destroy(anr_index *h);
+/* pre-size device storage for n rows (optional; add grows geometrically otherwise) */
+int anr_index_reserve(anr_index *h, int64_t n);
+/* append n rows; sequential ids continue from ntotal (IndexFlat.add, vector_index.py:196) */
+int anr_index_add(anr_index *h, const float *x_host, int64_t n);
+int anr_index_add_dev(anr_index *h, const float *x_dev, int64_t n, void *stream);
+int64_t anr_index_ntotal(const anr_index *h);
+int32_t anr_index_dim(const anr_index *h);
+int anr_index_reset(anr_index *h);
+/* copy the stored (already preprocessed) float32 rows [i0, i0+n) back to the host */
+int anr_index_reconstruct(anr_index *h, int64_t i0, int64_t n, float *out_host);
+
+/* Search nq queries for the k best rows (vector_index.py:223).  D[nq*k] scores best-first (inner
+ * product, or squared L2), I[nq*k] row ids, padded with -1 (and -FLT_MAX / +FLT_MAX scores) when
+ * k > ntotal, the faiss convention vector_index.py:234 relies on.  Ties in score are ordered by
+ * ascending id.  Results are the exact top-k of the stored float32 rows. */
+int anr_index_search(anr_index *h, const float *q_host, int64_t nq, int32_t k, float *D, int64_t *I);
+/* same with device buffers, asynchronous on `stream` apart from one small status read-back */
+int anr_index_search_dev(anr_index *h, const float *q_dev, int64_t nq, int32_t k, float *D_dev,
+                         int64_t *I_dev, void *stream);
+
+/* tuning / introspection */
+#define ANR_OPT_FORCE_EXACT 1     /* 1: skip the f16 scan, run the dense exact path for every query  */
+#define ANR_OPT_OVERFETCH 2       /* candidates kept per query before the exact re-score (0 = auto)  */
+#define ANR_OPT_SAMPLE_ROWS 3     /* rows of the threshold sample (0 = auto)                          */
+#define ANR_OPT_CAND_CAP 4        /* per-query candidate buffer entries                               */
+#define ANR_OPT_TIMING 5          /* 1: record HIP-event time of the scan kernel in stats             */
+int anr_index_set_option(anr_index *h, int32_t opt, int64_t value);
+
+typedef struct anr_search_stats {
+  int64_t n_queries;        /* queries of the last search call                                        */
+  int64_t n_fallback;       /* of those, answered by the dense exact path (certificate failed)         */
+  int64_t n_candidates;     /* candidates emitted by the scan, summed over queries                    */
+  int64_t n_overflow;       /* queries whose candidate buffer overflowed                               */
+  int64_t scan_bytes;       /* algorithmic bytes streamed by the dominant scan kernel (all launches)   */
+  int32_t overfetch;        /* candidates re-scored per query                                          */
+  int32_t sample_rows;
+  float scan_ms;            /* HIP-event time of the main scan launches (ANR_OPT_TIMING)              */
+  float total_ms;           /* HIP-event time of the whole call on the stream (ANR_OPT_TIMING)        */
+} anr_search_stats;
+int anr_index_last_stats(anr_index *h, anr_search_stats *out);
+
+/* In-place row normalisation on host memory through the device (vector_index.py:276-280): rows with
+ * zero norm are left unchanged. */
+int anr_normalize_rows(float *x_host, int64_t n, int32_t d, int32_t device);
+
+/* Merge P partial top-k lists per query (row-sharded corpus): Dp/Ip are [P][nq][k]
+ * device buffers holding GLOBAL ids, -1 padded; writes the best k per query to D/I [nq][k].
+ * larger_is_better selects the order.  Ties → lower id first. */
+int anr_merge_topk_dev(int32_t device, const float *Dp_dev, const int64_t *Ip_dev, int32_t P, int64_t nq,
+                       int32_t k, int32_t larger_is_better, float *D_dev, int64_t *I_dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ANORAG_H */
