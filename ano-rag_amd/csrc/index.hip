@@ -31,7 +31,7 @@ struct anr_index {
   int force_exact = 0;
   int overfetch = 0;
   int sample_rows = 0;
-  int64_t cand_cap = 8192;
+  int64_t cand_cap = 512;   // entries per (block, query) candidate list
   int timing = 0;
 
   // workspace (one batch)
@@ -42,9 +42,10 @@ struct anr_index {
   float *dense = nullptr;
   int64_t dense_ld = 0;
   float *ladder = nullptr;
-  unsigned *lhist = nullptr;  // [64][kLadder] followed by cnt [64]
-  unsigned *cnt = nullptr;
-  uint2 *cand = nullptr;
+  unsigned *lcum = nullptr;   // [64][kLadder][kCumStride]
+  unsigned *cntb = nullptr;   // [64][n_cu]
+  unsigned *ncand = nullptr;  // [64]
+  uint2 *cand = nullptr;      // [n_cu][64][cand_cap]
   int64_t cand_alloc = 0;
   float *sel_rank = nullptr;
   unsigned *sel_row = nullptr;
@@ -121,8 +122,9 @@ int ensure_workspace(anr_index *h) {
   ANR_TRY(dev_alloc(&h->qstat, kQB * 4, true));
   ANR_TRY(dev_alloc(&h->qstage, (int64_t)kQB * h->dim, true));
   ANR_TRY(dev_alloc(&h->ladder, kQB * kLadder, true));
-  ANR_TRY(dev_alloc(&h->lhist, kQB * kLadder + kQB, true));
-  h->cnt = h->lhist + kQB * kLadder;
+  ANR_TRY(dev_alloc(&h->lcum, (int64_t)kQB * kLadder * kCumStride, true));
+  ANR_TRY(dev_alloc(&h->cntb, (int64_t)kQB * h->n_cu, true));
+  ANR_TRY(dev_alloc(&h->ncand, kQB, true));
   ANR_TRY(dev_alloc(&h->sel_rank, kQB * kMaxSel, true));
   ANR_TRY(dev_alloc(&h->sel_row, kQB * kMaxSel, true));
   ANR_TRY(dev_alloc(&h->sel_m, kQB, true));
@@ -130,7 +132,7 @@ int ensure_workspace(anr_index *h) {
   ANR_TRY(dev_alloc(&h->exact, kQB * kMaxSel, true));
   ANR_TRY(dev_alloc(&h->flags, kQB, true));
   ANR_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->flags_host), kQB * sizeof(int), hipHostMallocDefault));
-  ANR_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->cnt_host), kQB * sizeof(unsigned), hipHostMallocDefault));
+  ANR_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->cnt_host), 2 * kQB * sizeof(unsigned), hipHostMallocDefault));
   for (auto &e : h->ev) ANR_HIP(hipEventCreate(&e));
   return ANR_OK;
 }
@@ -138,7 +140,7 @@ int ensure_workspace(anr_index *h) {
 int ensure_cand(anr_index *h) {
   if (h->cand && h->cand_alloc == h->cand_cap) return ANR_OK;
   dev_free(h->cand);
-  ANR_TRY(dev_alloc(&h->cand, (int64_t)kQB * h->cand_cap, false));
+  ANR_TRY(dev_alloc(&h->cand, (int64_t)h->n_cu * kQB * h->cand_cap, false));
   h->cand_alloc = h->cand_cap;
   return ANR_OK;
 }
@@ -150,16 +152,30 @@ int ensure_dense(anr_index *h, int64_t ld) {
   return dev_alloc(&h->dense, (int64_t)kQB * h->dense_ld, false);
 }
 
+int launch_select(int nblocks, const SelParams &sp, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    ANR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_select), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)sizeof(SelShared)));
+    attr_set = true;
+  }
+  if (sp.G > kSelMaxLists) return fail(ANR_EINTERNAL, "select: too many candidate lists (%d)", sp.G);
+  hipLaunchKernelGGL(k_select, dim3(nblocks), dim3(1024), sizeof(SelShared), st, sp);
+  ANR_HIP(hipGetLastError());
+  return ANR_OK;
+}
+
 template <bool DENSE>
-int launch_scan(anr_index *h, const ScanParams &p, hipStream_t st) {
+int launch_scan(anr_index *h, const ScanParams &p, hipStream_t st, int *grid_out = nullptr) {
   if (p.n_tiles <= 0) return ANR_OK;
-  const size_t lds = (size_t)2 * p.kb * 64 * 16 + kQB * kLadder * sizeof(float);
+  const size_t lds = (size_t)2 * p.kb * 64 * 16 + kQB * kLadder * 8 + kQB * 8;
   // 16 waves per block when there is enough work for every CU, else smaller blocks on more CUs
   int nwaves = 16;
   while (nwaves > 4 && ceil_div(p.n_tiles, nwaves) < h->n_cu) nwaves >>= 1;
   const int nt = nwaves * 64;
   int64_t grid = ceil_div(p.n_tiles, nwaves);
   if (grid > h->n_cu) grid = h->n_cu;
+  if (grid_out) *grid_out = (int)grid;
   if (p.kb % 16 == 0) {
     auto kern = k_scan<DENSE, 8, 1024>;
     ANR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -222,7 +238,7 @@ int run_exact(anr_index *h, const std::vector<int> &slots, int64_t out_off, int 
     sp.out_rank = h->sel_rank;
     sp.out_row = h->sel_row;
     sp.out_m = h->sel_m;
-    hipLaunchKernelGGL(k_select, dim3(nf), dim3(1024), 0, st, sp);
+    ANR_TRY(launch_select(nf, sp, st));
     EmitParams mp{};
     mp.rank = h->sel_rank;
     mp.row = h->sel_row;
@@ -276,7 +292,9 @@ int search_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_of
   const int M = auto_overfetch(h, k);
   const int64_t n_tiles = ceil_div(h->ntotal, kTileRows);
   const int64_t full_tiles = h->ntotal / kTileRows;
-  int64_t sample_tiles = (h->sample_rows > 0 ? h->sample_rows : 4096) / kTileRows;
+  // threshold sample: ~1/64 of the rows, between 4K and 32K (more rows -> tighter first threshold)
+  int64_t auto_sample = round_up(std::min<int64_t>(32768, std::max<int64_t>(4096, h->ntotal / 64)), 1024);
+  int64_t sample_tiles = (h->sample_rows > 0 ? h->sample_rows : auto_sample) / kTileRows;
   if (sample_tiles * kTileRows < 2 * M) sample_tiles = ceil_div(2 * M, kTileRows);
   const bool sparse = full_tiles >= 8 * sample_tiles;
 
@@ -311,7 +329,7 @@ int search_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_of
     sp.row0 = 0;
     sp.row_tile_stride = 1;
     sp.overflow = nullptr;
-    hipLaunchKernelGGL(k_select, dim3(nq), dim3(1024), 0, st, sp);
+    ANR_TRY(launch_select(nq, sp, st));
   } else {
     ANR_TRY(ensure_dense(h, sample_tiles * kTileRows));
     ANR_TRY(ensure_cand(h));
@@ -329,30 +347,34 @@ int search_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_of
     ss.row0 = 0;
     ss.row_tile_stride = sc.tile_stride;
     ss.ladder = h->ladder;
-    hipLaunchKernelGGL(k_select, dim3(kQB), dim3(1024), 0, st, ss);
-    ANR_HIP(hipMemsetAsync(h->lhist, 0, (kQB * kLadder + kQB) * sizeof(unsigned), st));
+    ss.lcum_zero = h->lcum;
+    ANR_TRY(launch_select(kQB, ss, st));
     // 2) the full scan
     sc.tile0 = 0;
     sc.tile_stride = 1;
     sc.n_tiles = n_tiles;
     sc.dense = nullptr;
     sc.ladder = h->ladder;
-    sc.lhist = h->lhist;
-    sc.cnt = h->cnt;
+    sc.lcum = h->lcum;
+    sc.cntb = h->cntb;
     sc.cand = h->cand;
-    sc.cap = (unsigned)h->cand_cap;
+    sc.capb = (unsigned)h->cand_cap;
     sc.kprime = (unsigned)M;
     if (h->timing) ANR_HIP(hipEventRecord(h->ev[0], st));
-    ANR_TRY(launch_scan<false>(h, sc, st));
+    int scan_grid = 0;
+    ANR_TRY(launch_scan<false>(h, sc, st, &scan_grid));
     if (h->timing) ANR_HIP(hipEventRecord(h->ev[1], st));
     h->stats.scan_bytes += n_tiles * kTileRows * (int64_t)h->dimp * 2;
     // 3) top-M of the candidates
     sp.cand = h->cand;
-    sp.cnt = h->cnt;
-    sp.cap = (unsigned)h->cand_cap;
+    sp.cntb = h->cntb;
+    sp.G = scan_grid;
+    sp.capb = (unsigned)h->cand_cap;
     sp.overflow = h->overflow;
-    hipLaunchKernelGGL(k_select, dim3(nq), dim3(1024), 0, st, sp);
-    ANR_HIP(hipMemcpyAsync(h->cnt_host, h->cnt, kQB * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    sp.ncand = h->ncand;
+    ANR_TRY(launch_select(nq, sp, st));
+    ANR_HIP(hipMemcpyAsync(h->cnt_host, h->ncand, kQB * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    ANR_HIP(hipMemcpyAsync(h->cnt_host + kQB, h->overflow, kQB * sizeof(unsigned), hipMemcpyDeviceToHost, st));
   }
 
   RescoreParams rp{};
@@ -400,7 +422,7 @@ int search_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_of
   if (sparse)
     for (int q = 0; q < nq; ++q) {
       h->stats.n_candidates += h->cnt_host[q];
-      if (h->cnt_host[q] > (unsigned)h->cand_cap) h->stats.n_overflow += 1;
+      if (h->cnt_host[kQB + q]) h->stats.n_overflow += 1;
     }
   for (int q = 0; q < nq; ++q)
     if (h->flags_host[q]) fallback.push_back(q);
@@ -514,7 +536,7 @@ int anr_index_create(int32_t dim, int32_t metric, int32_t normalize, int32_t dev
   h->dim = dim;
   h->dimp = (int)round_up(dim, 128);
   h->kb = h->dimp / 16;
-  if ((size_t)2 * h->kb * 64 * 16 + kQB * kLadder * sizeof(float) > 160 * 1024) {
+  if ((size_t)2 * h->kb * 64 * 16 + kQB * kLadder * 8 + kQB * 8 > 160 * 1024) {
     delete h;
     return fail(ANR_EINVAL, "dim %d needs more than 160 KiB of LDS for the query operand", dim);
   }
@@ -551,7 +573,9 @@ int anr_index_destroy(anr_index *h) {
   dev_free(h->qstage);
   dev_free(h->dense);
   dev_free(h->ladder);
-  dev_free(h->lhist);
+  dev_free(h->lcum);
+  dev_free(h->cntb);
+  dev_free(h->ncand);
   dev_free(h->cand);
   dev_free(h->sel_rank);
   dev_free(h->sel_row);
@@ -663,7 +687,7 @@ int anr_index_set_option(anr_index *h, int32_t opt, int64_t value) {
       h->sample_rows = (int)round_up(value, kTileRows);
       break;
     case ANR_OPT_CAND_CAP:
-      if (value < 1024 || value > (1 << 22)) return fail(ANR_EINVAL, "candidate capacity must be in 1024..2^22");
+      if (value < 64 || value > (1 << 16)) return fail(ANR_EINVAL, "candidate list capacity must be in 64..65536");
       h->cand_cap = value;
       break;
     case ANR_OPT_TIMING: h->timing = value != 0; break;

@@ -216,8 +216,16 @@ __global__ __launch_bounds__(256) void k_prepq(PrepQParams p) {
 // ------------------------------------------------------------------------------------------------
 // scan: the dominant kernel.  Streams the blocked f16 corpus once; per 32-row tile a wave runs
 // KB x 2 MFMAs (32 rows x 64 queries), then either writes the score tile densely (DENSE) or appends
-// the scores that pass the per-query running threshold to the per-query candidate lists.
+// the scores that pass the per-query running threshold to this block's per-query candidate list.
+//
+// Running threshold ("ladder"): the sample phase leaves, per query, kLadder ascending values
+// lad[0..L-1] = the sample's scores of rank K', K'/2, K'/4, ... 1.  lcum[q][j] counts the rows emitted
+// so far (by any block) whose score is >= lad[j].  Every row is scored exactly once, so once
+// lcum[q][j] >= K' there are K' distinct rows at or above lad[j] and lad[j] is a valid threshold:
+// nothing below it can be among the K' best.  Stale or under-counted counters only delay tightening.
 // ------------------------------------------------------------------------------------------------
+constexpr int kCumStride = 64;  // uints: one 256-B line per counter (spreads the hot words over channels)
+
 struct ScanParams {
   const uint4 *x16;
   const uint4 *q16;
@@ -230,10 +238,10 @@ struct ScanParams {
   int64_t dense_ld;
   // sparse
   const float *ladder;   // [64][kLadder] ascending thresholds from the sample
-  unsigned *lhist;       // [64][kLadder] emitted-candidate histogram over the ladder levels
-  unsigned *cnt;         // [64]
-  uint2 *cand;           // [64][cap] (rank-score bits, row)
-  unsigned cap;
+  unsigned *lcum;        // [64][kLadder][kCumStride] emitted rows with score >= ladder level
+  unsigned *cntb;        // [64][gridDim.x] list lengths, written when a block retires
+  uint2 *cand;           // [gridDim.x][64][capb] (rank-score bits, row)
+  unsigned capb;
   unsigned kprime;
 };
 
@@ -262,16 +270,66 @@ __device__ __forceinline__ unsigned ld_relaxed(const unsigned *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// append this lane's hits of one 32x32 accumulator block (all for query q) to the block's list and
+// count them against the next three ladder levels in the block's pending counters (LDS)
+__device__ __forceinline__ void scan_emit(const floatx16 &acc, float tau, int lvl, int q, int64_t row_base,
+                                          int64_t n_rows, const float *lad, unsigned *lds_cnt,
+                                          unsigned *lds_pend, const ScanParams &p) {
+  unsigned n = 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int64_t row = row_base + (r & 3) + 8 * (r >> 2);
+    n += (row < n_rows && acc[r] >= tau) ? 1u : 0u;
+  }
+  if (n) {
+    unsigned k = atomicAdd(lds_cnt + q, n);  // LDS: slot reservation inside the block
+    const int ja = lvl + 1 < kLadder ? lvl + 1 : kLadder - 1;
+    const int jb = lvl + 2 < kLadder ? lvl + 2 : kLadder - 1;
+    const int jc = lvl + 3 < kLadder ? lvl + 3 : kLadder - 1;
+    const float la = lad[q * kLadder + ja], lb = lad[q * kLadder + jb], lc = lad[q * kLadder + jc];
+    unsigned ca = 0, cb = 0, cc = 0;
+    uint2 *list = p.cand + ((int64_t)blockIdx.x * kQB + q) * p.capb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t row = row_base + (r & 3) + 8 * (r >> 2);
+      const float s = acc[r];
+      if (row < n_rows && s >= tau) {
+        if (k < p.capb) list[k] = make_uint2(__float_as_uint(s), (unsigned)row);
+        ++k;
+        ca += (s >= la) ? 1u : 0u;
+        cb += (s >= lb) ? 1u : 0u;
+        cc += (s >= lc) ? 1u : 0u;
+      }
+    }
+    // levels further than three above the current one are under-counted (safe, see header comment)
+    if (lvl + 1 < kLadder && ca) atomicAdd(lds_pend + q * kLadder + lvl + 1, ca);
+    if (lvl + 2 < kLadder && cb) atomicAdd(lds_pend + q * kLadder + lvl + 2, cb);
+    if (lvl + 3 < kLadder && cc) atomicAdd(lds_pend + q * kLadder + lvl + 3, cc);
+  }
+}
+
 template <bool DENSE, int CH, int NT>
 __global__ __launch_bounds__(NT) void k_scan(ScanParams p) {
-  extern __shared__ uint4 lds[];  // Q operand image [2][kb][64] then the ladder [64][kLadder]
+  // LDS: Q operand image [2][kb][64] | ladder [64][L] | list lengths [64] | level [64] | pending [64][L]
+  extern __shared__ uint4 lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nthreads = blockDim.x, nwaves = nthreads >> 6;
   const int nq16 = 2 * p.kb * 64;
   for (int i = tid; i < nq16; i += nthreads) lds[i] = p.q16[i];
   float *lad = reinterpret_cast<float *>(lds + nq16);
-  if (!DENSE)
-    for (int i = tid; i < kQB * kLadder; i += nthreads) lad[i] = p.ladder[i];
+  unsigned *lds_cnt = reinterpret_cast<unsigned *>(lad + kQB * kLadder);
+  int *lds_lvl = reinterpret_cast<int *>(lds_cnt + kQB);
+  unsigned *lds_pend = reinterpret_cast<unsigned *>(lds_lvl + kQB);
+  if (!DENSE) {
+    for (int i = tid; i < kQB * kLadder; i += nthreads) {
+      lad[i] = p.ladder[i];
+      lds_pend[i] = 0;
+    }
+    if (tid < kQB) {
+      lds_cnt[tid] = 0;
+      lds_lvl[tid] = 0;
+    }
+  }
   __syncthreads();
 
   const uint4 *ldsq0 = lds + lane;
@@ -280,6 +338,7 @@ __global__ __launch_bounds__(NT) void k_scan(ScanParams p) {
   const int64_t wglobal = (int64_t)blockIdx.x * nwaves + wave;
   const int64_t wtotal = (int64_t)gridDim.x * nwaves;
   const int nch = p.kb / CH;  // even by construction (kb % (2*CH) == 0)
+  const int per_wave = kQB / nwaves;  // queries whose counters this wave publishes
 
   for (int64_t i = wglobal; i < p.n_tiles; i += wtotal) {
     const int64_t tile = p.tile0 + i * p.tile_stride;
@@ -329,20 +388,10 @@ __global__ __launch_bounds__(NT) void k_scan(ScanParams p) {
         *reinterpret_cast<float4 *>(d1 + 8 * g) = v1;
       }
     } else {
-      // running thresholds of this lane's two queries: highest ladder level already reached by
-      // >= kprime emitted rows (each row is scored once, so the count is of distinct rows)
-      float tau0 = lad[q0 * kLadder], tau1 = lad[(q0 + 32) * kLadder];
-      {
-        unsigned c0 = 0, c1 = 0;
-        bool f0 = false, f1 = false;
-#pragma unroll
-        for (int j = kLadder - 1; j >= 1; --j) {
-          c0 += ld_relaxed(p.lhist + q0 * kLadder + j);
-          c1 += ld_relaxed(p.lhist + (q0 + 32) * kLadder + j);
-          if (!f0 && c0 >= p.kprime) { tau0 = lad[q0 * kLadder + j]; f0 = true; }
-          if (!f1 && c1 >= p.kprime) { tau1 = lad[(q0 + 32) * kLadder + j]; f1 = true; }
-        }
-      }
+      // the block's current ladder level of this lane's two queries (LDS, shared by all waves)
+      const int lv0 = __hip_atomic_load(lds_lvl + q0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const int lv1 = __hip_atomic_load(lds_lvl + q0 + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const float tau0 = lad[q0 * kLadder + lv0], tau1 = lad[(q0 + 32) * kLadder + lv1];
       float m0 = acc0[0], m1 = acc1[0];
 #pragma unroll
       for (int r = 1; r < 16; ++r) {
@@ -350,34 +399,34 @@ __global__ __launch_bounds__(NT) void k_scan(ScanParams p) {
         m1 = fmaxf(m1, acc1[r]);
       }
       if (__any((m0 >= tau0) || (m1 >= tau1))) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t row = row_base + (r & 3) + 8 * (r >> 2);
-          const bool live = row < p.n_rows;
-#pragma unroll
-          for (int b = 0; b < 2; ++b) {
-            const float s = b ? acc1[r] : acc0[r];
-            const float tau = b ? tau1 : tau0;
-            if (live && s >= tau) {
-              const int q = q0 + 32 * b;
-              const unsigned pos = atomicAdd(p.cnt + q, 1u);
-              if (pos < p.cap) p.cand[(int64_t)q * p.cap + pos] = make_uint2(__float_as_uint(s), (unsigned)row);
-              int lvl = 0;
-#pragma unroll
-              for (int j = 1; j < kLadder; ++j) lvl += (s >= lad[q * kLadder + j]) ? 1 : 0;
-              if (lvl > 0) atomicAdd(p.lhist + q * kLadder + lvl, 1u);
-            }
-          }
-        }
+        scan_emit(acc0, tau0, lv0, q0, row_base, p.n_rows, lad, lds_cnt, lds_pend, p);
+        scan_emit(acc1, tau1, lv1, q0 + 32, row_base, p.n_rows, lad, lds_cnt, lds_pend, p);
+      }
+      // publish this wave's share of the pending level counts and pick up the global totals
+      for (int e = lane; e < per_wave * kLadder; e += 64) {
+        const int q = wave * per_wave + (e >> 3), j = e & (kLadder - 1);
+        if (j == 0 || j <= __hip_atomic_load(lds_lvl + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) continue;
+        const unsigned v = atomicExch(lds_pend + q * kLadder + j, 0u);
+        unsigned *gc = p.lcum + (int64_t)(q * kLadder + j) * kCumStride;
+        const unsigned g = v ? atomicAdd(gc, v) + v : ld_relaxed(gc);
+        if (g >= p.kprime) atomicMax(lds_lvl + q, j);
       }
     }
+  }
+  if (!DENSE) {
+    __syncthreads();
+    if (tid < kQB) p.cntb[(int64_t)tid * gridDim.x + blockIdx.x] = lds_cnt[tid];
   }
 }
 
 // ------------------------------------------------------------------------------------------------
 // select: one block per query; radix-select the M largest 64-bit keys (rank desc, row asc) from a
-// dense score row or a candidate list, sort them, write (rank, row) and optionally the ladder.
+// dense score row or from the per-block candidate lists, sort them, write (rank, row) and optionally
+// the threshold ladder.  Keys are staged in LDS when they fit (the usual case).
 // ------------------------------------------------------------------------------------------------
+constexpr int kSelLds = 16384;   // keys staged in LDS (128 KiB)
+constexpr int kSelMaxLists = 1024;
+
 struct SelParams {
   // dense input (dense != nullptr): n entries per query, entry i -> row = (i/32)*row_tile_stride*32 + row0 + i%32
   const float *dense;
@@ -386,46 +435,93 @@ struct SelParams {
   int64_t row0, row_tile_stride;
   int negate;            // rank = -value (ascending select, L2 distances)
   // list input
-  const uint2 *cand;
-  const unsigned *cnt;
-  unsigned cap;
+  const uint2 *cand;     // [G][64][capb]
+  const unsigned *cntb;  // [64][G]
+  int G;
+  unsigned capb;
   int M;                 // entries wanted (<= kMaxSel)
-  const int *qmap;       // optional: block b handles query slot qmap[b]
   // outputs, [64][kMaxSel]
   float *out_rank;
   unsigned *out_row;
   int *out_m;            // entries written per query
   float *ladder;         // optional [64][kLadder]
-  unsigned *overflow;    // optional [64]: set when cnt > cap
+  unsigned *overflow;    // optional [64]: set when a list overflowed
+  unsigned *ncand;       // optional [64]: candidates seen
+  unsigned *lcum_zero;   // optional: ladder mode also clears this query's level counters
 };
 
-__device__ __forceinline__ unsigned long long sel_key(const SelParams &p, int q, int64_t i) {
+struct SelShared {
+  unsigned long long keys[kSelLds];
+  unsigned long long sel[kMaxSel];
+  unsigned long long red[16][2];
+  unsigned offs[kSelMaxLists + 1];
+  unsigned hist[256];
+  unsigned cnt;
+  int d;
+  unsigned above, h, ovf;
+};
+
+__device__ __forceinline__ unsigned long long sel_key(const SelParams &p, const SelShared &sh, int q, int64_t i,
+                                                      bool staged) {
+  if (staged) return sh.keys[i];
   if (p.dense) {
     float v = p.dense[(int64_t)q * p.dense_ld + i];
     if (p.negate) v = -v;
     const int64_t row = (i >> 5) * p.row_tile_stride * 32 + p.row0 + (i & 31);
     return make_key(v, (unsigned)row);
   }
-  const uint2 c = p.cand[(int64_t)q * p.cap + i];
+  // list entry i: binary search the block whose range holds i
+  int lo = 0, hi = p.G;  // offs[lo] <= i < offs[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (sh.offs[mid] <= (unsigned)i) lo = mid;
+    else hi = mid;
+  }
+  const uint2 c = p.cand[((int64_t)lo * kQB + q) * p.capb + ((unsigned)i - sh.offs[lo])];
   return make_key(__uint_as_float(c.x), c.y);
 }
 
 __global__ __launch_bounds__(1024) void k_select(SelParams p) {
-  __shared__ unsigned hist[256];
-  __shared__ unsigned long long sel[kMaxSel];
-  __shared__ unsigned long long s_red[16][2];
-  __shared__ unsigned s_cnt;
-  __shared__ int s_d;
-  __shared__ unsigned s_above, s_h;
+  extern __shared__ unsigned char sel_smem[];
+  SelShared &sh = *reinterpret_cast<SelShared *>(sel_smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int q = p.qmap ? p.qmap[blockIdx.x] : blockIdx.x;
+  const int q = blockIdx.x;
   int64_t n;
   if (p.dense) {
     n = p.n;
   } else {
-    const unsigned c = p.cnt[q];
-    n = c < p.cap ? c : p.cap;
-    if (p.overflow && tid == 0) p.overflow[q] = (c > p.cap) ? 1u : 0u;
+    if (tid == 0) sh.ovf = 0;
+    __syncthreads();
+    for (int b = tid; b < p.G; b += 1024) {
+      unsigned c = p.cntb[(int64_t)q * p.G + b];
+      if (c > p.capb) {
+        sh.ovf = 1;
+        c = p.capb;
+      }
+      sh.offs[b + 1] = c;
+    }
+    __syncthreads();
+    {
+      // inclusive scan of the (<= 1024) list lengths: wave scan + wave totals
+      unsigned v = tid < p.G ? sh.offs[tid + 1] : 0u;
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned t = __shfl_up(v, off);
+        if (lane >= off) v += t;
+      }
+      if (lane == 63) sh.hist[wave] = v;
+      __syncthreads();
+      unsigned base = 0;
+      for (int w = 0; w < wave; ++w) base += sh.hist[w];
+      __syncthreads();
+      if (tid < p.G) sh.offs[tid + 1] = v + base;
+      if (tid == 0) sh.offs[0] = 0;
+      __syncthreads();
+    }
+    n = sh.offs[p.G];
+    if (tid == 0) {
+      if (p.overflow) p.overflow[q] = sh.ovf;
+      if (p.ncand) p.ncand[q] = (unsigned)n;
+    }
   }
   const int M = (int)((int64_t)p.M < n ? (int64_t)p.M : n);
   if (tid == 0) p.out_m[q] = M;
@@ -433,11 +529,27 @@ __global__ __launch_bounds__(1024) void k_select(SelParams p) {
     if (p.ladder && tid < kLadder) p.ladder[q * kLadder + tid] = -__builtin_inff();
     return;
   }
+  const bool staged = n <= kSelLds;
+  if (staged) {
+    if (p.dense) {
+      for (int64_t i = tid; i < n; i += 1024) sh.keys[i] = sel_key(p, sh, q, i, false);
+    } else {
+      for (int b = wave; b < p.G; b += 16) {
+        const unsigned o = sh.offs[b], c = sh.offs[b + 1] - o;
+        const uint2 *list = p.cand + ((int64_t)b * kQB + q) * p.capb;
+        for (unsigned j = lane; j < c; j += 64) {
+          const uint2 e = list[j];
+          sh.keys[o + j] = make_key(__uint_as_float(e.x), e.y);
+        }
+      }
+    }
+    __syncthreads();
+  }
 
   // common leading bytes of all keys -> skip those passes (also avoids one-bin LDS atomic storms)
   unsigned long long kmin = ~0ull, kmax = 0ull;
   for (int64_t i = tid; i < n; i += 1024) {
-    const unsigned long long k = sel_key(p, q, i);
+    const unsigned long long k = sel_key(p, sh, q, i, staged);
     kmin = k < kmin ? k : kmin;
     kmax = k > kmax ? k : kmax;
   }
@@ -447,61 +559,73 @@ __global__ __launch_bounds__(1024) void k_select(SelParams p) {
     kmax = b > kmax ? b : kmax;
   }
   if (lane == 0) {
-    s_red[wave][0] = kmin;
-    s_red[wave][1] = kmax;
+    sh.red[wave][0] = kmin;
+    sh.red[wave][1] = kmax;
   }
   __syncthreads();
-  kmin = s_red[0][0];
-  kmax = s_red[0][1];
+  kmin = sh.red[0][0];
+  kmax = sh.red[0][1];
   for (int w = 1; w < 16; ++w) {
-    kmin = s_red[w][0] < kmin ? s_red[w][0] : kmin;
-    kmax = s_red[w][1] > kmax ? s_red[w][1] : kmax;
+    kmin = sh.red[w][0] < kmin ? sh.red[w][0] : kmin;
+    kmax = sh.red[w][1] > kmax ? sh.red[w][1] : kmax;
   }
   int bits = 0;
   while (bits < 64 && (kmin >> (56 - bits)) == (kmax >> (56 - bits))) bits += 8;
   unsigned long long prefix = bits ? (kmax >> (64 - bits)) : 0ull;
   unsigned need = (unsigned)M;
-  bool whole = (bits == 64);  // all keys equal cannot happen (rows differ) unless n == 1
+  bool whole = (bits == 64);
   while (!whole && bits < 64) {
-    for (int i = tid; i < 256; i += 1024) hist[i] = 0;
+    for (int i = tid; i < 256; i += 1024) sh.hist[i] = 0;
     __syncthreads();
     for (int64_t i = tid; i < n; i += 1024) {
-      const unsigned long long k = sel_key(p, q, i);
-      if (bits == 0 || (k >> (64 - bits)) == prefix) atomicAdd(&hist[(unsigned)(k >> (56 - bits)) & 255u], 1u);
+      const unsigned long long k = sel_key(p, sh, q, i, staged);
+      if (bits == 0 || (k >> (64 - bits)) == prefix) atomicAdd(&sh.hist[(unsigned)(k >> (56 - bits)) & 255u], 1u);
     }
     __syncthreads();
-    if (tid == 0) {
-      unsigned c = 0;
-      int d = 255;
-      for (; d > 0; --d) {
-        if (c + hist[d] >= need) break;
-        c += hist[d];
+    if (wave == 0) {
+      // lane l owns digits 255-4l .. 252-4l; find the digit where the count from the top reaches `need`
+      const int dtop = 255 - 4 * lane;
+      const unsigned h0 = sh.hist[dtop], h1 = sh.hist[dtop - 1], h2 = sh.hist[dtop - 2], h3 = sh.hist[dtop - 3];
+      const unsigned own = h0 + h1 + h2 + h3;
+      unsigned incl = own;
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
       }
-      s_d = d;
-      s_above = c;
-      s_h = hist[d];
+      const unsigned excl = incl - own;
+      if (excl < need && need <= incl) {
+        unsigned c = excl;
+        int d = dtop;
+        unsigned hd = h0;
+        if (c + h0 < need) { c += h0; d = dtop - 1; hd = h1;
+          if (c + h1 < need) { c += h1; d = dtop - 2; hd = h2;
+            if (c + h2 < need) { c += h2; d = dtop - 3; hd = h3; } } }
+        sh.d = d;
+        sh.above = c;
+        sh.h = hd;
+      }
     }
     __syncthreads();
-    need -= s_above;
-    prefix = (prefix << 8) | (unsigned long long)s_d;
+    need -= sh.above;
+    prefix = (prefix << 8) | (unsigned long long)sh.d;
     bits += 8;
-    if (s_h == need) whole = true;  // every key under this prefix is wanted
+    if (sh.h == need) whole = true;  // every key under this prefix is wanted
     __syncthreads();
   }
   // gather keys whose leading `bits` bits are >= prefix: exactly M of them
-  if (tid == 0) s_cnt = 0;
+  if (tid == 0) sh.cnt = 0;
   __syncthreads();
   for (int64_t i = tid; i < n; i += 1024) {
-    const unsigned long long k = sel_key(p, q, i);
+    const unsigned long long k = sel_key(p, sh, q, i, staged);
     if (bits == 0 || (k >> (64 - bits)) >= prefix) {
-      const unsigned pos = atomicAdd(&s_cnt, 1u);
-      if (pos < (unsigned)kMaxSel) sel[pos] = k;
+      const unsigned pos = atomicAdd(&sh.cnt, 1u);
+      if (pos < (unsigned)kMaxSel) sh.sel[pos] = k;
     }
   }
   __syncthreads();
   int Mp = 1;
   while (Mp < M) Mp <<= 1;
-  for (int i = M + tid; i < Mp; i += 1024) sel[i] = 0ull;
+  for (int i = M + tid; i < Mp; i += 1024) sh.sel[i] = 0ull;
   __syncthreads();
   // bitonic sort, descending
   for (int k2 = 2; k2 <= Mp; k2 <<= 1) {
@@ -509,11 +633,11 @@ __global__ __launch_bounds__(1024) void k_select(SelParams p) {
       for (int i = tid; i < Mp; i += 1024) {
         const int ixj = i ^ j;
         if (ixj > i) {
-          const unsigned long long a = sel[i], b = sel[ixj];
+          const unsigned long long a = sh.sel[i], b = sh.sel[ixj];
           const bool desc = ((i & k2) == 0);
           if (desc ? (a < b) : (a > b)) {
-            sel[i] = b;
-            sel[ixj] = a;
+            sh.sel[i] = b;
+            sh.sel[ixj] = a;
           }
         }
       }
@@ -521,16 +645,17 @@ __global__ __launch_bounds__(1024) void k_select(SelParams p) {
     }
   }
   for (int i = tid; i < M; i += 1024) {
-    const unsigned long long k = sel[i];
+    const unsigned long long k = sh.sel[i];
     float v = ord2f((unsigned)(k >> 32));
     p.out_rank[q * kMaxSel + i] = p.negate ? -v : v;
     p.out_row[q * kMaxSel + i] = 0xffffffffu - (unsigned)(k & 0xffffffffu);
   }
+  if (p.lcum_zero && tid < kLadder) p.lcum_zero[(int64_t)(q * kLadder + tid) * kCumStride] = 0u;
   if (p.ladder && tid < kLadder) {
     // level j = value of rank max(1, M >> j) (1-based) of the sample: ascending in j
     int rk = M >> tid;
     if (rk < 1 || tid == kLadder - 1) rk = 1;
-    p.ladder[q * kLadder + tid] = ord2f((unsigned)(sel[rk - 1] >> 32));
+    p.ladder[q * kLadder + tid] = ord2f((unsigned)(sh.sel[rk - 1] >> 32));
   }
 }
 

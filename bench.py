@@ -1,0 +1,292 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the dense-retrieval hot path (BASELINE.json `metric`).
+
+Workload: exact top-100 of batch-64 queries over a 10M x 768 synthetic corpus (unit-norm Gaussian rows,
+cosine == inner product), the configuration BASELINE.json's metric is quoted on.  One "step" is one
+batch of 64 queries answered end to end (query prep, scan, select, exact re-score, merge).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N = 1: the whole corpus sits on one MI355X (fp32 rows + blocked f16 image = 46 GB).
+N > 1 (launched by torch.distributed.run, one rank per GPU): the corpus is row-sharded, every rank
+scans its shard for the same batch, the [64,100] partial top-k (score f32 + global id i64) are
+all-gathered over RCCL and merged; strong scaling (total corpus fixed).
+
+Rank 0 prints ONE JSON line.  `value` = queries/s of the whole job with the corpus resident in HBM.
+`roofline` is for the dominant kernel (k_scan): algorithmic bytes = rows x 768 x 2 B (the f16 image
+actually streamed) per launch / HIP-event time of that launch.  `cpu_baseline` is the oracle (numpy
+sgemm + argpartition restatement of the reference's faiss-flat path) timed on this box's host cores on
+a bounded row sample and scaled linearly to the full corpus.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "ano-rag_amd"))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=10_000_000, help="total corpus rows (all ranks)")
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--k", type=int, default=100)
+    ap.add_argument("--cpu-rows", type=int, default=200_000, help="rows of the CPU-baseline sample")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--recall-queries", type=int, default=4)
+    return ap.parse_args()
+
+
+def gen_shard(rows, dim, shard, device, chunk=262_144):
+    """unit-norm-able Gaussian rows, generated on the device chunk by chunk (seed [1234, shard])."""
+    g = torch.Generator(device=device)
+    g.manual_seed(1234 * 1000 + shard)
+    done = 0
+    while done < rows:
+        m = min(chunk, rows - done)
+        yield torch.randn((m, dim), generator=g, device=device, dtype=torch.float32)
+        done += m
+
+
+def cpu_baseline(args, world):
+    """oracle timed on host cores: bounded sample, scaled linearly in rows."""
+    from oracle import flat_index as orc
+    try:
+        from threadpoolctl import threadpool_info
+        thr = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
+    except Exception:
+        thr = os.cpu_count() or 1
+    n = args.cpu_rows
+    x = orc.preprocess_vectors(np.random.default_rng(1234).standard_normal((n, args.dim), dtype=np.float32))
+    q = orc.preprocess_vectors(np.random.default_rng(4321).standard_normal((args.batch, args.dim), dtype=np.float32))
+
+    def one():
+        s = q @ x.T
+        part = np.argpartition(-s, args.k - 1, axis=1)[:, :args.k]
+        ps = np.take_along_axis(s, part, axis=1)
+        order = np.argsort(-ps, axis=1, kind="stable")
+        return np.take_along_axis(part, order, axis=1)
+
+    one()
+    t0 = time.perf_counter()
+    it = 0
+    while True:
+        one()
+        it += 1
+        dt = time.perf_counter() - t0
+        if dt > 10.0 or it >= 50:
+            break
+    t_batch = dt / it
+    qps_sample = args.batch / t_batch
+    qps_full = qps_sample * n / args.rows
+    return {
+        "value": qps_full,
+        "unit": "queries/s",
+        "cores": int(thr),
+        "kind": "port",
+        "sample": (f"numpy fp32 sgemm + argpartition top-{args.k}, batch {args.batch}, {n} x {args.dim} rows: "
+                   f"{qps_sample:.1f} q/s measured over {it} batches, scaled x{n / args.rows:.4g} to {args.rows} rows; "
+                   f"os.cpu_count()={os.cpu_count()}"),
+    }
+
+
+def recall_vs_oracle(args, shards_host_iter, q_host, I_gpu):
+    """recall@k of the GPU ids against the float64-arbitrated oracle for a few queries (full corpus)."""
+    from oracle import flat_index as orc
+    nq = q_host.shape[0]
+    qn = orc.preprocess_vectors(q_host)
+    best_s = np.full((nq, 0), 0.0)
+    best_i = np.zeros((nq, 0), dtype=np.int64)
+    base = 0
+    for xb in shards_host_iter():
+        xn = orc.preprocess_vectors(xb)
+        s = qn.astype(np.float64) @ xn.astype(np.float64).T
+        kk = min(args.k, s.shape[1])
+        part = np.argpartition(-s, kk - 1, axis=1)[:, :kk]
+        best_s = np.concatenate([best_s, np.take_along_axis(s, part, axis=1)], axis=1)
+        best_i = np.concatenate([best_i, part + base], axis=1)
+        o = np.argsort(-best_s, axis=1, kind="stable")[:, :args.k]
+        best_s = np.take_along_axis(best_s, o, axis=1)
+        best_i = np.take_along_axis(best_i, o, axis=1)
+        base += xb.shape[0]
+    hits = 0
+    for i in range(nq):
+        hits += len(set(best_i[i].tolist()) & set(I_gpu[i].tolist()))
+    return hits / float(nq * args.k)
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # noqa: F811
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from anorag_hip import FlatIndex, METRIC_IP, _lib
+    from anorag_hip._lib import OPT_TIMING
+
+    rows_total = args.rows
+    per = (rows_total + world - 1) // world
+    row0 = min(rank * per, rows_total)
+    my_rows = max(0, min(per, rows_total - row0))
+
+    idx = FlatIndex(args.dim, METRIC_IP, normalize=True, device=local_rank)
+    idx.reserve(my_rows)
+    for xb in gen_shard(my_rows, args.dim, rank, dev):
+        torch.cuda.synchronize()
+        idx.add_device(xb.data_ptr(), xb.shape[0])
+    del xb
+    torch.cuda.empty_cache()
+    idx.set_option(OPT_TIMING, 1)
+
+    nb = args.steps + args.warmup
+    gq = torch.Generator(device=dev)
+    gq.manual_seed(4321)
+    Q = torch.randn((nb, args.batch, args.dim), generator=gq, device=dev, dtype=torch.float32)
+    Dl = torch.empty((args.batch, args.k), device=dev, dtype=torch.float32)
+    Il = torch.empty((args.batch, args.k), device=dev, dtype=torch.int64)
+    if world > 1:
+        Dg = torch.empty((world, args.batch, args.k), device=dev, dtype=torch.float32)
+        Ig = torch.empty((world, args.batch, args.k), device=dev, dtype=torch.int64)
+        Dm = torch.empty_like(Dl)
+        Im = torch.empty_like(Il)
+    lib = _lib.load()
+    stream = torch.cuda.current_stream(dev)
+
+    scan_ms = 0.0
+    scan_bytes = 0
+    n_fallback = 0
+    n_cand = 0
+
+    def step(i, timed):
+        nonlocal scan_ms, scan_bytes, n_fallback, n_cand
+        idx.search_device(Q[i].data_ptr(), args.batch, args.k, Dl.data_ptr(), Il.data_ptr(), stream.cuda_stream)
+        if timed:
+            st = idx.last_stats()
+            scan_ms += st["scan_ms"]
+            scan_bytes += st["scan_bytes"]
+            n_fallback += st["n_fallback"]
+            n_cand += st["n_candidates"]
+        if world > 1:
+            Il.add_(row0)  # local -> global ids (padding -1 cannot occur: every shard holds >= k rows)
+            dist.all_gather_into_tensor(Dg, Dl)
+            dist.all_gather_into_tensor(Ig, Il)
+            _lib.check(lib.anr_merge_topk_dev(local_rank, C.c_void_p(Dg.data_ptr()), C.c_void_p(Ig.data_ptr()),
+                                              world, args.batch, args.k, 1, C.c_void_p(Dm.data_ptr()),
+                                              C.c_void_p(Im.data_ptr()), C.c_void_p(stream.cuda_stream)),
+                       "anr_merge_topk_dev")
+            return Dm, Im
+        return Dl, Il
+
+    for i in range(args.warmup):
+        step(i, False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, nb):
+        Dres, Ires = step(i, True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # recall@k of the last batch's first few queries vs the oracle (single-GPU run only: the oracle needs
+    # the rows on the host)
+    recall = None
+    if world == 1 and rank == 0 and args.recall_queries > 0:
+        nrq = min(args.recall_queries, args.batch)
+        I_gpu = Ires[:nrq].cpu().numpy()
+        qh = Q[nb - 1, :nrq].cpu().numpy()
+
+        def shards():
+            for xb in gen_shard(my_rows, args.dim, rank, dev, chunk=524_288):
+                yield xb.cpu().numpy()
+
+        recall = recall_vs_oracle(args, shards, qh, I_gpu)
+
+    if rank == 0:
+        qps = args.batch * args.steps / dt
+        achieved = (scan_bytes / 1e9) / (scan_ms / 1e3) if scan_ms > 0 else None
+        out = {
+            "metric": "queries/sec + recall@k vs CPU ref, 10M×768 corpus, batch-64 top-100",
+            "value": qps,
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f16 scan (MFMA, f32 accumulate) + f32 rows re-scored in f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{rows_total} x {args.dim} unit-norm Gaussian corpus, batch-{args.batch} top-{args.k} "
+                            f"exact cosine search",
+                "rows_total": rows_total,
+                "rows_per_gpu": per,
+                "dim": args.dim,
+                "batch": args.batch,
+                "k": args.k,
+                "parallelism": f"row-shard x{world}" if world > 1 else "single GPU",
+            },
+            "recall_at_k": recall,
+            "exact_fallback_queries": n_fallback,
+            "candidates_per_query": n_cand / max(1, args.steps * args.batch),
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_scan",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
+                "traffic": None,
+                "bytes_per_launch": scan_bytes / max(1, args.steps),
+                "ms_per_launch": scan_ms / max(1, args.steps),
+            },
+        }
+        if not args.no_cpu and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args, world)
+        print(json.dumps(out), flush=True)
+    idx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

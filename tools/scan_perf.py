@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Developer tool: time the search pipeline on synthetic data (not part of the product or the tests)."""
+import argparse, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "ano-rag_amd"))
+import torch
+from anorag_hip import FlatIndex, METRIC_IP
+from anorag_hip._lib import OPT_TIMING, OPT_SAMPLE_ROWS, OPT_OVERFETCH, OPT_CAND_CAP
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--rows", type=int, default=1_000_000)
+ap.add_argument("--dim", type=int, default=768)
+ap.add_argument("--batch", type=int, default=64)
+ap.add_argument("--k", type=int, default=100)
+ap.add_argument("--steps", type=int, default=20)
+ap.add_argument("--sample", type=int, default=0)
+ap.add_argument("--overfetch", type=int, default=0)
+a = ap.parse_args()
+dev = torch.device("cuda", 0)
+idx = FlatIndex(a.dim, METRIC_IP, normalize=True)
+idx.reserve(a.rows)
+g = torch.Generator(device=dev); g.manual_seed(1)
+done = 0
+while done < a.rows:
+    m = min(262144, a.rows - done)
+    x = torch.randn((m, a.dim), generator=g, device=dev)
+    torch.cuda.synchronize()
+    idx.add_device(x.data_ptr(), m)
+    done += m
+idx.set_option(OPT_TIMING, 1)
+if a.sample: idx.set_option(OPT_SAMPLE_ROWS, a.sample)
+if a.overfetch: idx.set_option(OPT_OVERFETCH, a.overfetch)
+Q = torch.randn((a.steps + 2, a.batch, a.dim), generator=g, device=dev)
+D = torch.empty((a.batch, a.k), device=dev); I = torch.empty((a.batch, a.k), device=dev, dtype=torch.int64)
+for i in range(2):
+    idx.search_device(Q[i].data_ptr(), a.batch, a.k, D.data_ptr(), I.data_ptr())
+torch.cuda.synchronize()
+tot_scan = tot_all = 0.0; cand = fb = 0
+t0 = time.perf_counter()
+for i in range(2, a.steps + 2):
+    idx.search_device(Q[i].data_ptr(), a.batch, a.k, D.data_ptr(), I.data_ptr())
+    st = idx.last_stats()
+    tot_scan += st["scan_ms"]; tot_all += st["total_ms"]; cand += st["n_candidates"]; fb += st["n_fallback"]
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / a.steps
+byt = st["scan_bytes"]
+print(f"rows={a.rows} wall/step={dt*1e3:.3f} ms  scan={tot_scan/a.steps:.3f} ms  gpu-total={tot_all/a.steps:.3f} ms  "
+      f"scan GB/s={byt/1e9/(tot_scan/a.steps/1e3):.0f}  qps={a.batch/dt:.0f}  cand/q={cand/a.steps/a.batch:.0f} fallback={fb} "
+      f"sample={st['sample_rows']} overfetch={st['overfetch']}")
