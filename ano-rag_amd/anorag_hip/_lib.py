@@ -76,6 +76,11 @@ SIGNATURES = {
         [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
          C.c_void_p],
     ),
+    "anr_fuse_lists": (
+        C.c_int,
+        [C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int32,
+         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    ),
 }
 
 _lib = None

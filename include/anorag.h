@@ -99,6 +99,22 @@ int anr_normalize_rows(float *x_host, int64_t n, int32_t d, int32_t device);
 int anr_merge_topk_dev(int32_t device, const float *Dp_dev, const int64_t *Ip_dev, int32_t P, int64_t nq,
                        int32_t k, int32_t larger_is_better, float *D_dev, int64_t *I_dev, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Score fusion: the arithmetic of HybridSearcher.fuse, retrieval/hybrid_search.py:34-103, for a batch
+ * of nq queries on the device (float64, bit-identical to the Python reference).
+ * Each query has four (id, score) lists in the order dense, bm25, graph, path; ids are integers (the
+ * caller maps note ids to integers), unique inside a list and listed in the caller's order (the order
+ * matters for rrf ties, hybrid_search.py:66).  All lists are concatenated: `ids`/`scores` hold the
+ * entries, `offs` is [nq][5] with the entry offset of each of the four lists of a query and its end.
+ * method 0 = "linear" (max-normalised weighted sum, :83-100), 1 = "rrf" (:64-82).
+ * Outputs per query, best first: out_ids [nq][pool] (-1 padded), out_final [nq][pool],
+ * out_src [nq][pool][4] = the raw score of the id in each source or NaN when absent, out_count [nq].
+ * A query may carry at most 4096 list entries in total.
+ * ---------------------------------------------------------------------------------------------- */
+int anr_fuse_lists(int32_t device, int32_t method, int64_t nq, const int64_t *ids, const double *scores,
+                   const int64_t *offs, const double *weights /*[4]*/, double rrf_k, int32_t pool,
+                   int64_t *out_ids, double *out_final, double *out_src, int32_t *out_count);
+
 #ifdef __cplusplus
 }
 #endif
