@@ -22,6 +22,7 @@ OPT_OVERFETCH = 2
 OPT_SAMPLE_ROWS = 3
 OPT_CAND_CAP = 4
 OPT_TIMING = 5
+OPT_ADD_RAW = 6
 
 
 class AnoragError(RuntimeError):
@@ -43,6 +44,14 @@ class SearchStats(C.Structure):
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+class EncoderConfig(C.Structure):
+    _fields_ = [
+        ("n_layers", C.c_int32), ("hidden", C.c_int32), ("n_heads", C.c_int32), ("intermediate", C.c_int32),
+        ("vocab_size", C.c_int32), ("max_positions", C.c_int32), ("type_vocab_size", C.c_int32),
+        ("pos_offset", C.c_int32), ("pooling", C.c_int32), ("act", C.c_int32), ("ln_eps", C.c_float),
+    ]
 
 
 _f32p = C.POINTER(C.c_float)
@@ -80,6 +89,14 @@ SIGNATURES = {
         C.c_int,
         [C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int32,
          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    ),
+    "anr_encoder_create": (C.c_int, [C.POINTER(EncoderConfig), C.c_int32, C.POINTER(C.c_void_p)]),
+    "anr_encoder_destroy": (C.c_int, [C.c_void_p]),
+    "anr_encoder_set_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),
+    "anr_encoder_finalize": (C.c_int, [C.c_void_p]),
+    "anr_encoder_forward": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p],
     ),
 }
 

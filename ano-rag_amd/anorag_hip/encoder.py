@@ -1,0 +1,255 @@
+"""Host side of the device sentence encoder: model-directory reader, tokeniser front end and the
+``SentenceEncoder`` object the drop-in ``EmbeddingManager`` holds in ``self.model`` (where the reference holds
+a ``sentence_transformers.SentenceTransformer``, embedding_manager.py:350).
+
+What runs where: tokenisation (``tokenizers``) and batching on the host; embedding gather, transformer
+blocks, pooling and L2 normalisation on the device through ``anr_encoder_*`` (libanorag_hip.so).  There is no
+CPU forward: without the HIP library or a device, construction raises.
+
+The pipeline restates ``SentenceTransformer.encode`` (sentence-transformers >= 2.2, not vendored in the
+reference): sort by text length (longest first), batches of ``batch_size``, tokenise with truncation to
+``max_seq_length`` and padding to the longest of the batch, Transformer -> Pooling (mode from the model's
+``1_Pooling/config.json``) -> optional Normalize module, then ``normalize_embeddings``, results restored to
+the input order as float32.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import EncoderConfig
+
+_PREFIXES = ("bert.", "roberta.", "xlm_roberta.", "model.", "0.auto_model.", "auto_model.")
+
+
+def _strip(name: str) -> str:
+    changed = True
+    while changed:
+        changed = False
+        for p in _PREFIXES:
+            if name.startswith(p):
+                name = name[len(p):]
+                changed = True
+    return name
+
+
+def map_hf_name(name: str) -> Optional[str]:
+    """HF BERT/RoBERTa parameter name -> tensor name of anr_encoder_set_tensor (None = not used)."""
+    n = _strip(name)
+    table = {
+        "embeddings.word_embeddings.weight": "emb.word",
+        "embeddings.position_embeddings.weight": "emb.pos",
+        "embeddings.token_type_embeddings.weight": "emb.type",
+        "embeddings.LayerNorm.weight": "emb.ln.g",
+        "embeddings.LayerNorm.bias": "emb.ln.b",
+    }
+    if n in table:
+        return table[n]
+    if not n.startswith("encoder.layer."):
+        return None
+    rest = n[len("encoder.layer."):]
+    li, _, tail = rest.partition(".")
+    sub = {
+        "attention.self.query": "q", "attention.self.key": "k", "attention.self.value": "v",
+        "attention.output.dense": "o", "intermediate.dense": "ffn1", "output.dense": "ffn2",
+    }
+    for k, v in sub.items():
+        if tail == k + ".weight":
+            return f"L{li}.{v}.w"
+        if tail == k + ".bias":
+            return f"L{li}.{v}.b"
+    ln = {"attention.output.LayerNorm": "ln1", "output.LayerNorm": "ln2"}
+    for k, v in ln.items():
+        if tail == k + ".weight":
+            return f"L{li}.{v}.g"
+        if tail == k + ".bias":
+            return f"L{li}.{v}.b"
+    return None
+
+
+def read_model_dir(path: str) -> Dict:
+    """config + pooling + tokenizer location of a sentence-transformers / HF model directory."""
+    with open(os.path.join(path, "config.json")) as f:
+        hf = json.load(f)
+    mtype = hf.get("model_type", "bert")
+    if mtype not in ("bert", "roberta", "xlm-roberta"):
+        raise ValueError(f"model_type {mtype!r} is not supported by the HIP encoder (bert / roberta / xlm-roberta)")
+    if hf.get("position_embedding_type", "absolute") != "absolute":
+        raise ValueError("only absolute position embeddings are supported")
+    act = hf.get("hidden_act", "gelu")
+    if act != "gelu":
+        raise ValueError(f"hidden_act {act!r} is not supported (gelu)")
+    pooling, normalize_module, max_seq = "mean", False, None
+    mod_file = os.path.join(path, "modules.json")
+    if os.path.exists(mod_file):
+        with open(mod_file) as f:
+            for m in json.load(f):
+                t = m.get("type", "")
+                if t.endswith("Pooling"):
+                    with open(os.path.join(path, m.get("path", "1_Pooling"), "config.json")) as pf:
+                        pc = json.load(pf)
+                    if pc.get("pooling_mode_cls_token"):
+                        pooling = "cls"
+                    elif pc.get("pooling_mode_mean_tokens", True):
+                        pooling = "mean"
+                    else:
+                        raise ValueError("unsupported pooling mode (only mean / cls)")
+                elif t.endswith("Normalize"):
+                    normalize_module = True
+    sb = os.path.join(path, "sentence_bert_config.json")
+    if os.path.exists(sb):
+        with open(sb) as f:
+            max_seq = json.load(f).get("max_seq_length")
+    pad_idx = hf.get("pad_token_id", 0 if mtype == "bert" else 1)
+    return {
+        "hf": hf,
+        "model_type": mtype,
+        "pooling": pooling,
+        "normalize_module": normalize_module,
+        "max_seq_length": max_seq,
+        "pos_offset": 0 if mtype == "bert" else int(pad_idx) + 1,
+        "pad_token_id": int(pad_idx),
+    }
+
+
+def load_weights(path: str) -> Dict[str, np.ndarray]:
+    st = os.path.join(path, "model.safetensors")
+    if os.path.exists(st):
+        from safetensors.numpy import load_file
+        raw = load_file(st)
+    else:
+        import torch
+        raw = {k: v.float().numpy() for k, v in torch.load(os.path.join(path, "pytorch_model.bin"),
+                                                           map_location="cpu").items()}
+    out = {}
+    for k, v in raw.items():
+        name = map_hf_name(k)
+        if name is not None:
+            out[name] = np.ascontiguousarray(v, dtype=np.float32)
+    return out
+
+
+def load_tokenizer(path: str):
+    from tokenizers import Tokenizer
+    tj = os.path.join(path, "tokenizer.json")
+    if os.path.exists(tj):
+        return Tokenizer.from_file(tj)
+    vocab = os.path.join(path, "vocab.txt")
+    if os.path.exists(vocab):
+        from tokenizers import BertWordPieceTokenizer
+        lower = True
+        tc = os.path.join(path, "tokenizer_config.json")
+        if os.path.exists(tc):
+            with open(tc) as f:
+                lower = json.load(f).get("do_lower_case", True)
+        return BertWordPieceTokenizer(vocab, lowercase=lower)._tokenizer
+    raise FileNotFoundError(f"no tokenizer.json or vocab.txt under {path}")
+
+
+class DeviceEncoder:
+    """anr_encoder handle + weights."""
+
+    def __init__(self, hf_config: Dict, tensors: Dict[str, np.ndarray], pooling: str = "mean", pos_offset: int = 0,
+                 device: int = 0):
+        self._lib = _lib.load()
+        cfg = EncoderConfig(
+            n_layers=int(hf_config["num_hidden_layers"]), hidden=int(hf_config["hidden_size"]),
+            n_heads=int(hf_config["num_attention_heads"]), intermediate=int(hf_config["intermediate_size"]),
+            vocab_size=int(hf_config["vocab_size"]), max_positions=int(hf_config["max_position_embeddings"]),
+            type_vocab_size=int(hf_config.get("type_vocab_size", 1)), pos_offset=int(pos_offset),
+            pooling=1 if pooling == "cls" else 0, act=0, ln_eps=float(hf_config.get("layer_norm_eps", 1e-12)),
+        )
+        self.hidden = cfg.hidden
+        self.max_positions = cfg.max_positions - cfg.pos_offset
+        h = C.c_void_p()
+        _lib.check(self._lib.anr_encoder_create(C.byref(cfg), int(device), C.byref(h)), "anr_encoder_create")
+        self._h = h
+        for name, arr in tensors.items():
+            a = np.ascontiguousarray(arr, dtype=np.float32)
+            _lib.check(self._lib.anr_encoder_set_tensor(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), a.size),
+                       f"anr_encoder_set_tensor({name})")
+        _lib.check(self._lib.anr_encoder_finalize(self._h), "anr_encoder_finalize")
+
+    def forward(self, ids: np.ndarray, lengths: np.ndarray, type_ids: Optional[np.ndarray] = None,
+                normalize: bool = False) -> np.ndarray:
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        lengths = np.ascontiguousarray(lengths, dtype=np.int32)
+        B, L = ids.shape
+        out = np.empty((B, self.hidden), dtype=np.float32)
+        tp = None
+        if type_ids is not None:
+            type_ids = np.ascontiguousarray(type_ids, dtype=np.int32)
+            tp = type_ids.ctypes.data_as(C.c_void_p)
+        _lib.check(self._lib.anr_encoder_forward(self._h, ids.ctypes.data_as(C.c_void_p),
+                                                 lengths.ctypes.data_as(C.c_void_p), tp, B, L, int(bool(normalize)),
+                                                 out.ctypes.data_as(C.c_void_p)), "anr_encoder_forward")
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.anr_encoder_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SentenceEncoder:
+    """The subset of the SentenceTransformer surface the reference uses: ``encode``,
+    ``get_sentence_embedding_dimension``, ``max_seq_length`` (embedding_manager.py:353-362, :392-399)."""
+
+    def __init__(self, model_path: str, device: int = 0, trust_remote_code: bool = True, **_):
+        info = read_model_dir(model_path)
+        self.model_path = model_path
+        self._info = info
+        self.tokenizer = load_tokenizer(model_path)
+        self._enc = DeviceEncoder(info["hf"], load_weights(model_path), pooling=info["pooling"],
+                                  pos_offset=info["pos_offset"], device=device)
+        self.max_seq_length = int(info["max_seq_length"] or min(512, self._enc.max_positions))
+        self._pad = info["pad_token_id"]
+        self.device = device
+
+    def get_sentence_embedding_dimension(self) -> int:
+        return self._enc.hidden
+
+    def tokenize(self, texts: Sequence[str]):
+        tok = self.tokenizer
+        max_len = int(min(self.max_seq_length, self._enc.max_positions))
+        tok.enable_truncation(max_length=max_len)
+        tok.no_padding()
+        encs = tok.encode_batch([str(t) for t in texts])
+        lens = np.array([len(e.ids) for e in encs], dtype=np.int32)
+        L = int(lens.max())
+        ids = np.full((len(encs), L), self._pad, dtype=np.int32)
+        types = np.zeros((len(encs), L), dtype=np.int32)
+        for i, e in enumerate(encs):
+            ids[i, :lens[i]] = e.ids
+            types[i, :lens[i]] = e.type_ids
+        return ids, lens, types
+
+    def encode(self, sentences, batch_size: int = 32, show_progress_bar: bool = False, convert_to_numpy: bool = True,
+               normalize_embeddings: bool = False, device=None, **_):
+        single = isinstance(sentences, str)
+        if single:
+            sentences = [sentences]
+        n = len(sentences)
+        out = np.zeros((n, self._enc.hidden), dtype=np.float32)
+        order = np.argsort([-len(s) for s in sentences], kind="stable")
+        want_norm = bool(normalize_embeddings) or self._info["normalize_module"]
+        use_types = self._info["hf"].get("type_vocab_size", 1) > 1
+        for s in range(0, n, batch_size):
+            sel = order[s:s + batch_size]
+            ids, lens, types = self.tokenize([sentences[i] for i in sel])
+            out[sel] = self._enc.forward(ids, lens, types if use_types else None, normalize=want_norm)
+        return out[0] if single else out
+
+    def close(self):
+        self._enc.close()

@@ -1,0 +1,747 @@
+// Sentence encoder behind anr_encoder_* (include/anorag.h): the forward pass the reference obtains from
+// sentence_transformers.SentenceTransformer.encode (vector_store/embedding_manager.py:392-399): a
+// BERT-family encoder (bert / roberta / xlm-roberta: post-LN blocks, learned absolute positions), pooling
+// (masked mean or CLS) and optional L2 normalisation.  Tokenisation stays on the host.
+//
+// CDNA4 design: every activation lives in HBM in MFMA *operand* layout, so no kernel needs LDS or a
+// transpose and every global access is a contiguous 1 KiB per wave instruction:
+//   act  [T/32][KB][64 lanes][8]  f16   token (t%32) on lane&31, 8 features per lane
+//   res  same shape, f32 (residual stream, LayerNorm input/output)
+//   W    [N/32][KB][64][8]        f16   output feature (n%32) on lane&31, 8 input features per lane
+// with the *same* feature permutation inside each 16-feature block kb:
+//   element j of lane half h  <->  feature kb*16 + 8*(j>>2) + 4*h + (j&3)
+// which is exactly where v_mfma_f32_32x32x16_f16 leaves its results (C row = (r&3)+8*(r>>2)+4*h): the
+// 16 accumulator registers of a lane are two ready-made 8-element operand fragments (r>>3 picks the
+// 16-block, r&7 the element), so a GEMM epilogue is two 16-byte stores and the next GEMM / the attention
+// consume them as is.  GEMMs run "token on lane" (C^T = W * act^T); V is projected with the operands
+// swapped so that it lands "feature on lane, keys in k" — the A operand P*V needs.
+// f16 operands, f32 accumulation, f32 residual stream and LayerNorm.
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+
+namespace anr {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int feat_of(int kb, int h, int j) { return kb * 16 + 8 * (j >> 2) + 4 * h + (j & 3); }
+
+// ---- weight packing ------------------------------------------------------------------------------
+// W row-major [N][K] f32 -> blocked f16 operand image [N/32][K/16][64][8]
+__global__ void k_pack_weight(const float *w, int N, int K, _Float16 *out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one 16-byte fragment element group
+  const int KB = K / 16;
+  const int64_t total = (int64_t)(N / 32) * KB * 64;
+  if (i >= total) return;
+  const int lane = (int)(i & 63);
+  const int kb = (int)((i >> 6) % KB);
+  const int nb = (int)((i >> 6) / KB);
+  const int n = nb * 32 + (lane & 31), h = lane >> 5;
+  half8 v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (_Float16)w[(int64_t)n * K + feat_of(kb, h, j)];
+  *reinterpret_cast<half8 *>(out + i * 8) = v;
+}
+// bias [N] -> accumulator order [N/32][2 halves][16 regs]
+__global__ void k_pack_bias_acc(const float *b, int N, float *out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int nb = i / 32, rem = i % 32, h = rem / 16, r = rem % 16;
+  out[i] = b[nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+}
+// per-feature vector [H] (LayerNorm gamma/beta) or table rows [R][H] -> blocked order [R][KB][2][8]
+__global__ void k_pack_rows(const float *src, int64_t R, int H, float *out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R * H) return;
+  const int64_t row = i / H;
+  const int c = (int)(i % H);
+  const int kb = c / 16, h = (c % 16) / 8, j = c % 8;
+  out[i] = src[row * H + feat_of(kb, h, j)];
+}
+
+// ---- embeddings + LayerNorm ----------------------------------------------------------------------
+struct EmbedParams {
+  const int *ids;      // [B][L]
+  const int *types;    // [B][L] or null
+  const int *lens;     // [B]
+  int B, L, Lp, H, KB, pos_offset, max_pos;
+  const float *word, *pos, *type;  // blocked rows
+  const float *g, *b;              // blocked LN params
+  float eps;
+  float *res;
+  _Float16 *act;
+};
+
+// one wave per 32-token block; each lane owns (token, half) and walks the KB feature blocks
+__global__ __launch_bounds__(256) void k_embed_ln(EmbedParams p) {
+  const int lane = threadIdx.x & 63;
+  const int64_t tb = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t TB = (int64_t)p.B * p.Lp / 32;
+  if (tb >= TB) return;
+  const int64_t t = tb * 32 + (lane & 31);
+  const int h = lane >> 5;
+  const int b = (int)(t / p.Lp), pos = (int)(t % p.Lp);
+  const bool real = pos < p.L;
+  const int id = real ? p.ids[(int64_t)b * p.L + pos] : 0;
+  const int ty = (real && p.types) ? p.types[(int64_t)b * p.L + pos] : 0;
+  const int64_t prow = pos + p.pos_offset < p.max_pos ? pos + p.pos_offset : p.max_pos - 1;  // padding rows only
+  float s = 0.f;
+  for (int kb = 0; kb < p.KB; ++kb) {
+    const int o = (kb * 2 + h) * 8;
+    const float4 *w = reinterpret_cast<const float4 *>(p.word + (int64_t)id * p.H + o);
+    const float4 *q = reinterpret_cast<const float4 *>(p.pos + prow * p.H + o);
+    const float4 *y = reinterpret_cast<const float4 *>(p.type + (int64_t)ty * p.H + o);
+    const float4 a0 = w[0], a1 = w[1], b0 = q[0], b1 = q[1], c0 = y[0], c1 = y[1];
+    s += (a0.x + b0.x + c0.x) + (a0.y + b0.y + c0.y) + (a0.z + b0.z + c0.z) + (a0.w + b0.w + c0.w) +
+         (a1.x + b1.x + c1.x) + (a1.y + b1.y + c1.y) + (a1.z + b1.z + c1.z) + (a1.w + b1.w + c1.w);
+  }
+  s += __shfl_xor(s, 32);
+  const float mean = s / p.H;
+  float v = 0.f;
+  for (int kb = 0; kb < p.KB; ++kb) {
+    const int o = (kb * 2 + h) * 8;
+    const float *w = p.word + (int64_t)id * p.H + o, *q = p.pos + prow * p.H + o, *y = p.type + (int64_t)ty * p.H + o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float d = (w[j] + q[j] + y[j]) - mean;
+      v += d * d;
+    }
+  }
+  v += __shfl_xor(v, 32);
+  const float rstd = rsqrtf(v / p.H + p.eps);
+  for (int kb = 0; kb < p.KB; ++kb) {
+    const int o = (kb * 2 + h) * 8;
+    const float *w = p.word + (int64_t)id * p.H + o, *q = p.pos + prow * p.H + o, *y = p.type + (int64_t)ty * p.H + o;
+    float out[8];
+    half8 hv;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      out[j] = ((w[j] + q[j] + y[j]) - mean) * rstd * p.g[o + j] + p.b[o + j];
+      hv[j] = (_Float16)out[j];
+    }
+    const int64_t e = ((tb * p.KB + kb) * 64 + lane) * 8;
+    *reinterpret_cast<float4 *>(p.res + e) = make_float4(out[0], out[1], out[2], out[3]);
+    *reinterpret_cast<float4 *>(p.res + e + 4) = make_float4(out[4], out[5], out[6], out[7]);
+    *reinterpret_cast<half8 *>(p.act + e) = hv;
+  }
+}
+
+struct LnParams {
+  const float *in;  // blocked f32 (pre-LN sum)
+  int64_t TB;
+  int H, KB;
+  const float *g, *b;
+  float eps;
+  float *res;
+  _Float16 *act;
+};
+
+__global__ __launch_bounds__(256) void k_layernorm(LnParams p) {
+  const int lane = threadIdx.x & 63;
+  const int64_t tb = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tb >= p.TB) return;
+  const int h = lane >> 5;
+  float s = 0.f;
+  for (int kb = 0; kb < p.KB; ++kb) {
+    const float4 *x = reinterpret_cast<const float4 *>(p.in + ((tb * p.KB + kb) * 64 + lane) * 8);
+    const float4 a = x[0], c = x[1];
+    s += (a.x + a.y) + (a.z + a.w) + (c.x + c.y) + (c.z + c.w);
+  }
+  s += __shfl_xor(s, 32);
+  const float mean = s / p.H;
+  float v = 0.f;
+  for (int kb = 0; kb < p.KB; ++kb) {
+    const float *x = p.in + ((tb * p.KB + kb) * 64 + lane) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float d = x[j] - mean;
+      v += d * d;
+    }
+  }
+  v += __shfl_xor(v, 32);
+  const float rstd = rsqrtf(v / p.H + p.eps);
+  for (int kb = 0; kb < p.KB; ++kb) {
+    const int64_t e = ((tb * p.KB + kb) * 64 + lane) * 8;
+    const int o = (kb * 2 + h) * 8;
+    float out[8];
+    half8 hv;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      out[j] = (p.in[e + j] - mean) * rstd * p.g[o + j] + p.b[o + j];
+      hv[j] = (_Float16)out[j];
+    }
+    *reinterpret_cast<float4 *>(p.res + e) = make_float4(out[0], out[1], out[2], out[3]);
+    *reinterpret_cast<float4 *>(p.res + e + 4) = make_float4(out[4], out[5], out[6], out[7]);
+    *reinterpret_cast<half8 *>(p.act + e) = hv;
+  }
+}
+
+// ---- GEMM: out[t][n] = sum_k act[t][k] * W[n][k] + bias[n] -------------------------------------------
+enum { EPI_ACT = 0, EPI_GELU = 1, EPI_RES = 2, EPI_VT = 3 };
+
+struct GemmParams {
+  const uint4 *act;   // [TB][KB][64]
+  const uint4 *w;     // [NB][KB][64]
+  int64_t TB;
+  int NB, KB;
+  const float *bias_acc;  // [NB][2][16] (token-on-lane epilogues)
+  const float *bias;      // [N] plain (EPI_VT)
+  const float *res_in;    // EPI_RES: blocked f32 [TB][NB*2][64][8]
+  float *res_out;         // EPI_RES
+  _Float16 *out;          // EPI_ACT / EPI_GELU: [TB][NB*2][64][8]; EPI_VT: [NB][TB*2][64][8]
+};
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+// each wave: MT token blocks x NT feature blocks; waves are laid out feature-group fastest so the waves of a
+// workgroup share their activation fragments through L1
+template <int MT, int NT, int EPI>
+__global__ __launch_bounds__(256) void k_gemm(GemmParams p) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int NG = (p.NB + NT - 1) / NT;
+  const int64_t TG = (p.TB + MT - 1) / MT;
+  if (wg >= TG * NG) return;
+  const int64_t tb0 = (wg / NG) * MT;
+  const int nb0 = (int)(wg % NG) * NT;
+  floatx16 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+  const uint4 *ap[MT];
+  const uint4 *wp[NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int64_t tb = tb0 + m < p.TB ? tb0 + m : p.TB - 1;  // clamp: tail tiles recompute the last block
+    ap[m] = p.act + tb * p.KB * 64 + lane;
+  }
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int nb = nb0 + n < p.NB ? nb0 + n : p.NB - 1;
+    wp[n] = p.w + (int64_t)nb * p.KB * 64 + lane;
+  }
+  uint4 a[MT], b[NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) a[m] = ap[m][0];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) b[n] = wp[n][0];
+  for (int kb = 0; kb < p.KB; ++kb) {
+    uint4 an[MT], bn[NT];
+    const int kn = kb + 1 < p.KB ? kb + 1 : kb;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) an[m] = ap[m][(int64_t)kn * 64];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) bn[n] = wp[n][(int64_t)kn * 64];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const half8 av = __builtin_bit_cast(half8, a[m]);
+        const half8 bv = __builtin_bit_cast(half8, b[n]);
+        if (EPI == EPI_VT)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[m][n], 0, 0, 0);  // rows = tokens
+        else
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bv, av, acc[m][n], 0, 0, 0);  // rows = features
+      }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) a[m] = an[m];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) b[n] = bn[n];
+  }
+  const int h = lane >> 5;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int64_t tb = tb0 + m;
+    if (tb >= p.TB) continue;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int nb = nb0 + n;
+      if (nb >= p.NB) continue;
+      floatx16 c = acc[m][n];
+      if (EPI == EPI_VT) {
+        const float bb = p.bias[nb * 32 + (lane & 31)];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          half8 hv;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) hv[j] = (_Float16)(c[8 * s + j] + bb);
+          *reinterpret_cast<half8 *>(p.out + (((int64_t)nb * (p.TB * 2) + tb * 2 + s) * 64 + lane) * 8) = hv;
+        }
+      } else {
+        const float *ba = p.bias_acc + ((int64_t)nb * 2 + h) * 16;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int64_t e = ((tb * (p.NB * 2) + nb * 2 + s) * 64 + lane) * 8;
+          float o[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = c[8 * s + j] + ba[8 * s + j];
+          if (EPI == EPI_RES) {
+            const float4 r0 = *reinterpret_cast<const float4 *>(p.res_in + e);
+            const float4 r1 = *reinterpret_cast<const float4 *>(p.res_in + e + 4);
+            *reinterpret_cast<float4 *>(p.res_out + e) = make_float4(o[0] + r0.x, o[1] + r0.y, o[2] + r0.z, o[3] + r0.w);
+            *reinterpret_cast<float4 *>(p.res_out + e + 4) =
+                make_float4(o[4] + r1.x, o[5] + r1.y, o[6] + r1.z, o[7] + r1.w);
+          } else {
+            half8 hv;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) hv[j] = (_Float16)(EPI == EPI_GELU ? gelu_erf(o[j]) : o[j]);
+            *reinterpret_cast<half8 *>(p.out + e) = hv;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---- attention: one wave per (sequence, head, 32-query block), online softmax, all in registers --------
+struct AttnParams {
+  const uint4 *qk;    // act layout, KBqk = 2H/16: Q blocks then K blocks
+  const uint4 *vt;    // [H/32][T/16][64]
+  const int *lens;
+  int B, Lp, H, heads, dh;
+  float scale;
+  _Float16 *ctx;      // act layout [TB][H/16][64][8]
+};
+
+template <int DH>
+__global__ __launch_bounds__(256) void k_attention(AttnParams p) {
+  constexpr int KD = DH / 16, DF = DH / 32;
+  const int lane = threadIdx.x & 63, h = lane >> 5;
+  const int QB = p.Lp / 32;
+  const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= (int64_t)p.B * p.heads * QB) return;
+  const int qb = (int)(w % QB);
+  const int hd = (int)((w / QB) % p.heads);
+  const int b = (int)(w / ((int64_t)QB * p.heads));
+  const int len = p.lens[b];
+  const int KBqk = 2 * p.H / 16, KBh = p.H / 16;
+  const int64_t tb_seq = (int64_t)b * QB;
+  const int64_t KT = (int64_t)p.B * p.Lp / 16;
+  half8 qf[KD];
+#pragma unroll
+  for (int kd = 0; kd < KD; ++kd)
+    qf[kd] = __builtin_bit_cast(half8, p.qk[((tb_seq + qb) * KBqk + hd * KD + kd) * 64 + lane]);
+  floatx16 O[DF];
+#pragma unroll
+  for (int d = 0; d < DF; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[d][r] = 0.f;
+  float m = -__builtin_inff(), l = 0.f;
+  for (int kbk = 0; kbk * 32 < len; ++kbk) {
+    const int64_t tbk = tb_seq + kbk;
+    floatx16 S;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) S[r] = 0.f;
+#pragma unroll
+    for (int kd = 0; kd < KD; ++kd) {
+      const half8 kf = __builtin_bit_cast(half8, p.qk[(tbk * KBqk + KBh + hd * KD + kd) * 64 + lane]);
+      S = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kd], S, 0, 0, 0);  // rows = keys, lane = query
+    }
+    float mx = -__builtin_inff();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kbk * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      S[r] = key < len ? S[r] * p.scale : -__builtin_inff();
+      mx = fmaxf(mx, S[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mn = fmaxf(m, mx);
+    const float alpha = __expf(m - mn);
+    float ps = 0.f;
+    half8 pf0, pf1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float e = __expf(S[r] - mn);
+      ps += e;
+      if (r < 8) pf0[r] = (_Float16)e;
+      else pf1[r - 8] = (_Float16)e;
+    }
+    l = l * alpha + ps;
+    m = mn;
+#pragma unroll
+    for (int d = 0; d < DF; ++d) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) O[d][r] *= alpha;
+      const int64_t fb = (int64_t)hd * DF + d;
+      const half8 v0 = __builtin_bit_cast(half8, p.vt[(fb * KT + tbk * 2 + 0) * 64 + lane]);
+      const half8 v1 = __builtin_bit_cast(half8, p.vt[(fb * KT + tbk * 2 + 1) * 64 + lane]);
+      O[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0, pf0, O[d], 0, 0, 0);  // rows = head features
+      O[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1, pf1, O[d], 0, 0, 0);
+    }
+  }
+  l += __shfl_xor(l, 32);
+  const float inv = 1.0f / l;
+#pragma unroll
+  for (int d = 0; d < DF; ++d)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      half8 hv;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) hv[j] = (_Float16)(O[d][8 * s + j] * inv);
+      const int64_t kb = (int64_t)hd * KD + d * 2 + s;
+      *reinterpret_cast<half8 *>(p.ctx + (((tb_seq + qb) * KBh + kb) * 64 + lane) * 8) = hv;
+    }
+}
+
+// ---- pooling + normalisation: one block per sequence, thread per feature -------------------------------
+struct PoolParams {
+  const float *res;  // final LayerNorm output, blocked f32
+  const int *lens;
+  int B, Lp, H, KB, pooling, normalize;
+  float *out;  // [B][H] row-major
+};
+
+__global__ __launch_bounds__(256) void k_pool(PoolParams p) {
+  __shared__ float s_red[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int len = p.lens[b];
+  float ss = 0.f;
+  for (int f = tid; f < p.H; f += 256) {
+    const int kb = f / 16, off = f % 16, g = off / 8, hh = (off % 8) / 4, jj = off % 4, j = g * 4 + jj;
+    const int nt = p.pooling == 1 ? 1 : len;
+    float acc = 0.f;
+    for (int t = 0; t < nt; ++t) {
+      const int64_t tok = (int64_t)b * p.Lp + t;
+      acc += p.res[(((tok >> 5) * p.KB + kb) * 64 + (tok & 31) + 32 * hh) * 8 + j];
+    }
+    // sentence-transformers: sum / clamp(mask_sum, 1e-9)
+    const float v = p.pooling == 1 ? acc : acc / fmaxf((float)len, 1e-9f);
+    p.out[(int64_t)b * p.H + f] = v;
+    ss += v * v;
+  }
+  if (p.normalize) {
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    if ((tid & 63) == 0) s_red[tid >> 6] = ss;
+    __syncthreads();
+    // torch.nn.functional.normalize: x / max(||x||, 1e-12)
+    const float nrm = fmaxf(sqrtf(s_red[0] + s_red[1] + s_red[2] + s_red[3]), 1e-12f);
+    for (int f = tid; f < p.H; f += 256) p.out[(int64_t)b * p.H + f] /= nrm;
+  }
+}
+
+}  // namespace anr
+
+using namespace anr;
+
+// ====================================================================================================
+struct LayerW {
+  _Float16 *wqk = nullptr, *wv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr;
+  float *bqk = nullptr, *bv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;  // bqk/bo/b1/b2 in acc order
+  float *ln1g = nullptr, *ln1b = nullptr, *ln2g = nullptr, *ln2b = nullptr;          // blocked
+  bool have[16] = {false};
+};
+
+struct anr_encoder {
+  anr_encoder_config cfg{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::mutex mu;
+  float *word = nullptr, *pos = nullptr, *type = nullptr, *eg = nullptr, *eb = nullptr;
+  bool have_emb[5] = {false, false, false, false, false};
+  std::vector<LayerW> layers;
+  bool finalized = false;
+  // workspace
+  int64_t ws_tokens = 0;
+  int *d_ids = nullptr, *d_types = nullptr, *d_lens = nullptr;
+  int64_t ws_b = 0, ws_bl = 0;
+  float *res = nullptr, *res2 = nullptr, *out = nullptr;
+  _Float16 *act = nullptr, *qk = nullptr, *vt = nullptr, *ctx = nullptr, *ffn = nullptr;
+};
+
+namespace {
+
+template <typename T>
+int enc_alloc(T **p, int64_t n) {
+  *p = nullptr;
+  ANR_HIP(hipMalloc(reinterpret_cast<void **>(p), (size_t)(n > 0 ? n : 1) * sizeof(T)));
+  return ANR_OK;
+}
+template <typename T>
+void enc_free(T *&p) {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+}
+
+// upload a host f32 tensor to a temporary device buffer
+int upload(const float *host, int64_t n, float **dev) {
+  ANR_TRY(enc_alloc(dev, n));
+  ANR_HIP(hipMemcpy(*dev, host, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+  return ANR_OK;
+}
+
+int pack_weight(anr_encoder *e, const float *host, int N, int K, _Float16 **dst, int row_off, int N_total) {
+  // packs rows [row_off, row_off+N) of a (possibly concatenated) [N_total][K] operand image
+  if (!*dst) ANR_TRY(enc_alloc(dst, (int64_t)N_total * K));
+  float *tmp = nullptr;
+  ANR_TRY(upload(host, (int64_t)N * K, &tmp));
+  const int64_t total = (int64_t)(N / 32) * (K / 16) * 64;
+  hipLaunchKernelGGL(k_pack_weight, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, e->stream, tmp, N, K,
+                     *dst + (int64_t)row_off * K);
+  ANR_HIP(hipStreamSynchronize(e->stream));
+  (void)hipFree(tmp);
+  return ANR_OK;
+}
+
+int pack_bias_acc(anr_encoder *e, const float *host, int N, float **dst, int off, int N_total) {
+  if (!*dst) ANR_TRY(enc_alloc(dst, N_total));
+  float *tmp = nullptr;
+  ANR_TRY(upload(host, N, &tmp));
+  hipLaunchKernelGGL(k_pack_bias_acc, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, e->stream, tmp, N, *dst + off);
+  ANR_HIP(hipStreamSynchronize(e->stream));
+  (void)hipFree(tmp);
+  return ANR_OK;
+}
+
+int pack_rows(anr_encoder *e, const float *host, int64_t R, int H, float **dst) {
+  if (!*dst) ANR_TRY(enc_alloc(dst, R * H));
+  float *tmp = nullptr;
+  ANR_TRY(upload(host, R * H, &tmp));
+  hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)ceil_div(R * H, 256)), dim3(256), 0, e->stream, tmp, R, H, *dst);
+  ANR_HIP(hipStreamSynchronize(e->stream));
+  (void)hipFree(tmp);
+  return ANR_OK;
+}
+
+int plain_copy(const float *host, int64_t n, float **dst) {
+  if (!*dst) ANR_TRY(enc_alloc(dst, n));
+  ANR_HIP(hipMemcpy(*dst, host, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+  return ANR_OK;
+}
+
+template <int EPI>
+void launch_gemm(anr_encoder *e, GemmParams &g) {
+  constexpr int MT = 2, NT = 4;
+  const int64_t waves = ceil_div(g.TB, MT) * ceil_div(g.NB, NT);
+  hipLaunchKernelGGL((k_gemm<MT, NT, EPI>), dim3((unsigned)ceil_div(waves, 4)), dim3(256), 0, e->stream, g);
+}
+
+int ensure_ws(anr_encoder *e, int B, int L, int Lp) {
+  const int64_t T = (int64_t)B * Lp;
+  const auto &c = e->cfg;
+  if (T > e->ws_tokens) {
+    enc_free(e->res);
+    enc_free(e->res2);
+    enc_free(e->act);
+    enc_free(e->qk);
+    enc_free(e->vt);
+    enc_free(e->ctx);
+    enc_free(e->ffn);
+    ANR_TRY(enc_alloc(&e->res, T * c.hidden));
+    ANR_TRY(enc_alloc(&e->res2, T * c.hidden));
+    ANR_TRY(enc_alloc(&e->act, T * c.hidden));
+    ANR_TRY(enc_alloc(&e->qk, T * c.hidden * 2));
+    ANR_TRY(enc_alloc(&e->vt, T * c.hidden));
+    ANR_TRY(enc_alloc(&e->ctx, T * c.hidden));
+    ANR_TRY(enc_alloc(&e->ffn, T * c.intermediate));
+    e->ws_tokens = T;
+  }
+  if (B > e->ws_b) {
+    enc_free(e->d_lens);
+    enc_free(e->out);
+    ANR_TRY(enc_alloc(&e->d_lens, B));
+    ANR_TRY(enc_alloc(&e->out, (int64_t)B * c.hidden));
+    e->ws_b = B;
+  }
+  if ((int64_t)B * L > e->ws_bl) {
+    enc_free(e->d_ids);
+    enc_free(e->d_types);
+    ANR_TRY(enc_alloc(&e->d_ids, (int64_t)B * L));
+    ANR_TRY(enc_alloc(&e->d_types, (int64_t)B * L));
+    e->ws_bl = (int64_t)B * L;
+  }
+  return ANR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int anr_encoder_create(const anr_encoder_config *cfg, int32_t device, anr_encoder **out) {
+  if (!cfg || !out) return fail(ANR_EINVAL, "null argument");
+  *out = nullptr;
+  const auto &c = *cfg;
+  if (c.n_layers <= 0 || c.hidden <= 0 || c.n_heads <= 0 || c.intermediate <= 0 || c.vocab_size <= 0 ||
+      c.max_positions <= 0 || c.type_vocab_size <= 0)
+    return fail(ANR_EINVAL, "encoder config has non-positive sizes");
+  if (c.hidden % 32 || c.intermediate % 32) return fail(ANR_EINVAL, "hidden and intermediate sizes must be multiples of 32");
+  if (c.hidden % c.n_heads) return fail(ANR_EINVAL, "hidden not divisible by heads");
+  const int dh = c.hidden / c.n_heads;
+  if (dh != 32 && dh != 64 && dh != 128) return fail(ANR_EINVAL, "head size %d not supported (32, 64, 128)", dh);
+  if (c.pooling != 0 && c.pooling != 1) return fail(ANR_EINVAL, "pooling must be 0 (mean) or 1 (cls)");
+  if (c.act != 0) return fail(ANR_EINVAL, "only gelu (erf) activation is supported");
+  int ndev = anr_device_count();
+  if (ndev <= 0) return fail(ANR_EHIP, "no HIP device is visible");
+  if (device < 0 || device >= ndev) return fail(ANR_EINVAL, "device %d out of range", device);
+  DeviceGuard g(device);
+  anr_encoder *e = new anr_encoder();
+  e->cfg = c;
+  e->device = device;
+  e->layers.resize(c.n_layers);
+  if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete e;
+    return fail(ANR_EHIP, "hipStreamCreate failed");
+  }
+  *out = e;
+  return ANR_OK;
+}
+
+int anr_encoder_destroy(anr_encoder *e) {
+  if (!e) return ANR_OK;
+  DeviceGuard g(e->device);
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  enc_free(e->word); enc_free(e->pos); enc_free(e->type); enc_free(e->eg); enc_free(e->eb);
+  for (auto &l : e->layers) {
+    enc_free(l.wqk); enc_free(l.wv); enc_free(l.wo); enc_free(l.w1); enc_free(l.w2);
+    enc_free(l.bqk); enc_free(l.bv); enc_free(l.bo); enc_free(l.b1); enc_free(l.b2);
+    enc_free(l.ln1g); enc_free(l.ln1b); enc_free(l.ln2g); enc_free(l.ln2b);
+  }
+  enc_free(e->d_ids); enc_free(e->d_types); enc_free(e->d_lens);
+  enc_free(e->res); enc_free(e->res2); enc_free(e->out);
+  enc_free(e->act); enc_free(e->qk); enc_free(e->vt); enc_free(e->ctx); enc_free(e->ffn);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+  return ANR_OK;
+}
+
+// tensor names: emb.word [V][H], emb.pos [P][H], emb.type [Tv][H], emb.ln.g/.b [H];
+// L<i>.q.w/.k.w/.v.w/.o.w [H][H], L<i>.ffn1.w [I][H], L<i>.ffn2.w [H][I] (nn.Linear layout [out][in]),
+// the matching .b vectors, L<i>.ln1.g/.b (after attention), L<i>.ln2.g/.b (after the FFN)
+int anr_encoder_set_tensor(anr_encoder *e, const char *name, const float *data, int64_t n) {
+  if (!e || !name || !data) return fail(ANR_EINVAL, "null argument");
+  DeviceGuard g(e->device);
+  std::lock_guard<std::mutex> lk(e->mu);
+  const auto &c = e->cfg;
+  const int H = c.hidden, I = c.intermediate;
+  const std::string s(name);
+  auto need = [&](int64_t want) -> int {
+    return n == want ? ANR_OK : fail(ANR_EINVAL, "tensor %s: expected %lld elements, got %lld", name, (long long)want, (long long)n);
+  };
+  e->finalized = false;
+  if (s == "emb.word") { ANR_TRY(need((int64_t)c.vocab_size * H)); e->have_emb[0] = true; return pack_rows(e, data, c.vocab_size, H, &e->word); }
+  if (s == "emb.pos") { ANR_TRY(need((int64_t)c.max_positions * H)); e->have_emb[1] = true; return pack_rows(e, data, c.max_positions, H, &e->pos); }
+  if (s == "emb.type") { ANR_TRY(need((int64_t)c.type_vocab_size * H)); e->have_emb[2] = true; return pack_rows(e, data, c.type_vocab_size, H, &e->type); }
+  if (s == "emb.ln.g") { ANR_TRY(need(H)); e->have_emb[3] = true; return pack_rows(e, data, 1, H, &e->eg); }
+  if (s == "emb.ln.b") { ANR_TRY(need(H)); e->have_emb[4] = true; return pack_rows(e, data, 1, H, &e->eb); }
+  if (s.size() < 4 || s[0] != 'L') return fail(ANR_EINVAL, "unknown tensor name %s", name);
+  const size_t dot = s.find('.');
+  if (dot == std::string::npos) return fail(ANR_EINVAL, "unknown tensor name %s", name);
+  const int li = atoi(s.substr(1, dot - 1).c_str());
+  if (li < 0 || li >= c.n_layers) return fail(ANR_EINVAL, "tensor %s: layer out of range", name);
+  LayerW &l = e->layers[li];
+  const std::string t = s.substr(dot + 1);
+  if (t == "q.w") { ANR_TRY(need((int64_t)H * H)); l.have[0] = true; return pack_weight(e, data, H, H, &l.wqk, 0, 2 * H); }
+  if (t == "k.w") { ANR_TRY(need((int64_t)H * H)); l.have[1] = true; return pack_weight(e, data, H, H, &l.wqk, H, 2 * H); }
+  if (t == "v.w") { ANR_TRY(need((int64_t)H * H)); l.have[2] = true; return pack_weight(e, data, H, H, &l.wv, 0, H); }
+  if (t == "o.w") { ANR_TRY(need((int64_t)H * H)); l.have[3] = true; return pack_weight(e, data, H, H, &l.wo, 0, H); }
+  if (t == "ffn1.w") { ANR_TRY(need((int64_t)I * H)); l.have[4] = true; return pack_weight(e, data, I, H, &l.w1, 0, I); }
+  if (t == "ffn2.w") { ANR_TRY(need((int64_t)H * I)); l.have[5] = true; return pack_weight(e, data, H, I, &l.w2, 0, H); }
+  if (t == "q.b") { ANR_TRY(need(H)); l.have[6] = true; return pack_bias_acc(e, data, H, &l.bqk, 0, 2 * H); }
+  if (t == "k.b") { ANR_TRY(need(H)); l.have[7] = true; return pack_bias_acc(e, data, H, &l.bqk, H, 2 * H); }
+  if (t == "v.b") { ANR_TRY(need(H)); l.have[8] = true; return plain_copy(data, H, &l.bv); }
+  if (t == "o.b") { ANR_TRY(need(H)); l.have[9] = true; return pack_bias_acc(e, data, H, &l.bo, 0, H); }
+  if (t == "ffn1.b") { ANR_TRY(need(I)); l.have[10] = true; return pack_bias_acc(e, data, I, &l.b1, 0, I); }
+  if (t == "ffn2.b") { ANR_TRY(need(H)); l.have[11] = true; return pack_bias_acc(e, data, H, &l.b2, 0, H); }
+  if (t == "ln1.g") { ANR_TRY(need(H)); l.have[12] = true; return pack_rows(e, data, 1, H, &l.ln1g); }
+  if (t == "ln1.b") { ANR_TRY(need(H)); l.have[13] = true; return pack_rows(e, data, 1, H, &l.ln1b); }
+  if (t == "ln2.g") { ANR_TRY(need(H)); l.have[14] = true; return pack_rows(e, data, 1, H, &l.ln2g); }
+  if (t == "ln2.b") { ANR_TRY(need(H)); l.have[15] = true; return pack_rows(e, data, 1, H, &l.ln2b); }
+  return fail(ANR_EINVAL, "unknown tensor name %s", name);
+}
+
+int anr_encoder_finalize(anr_encoder *e) {
+  if (!e) return fail(ANR_EINVAL, "null handle");
+  std::lock_guard<std::mutex> lk(e->mu);
+  for (int i = 0; i < 5; ++i)
+    if (!e->have_emb[i]) return fail(ANR_ESTATE, "embedding tensor %d was not set", i);
+  for (size_t li = 0; li < e->layers.size(); ++li)
+    for (int i = 0; i < 16; ++i)
+      if (!e->layers[li].have[i]) return fail(ANR_ESTATE, "layer %zu: tensor slot %d was not set", li, i);
+  e->finalized = true;
+  return ANR_OK;
+}
+
+int anr_encoder_forward(anr_encoder *e, const int32_t *ids, const int32_t *lengths, const int32_t *type_ids, int32_t B,
+                        int32_t L, int32_t normalize, float *out_host) {
+  if (!e || !ids || !lengths || !out_host) return fail(ANR_EINVAL, "null argument");
+  if (B <= 0 || L <= 0) return fail(ANR_EINVAL, "B and L must be positive");
+  const auto &c = e->cfg;
+  if (L + c.pos_offset > c.max_positions) return fail(ANR_EINVAL, "sequence length %d exceeds the position table", L);
+  for (int b = 0; b < B; ++b)
+    if (lengths[b] <= 0 || lengths[b] > L) return fail(ANR_EINVAL, "lengths[%d] = %d out of range 1..%d", b, lengths[b], L);
+  for (int64_t i = 0; i < (int64_t)B * L; ++i) {
+    if (ids[i] < 0 || ids[i] >= c.vocab_size) return fail(ANR_EINVAL, "token id %d out of range", ids[i]);
+    if (type_ids && (type_ids[i] < 0 || type_ids[i] >= c.type_vocab_size)) return fail(ANR_EINVAL, "type id out of range");
+  }
+  DeviceGuard g(e->device);
+  if (!g.ok) return fail(ANR_EHIP, "hipSetDevice failed");
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (!e->finalized) return fail(ANR_ESTATE, "encoder weights are not finalized");
+  const int Lp = (int)round_up(L, 32);
+  ANR_TRY(ensure_ws(e, B, L, Lp));
+  hipStream_t st = e->stream;
+  ANR_HIP(hipMemcpyAsync(e->d_ids, ids, (size_t)B * L * sizeof(int), hipMemcpyHostToDevice, st));
+  if (type_ids) ANR_HIP(hipMemcpyAsync(e->d_types, type_ids, (size_t)B * L * sizeof(int), hipMemcpyHostToDevice, st));
+  ANR_HIP(hipMemcpyAsync(e->d_lens, lengths, (size_t)B * sizeof(int), hipMemcpyHostToDevice, st));
+  const int H = c.hidden, I = c.intermediate, KB = H / 16;
+  const int64_t TB = (int64_t)B * Lp / 32;
+
+  EmbedParams ep{};
+  ep.ids = e->d_ids;
+  ep.types = type_ids ? e->d_types : nullptr;
+  ep.lens = e->d_lens;
+  ep.B = B; ep.L = L; ep.Lp = Lp; ep.H = H; ep.KB = KB; ep.pos_offset = c.pos_offset; ep.max_pos = c.max_positions;
+  ep.word = e->word; ep.pos = e->pos; ep.type = e->type; ep.g = e->eg; ep.b = e->eb; ep.eps = c.ln_eps;
+  ep.res = e->res; ep.act = e->act;
+  hipLaunchKernelGGL(k_embed_ln, dim3((unsigned)ceil_div(TB, 4)), dim3(256), 0, st, ep);
+
+  const int dh = H / c.n_heads;
+  for (int li = 0; li < c.n_layers; ++li) {
+    const LayerW &l = e->layers[li];
+    GemmParams gq{};
+    gq.act = reinterpret_cast<const uint4 *>(e->act); gq.w = reinterpret_cast<const uint4 *>(l.wqk);
+    gq.TB = TB; gq.NB = 2 * H / 32; gq.KB = KB; gq.bias_acc = l.bqk; gq.out = e->qk;
+    launch_gemm<EPI_ACT>(e, gq);
+    GemmParams gv{};
+    gv.act = reinterpret_cast<const uint4 *>(e->act); gv.w = reinterpret_cast<const uint4 *>(l.wv);
+    gv.TB = TB; gv.NB = H / 32; gv.KB = KB; gv.bias = l.bv; gv.out = e->vt;
+    launch_gemm<EPI_VT>(e, gv);
+    AttnParams ap{};
+    ap.qk = reinterpret_cast<const uint4 *>(e->qk); ap.vt = reinterpret_cast<const uint4 *>(e->vt);
+    ap.lens = e->d_lens; ap.B = B; ap.Lp = Lp; ap.H = H; ap.heads = c.n_heads; ap.dh = dh;
+    ap.scale = 1.0f / sqrtf((float)dh); ap.ctx = e->ctx;
+    const int64_t aw = (int64_t)B * c.n_heads * (Lp / 32);
+    if (dh == 32) hipLaunchKernelGGL(k_attention<32>, dim3((unsigned)ceil_div(aw, 4)), dim3(256), 0, st, ap);
+    else if (dh == 64) hipLaunchKernelGGL(k_attention<64>, dim3((unsigned)ceil_div(aw, 4)), dim3(256), 0, st, ap);
+    else hipLaunchKernelGGL(k_attention<128>, dim3((unsigned)ceil_div(aw, 4)), dim3(256), 0, st, ap);
+    GemmParams go{};
+    go.act = reinterpret_cast<const uint4 *>(e->ctx); go.w = reinterpret_cast<const uint4 *>(l.wo);
+    go.TB = TB; go.NB = H / 32; go.KB = KB; go.bias_acc = l.bo; go.res_in = e->res; go.res_out = e->res2;
+    launch_gemm<EPI_RES>(e, go);
+    LnParams l1{e->res2, TB, H, KB, l.ln1g, l.ln1b, c.ln_eps, e->res, e->act};
+    hipLaunchKernelGGL(k_layernorm, dim3((unsigned)ceil_div(TB, 4)), dim3(256), 0, st, l1);
+    GemmParams g1{};
+    g1.act = reinterpret_cast<const uint4 *>(e->act); g1.w = reinterpret_cast<const uint4 *>(l.w1);
+    g1.TB = TB; g1.NB = I / 32; g1.KB = KB; g1.bias_acc = l.b1; g1.out = e->ffn;
+    launch_gemm<EPI_GELU>(e, g1);
+    GemmParams g2{};
+    g2.act = reinterpret_cast<const uint4 *>(e->ffn); g2.w = reinterpret_cast<const uint4 *>(l.w2);
+    g2.TB = TB; g2.NB = H / 32; g2.KB = I / 16; g2.bias_acc = l.b2; g2.res_in = e->res; g2.res_out = e->res2;
+    launch_gemm<EPI_RES>(e, g2);
+    LnParams l2{e->res2, TB, H, KB, l.ln2g, l.ln2b, c.ln_eps, e->res, e->act};
+    hipLaunchKernelGGL(k_layernorm, dim3((unsigned)ceil_div(TB, 4)), dim3(256), 0, st, l2);
+  }
+  PoolParams pp{e->res, e->d_lens, B, Lp, H, KB, c.pooling, normalize ? 1 : 0, e->out};
+  hipLaunchKernelGGL(k_pool, dim3(B), dim3(256), 0, st, pp);
+  ANR_HIP(hipGetLastError());
+  ANR_HIP(hipMemcpyAsync(out_host, e->out, (size_t)B * H * sizeof(float), hipMemcpyDeviceToHost, st));
+  ANR_HIP(hipStreamSynchronize(st));
+  return ANR_OK;
+}
+
+}  // extern "C"

@@ -33,6 +33,7 @@ struct anr_index {
   int sample_rows = 0;
   int64_t cand_cap = 512;   // entries per (block, query) candidate list
   int timing = 0;
+  int add_raw = 0;          // adds store the rows as given (already preprocessed, e.g. a reloaded index)
 
   // workspace (one batch)
   float *q32 = nullptr;
@@ -506,7 +507,7 @@ int add_impl(anr_index *h, const float *x_dev, int64_t n, hipStream_t st) {
   ap.dim = h->dim;
   ap.dimp = h->dimp;
   ap.kb = h->kb;
-  ap.normalize = h->normalize;
+  ap.normalize = h->normalize && !h->add_raw;
   ap.x32 = h->x32;
   ap.x16 = h->x16;
   ap.rowbias = h->rowbias;
@@ -691,6 +692,7 @@ int anr_index_set_option(anr_index *h, int32_t opt, int64_t value) {
       h->cand_cap = value;
       break;
     case ANR_OPT_TIMING: h->timing = value != 0; break;
+    case ANR_OPT_ADD_RAW: h->add_raw = value != 0; break;
     default: return fail(ANR_EINVAL, "unknown option %d", opt);
   }
   return ANR_OK;

@@ -1,0 +1,341 @@
+"""MI355X drop-in for the reference's ``vector_store/vector_index.py`` (class ``VectorIndex``).
+
+Same constructor, attributes, method names, return shapes and never-raise/sentinel conventions as the
+reference (vector_index.py:9-500); the object it keeps in ``self.index`` is an ``anorag_hip.FlatIndex``
+(exact scan on the device through libanorag_hip.so) where the reference keeps a faiss index.
+
+Differences a maintainer should know (also in INTEGRATION.md):
+  * every ``index_type`` (Flat / IVFFlat / IVFPQ / HNSW / LSH) is served by the exact scan, so results are
+    those of ``Flat`` (a superset of what the approximate types would return); ``nlist`` / ``nprobe`` /
+    ``is_trained`` keep their bookkeeping semantics;
+  * ``save_index`` writes this build's own container (header + float32 rows) under the reference's file
+    name ``index_{type}_{dim}d.faiss`` with the same ``_metadata.json`` sidecar; a file written by faiss
+    cannot be read (``load_index`` returns False);
+  * there is no CPU path: with no HIP device ``create_index`` logs the error and returns False.
+"""
+from __future__ import annotations
+
+import os
+import struct
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+
+from anorag_hip import METRIC_IP, METRIC_L2, FlatIndex
+from anorag_hip._lib import OPT_ADD_RAW
+from anorag_hip.compat import FileUtils, config, default_tmp, hip_available, logger
+
+_SUPPORTED = ("Flat", "IVFFlat", "IVFPQ", "HNSW", "LSH")
+_MAGIC = b"ANRFLAT1"
+
+
+class VectorIndex:
+    """Builds and manages the vector index (reference vector_index.py:9)."""
+
+    def __init__(self, embedding_dim: int = None):
+        self.embedding_dim = embedding_dim or config.get("vector_store.dimension", 768)
+        self.index_type = config.get("vector_store.index_type", "IVFFlat")
+        self.similarity_metric = config.get("vector_store.similarity_metric", "cosine")
+        self.use_gpu = config.get("performance.use_gpu", True) and hip_available()
+
+        self.nlist = config.get("vector_store.nlist", 100)
+        self.nprobe = config.get("vector_store.nprobe", 10)
+        self.m = config.get("vector_store.pq_m", 8)
+
+        self.index = None
+        self.is_trained = False
+        self.total_vectors = 0
+        self._ids: Optional[np.ndarray] = None  # caller-supplied ids (add_with_ids semantics), else sequential
+
+        self.index_dir = config.get("storage.vector_index_path")
+        if not self.index_dir:
+            work_dir = config.get("storage.work_dir")
+            self.index_dir = os.path.join(work_dir, "vector_index") if work_dir else default_tmp("anorag_vector_index")
+        FileUtils.ensure_dir(self.index_dir)
+
+        self.gpu_resource = None  # the reference's faiss.StandardGpuResources slot; nothing to hold here
+        self.device = int(config.get("anorag_hip.device", 0) or 0)
+        logger.info(f"VectorIndex initialized: dim={self.embedding_dim}, type={self.index_type}, gpu={self.use_gpu}")
+
+    # ------------------------------------------------------------------------------------------
+    def _cosine(self) -> bool:
+        # anything that is not 'cosine' means L2 (reference vector_index.py:69-74)
+        return self.similarity_metric == "cosine"
+
+    def create_index(self, index_type: str = None) -> bool:
+        index_type = index_type or self.index_type
+        try:
+            if index_type not in _SUPPORTED:
+                raise ValueError(f"Unsupported index type: {index_type}")
+            if self.index is not None:
+                self.index.close()
+            self.index = FlatIndex(int(self.embedding_dim), METRIC_IP if self._cosine() else METRIC_L2,
+                                   normalize=self._cosine(), device=self.device)
+            self._ids = None
+            if index_type in ("Flat", "HNSW", "LSH"):
+                self.is_trained = True
+            self.index_type = index_type
+            logger.info(f"Index created successfully: {index_type} (exact scan on HIP device {self.device})")
+            return True
+        except Exception as e:
+            logger.error(f"Failed to create index: {e}")
+            return False
+
+    def train_index(self, training_vectors: np.ndarray) -> bool:
+        if self.index is None:
+            logger.error("Index not created yet")
+            return False
+        if self.is_trained:
+            return True
+        try:
+            if self.index_type in ("IVFFlat", "IVFPQ") and len(training_vectors) < self.nlist * 2:
+                # the reference shrinks nlist and re-creates the index (vector_index.py:140-155)
+                old = self.nlist
+                self.nlist = max(1, len(training_vectors) // 2)
+                logger.warning(f"Training data insufficient for nlist={old}, adjusting to {self.nlist}")
+                if not self.create_index(self.index_type):
+                    self.nlist = old
+                    return False
+            self._preprocess_vectors(training_vectors)  # same validation the reference's train performs
+            self.is_trained = True  # an exact scan has nothing to learn
+            return True
+        except Exception as e:
+            logger.error(f"Failed to train index: {e}")
+            return False
+
+    def add_vectors(self, vectors: np.ndarray, ids: Optional[np.ndarray] = None) -> bool:
+        if self.index is None:
+            logger.error("Index not created yet")
+            return False
+        if not self.is_trained and self.index_type in ("IVFFlat", "IVFPQ"):
+            if not self.train_index(vectors):
+                return False
+        try:
+            v = np.asarray(vectors)
+            if v.ndim != 2:
+                raise ValueError("vectors must be 2-D")  # the reference fails in norm(axis=1) here
+            before = self.index.ntotal
+            self.index.add(v)  # cast / contiguity / cosine normalisation happen on the device
+            if ids is not None and self.index_type not in ("Flat", "HNSW", "LSH"):
+                ids = np.asarray(ids, dtype=np.int64).reshape(-1)
+                if len(ids) != len(v):
+                    raise ValueError("ids length mismatch")
+                seq = np.arange(before, before + len(v), dtype=np.int64)
+                if self._ids is not None or not np.array_equal(ids, seq):
+                    base = self._ids if self._ids is not None else np.arange(before, dtype=np.int64)
+                    self._ids = np.concatenate([base, ids])
+            elif self._ids is not None:
+                self._ids = np.concatenate([self._ids, np.arange(before, before + len(v), dtype=np.int64)])
+            self.total_vectors += len(vectors)
+            logger.info(f"Added {len(vectors)} vectors to index, total: {self.total_vectors}")
+            return True
+        except Exception as e:
+            logger.error(f"Failed to add vectors to index: {e}")
+            return False
+
+    def search(self, query_vectors: np.ndarray, top_k: int = 10, return_vectors: bool = False) -> List[Dict[str, Any]]:
+        if self.index is None:
+            logger.error("Index not created yet")
+            return []
+        if self.total_vectors == 0:
+            logger.warning("Index is empty")
+            return []
+        try:
+            q = np.asarray(query_vectors)
+            if q.ndim != 2:
+                raise ValueError("query_vectors must be 2-D")
+            scores, indices = self.index.search(q, int(top_k))
+            if self._ids is not None:
+                indices = np.where(indices >= 0, self._ids[np.clip(indices, 0, len(self._ids) - 1)], -1)
+            cosine = self._cosine()
+            results = []
+            for qi in range(len(q)):
+                hits = []
+                row_i, row_s = indices[qi], scores[qi]
+                for rank in range(int(top_k)):
+                    idx = row_i[rank]
+                    if idx == -1:
+                        continue
+                    score = float(row_s[rank])
+                    hits.append({"index": int(idx), "score": score, "rank": rank,
+                                 "similarity": score if cosine else 1.0 / (1.0 + score)})
+                results.append(hits)
+            return results[0] if len(results) == 1 else results
+        except Exception as e:
+            logger.error(f"Failed to search index: {e}")
+            return []
+
+    def _preprocess_vectors(self, vectors: np.ndarray) -> np.ndarray:
+        """Host view of what the device does at add/search time (reference vector_index.py:265-282)."""
+        if vectors.dtype != np.float32:
+            vectors = vectors.astype(np.float32)
+        if not vectors.flags["C_CONTIGUOUS"]:
+            vectors = np.ascontiguousarray(vectors)
+        if self._cosine():
+            norms = np.linalg.norm(vectors, axis=1, keepdims=True)
+            norms = np.where(norms == 0, 1, norms)
+            vectors = vectors / norms
+        return vectors
+
+    # ------------------------------------------------------------------------------------------
+    def _metadata(self) -> Dict[str, Any]:
+        return {"index_type": self.index_type, "embedding_dim": self.embedding_dim,
+                "similarity_metric": self.similarity_metric, "total_vectors": self.total_vectors,
+                "is_trained": self.is_trained, "nlist": self.nlist, "nprobe": self.nprobe}
+
+    def save_index(self, filename: str = None) -> str:
+        if self.index is None:
+            logger.error("No index to save")
+            return ""
+        try:
+            filename = filename or f"index_{self.index_type}_{self.embedding_dim}d.faiss"
+            filepath = os.path.join(self.index_dir, filename)
+            n = self.index.ntotal
+            with open(filepath, "wb") as f:
+                f.write(_MAGIC)
+                f.write(struct.pack("<iiiq", int(self.embedding_dim), int(self.index.metric),
+                                    int(self.index.normalize), int(n)))
+                has_ids = self._ids is not None
+                f.write(struct.pack("<i", 1 if has_ids else 0))
+                if has_ids:
+                    self._ids.astype("<i8").tofile(f)
+                step = 1 << 16
+                for s in range(0, n, step):
+                    self.index.reconstruct_n(s, min(step, n - s)).astype("<f4").tofile(f)
+            FileUtils.write_json(self._metadata(), filepath.replace(".faiss", "_metadata.json"))
+            logger.info(f"Index saved to {filepath}")
+            return filepath
+        except Exception as e:
+            logger.error(f"Failed to save index: {e}")
+            return ""
+
+    def load_index(self, filename: str) -> bool:
+        try:
+            filepath = os.path.join(self.index_dir, filename)
+            if not os.path.exists(filepath):
+                logger.error(f"Index file not found: {filepath}")
+                return False
+            with open(filepath, "rb") as f:
+                if f.read(8) != _MAGIC:
+                    raise ValueError("not an anorag-hip index file (faiss files cannot be read by this build)")
+                dim, metric, normalize, n = struct.unpack("<iiiq", f.read(20))
+                (has_ids,) = struct.unpack("<i", f.read(4))
+                ids = np.fromfile(f, dtype="<i8", count=n) if has_ids else None
+                if self.index is not None:
+                    self.index.close()
+                self.index = FlatIndex(dim, metric, normalize=bool(normalize), device=self.device)
+                self.index.reserve(n)
+                self.index.set_option(OPT_ADD_RAW, 1)  # rows were stored already preprocessed
+                step = 1 << 16
+                for s in range(0, n, step):
+                    m = min(step, n - s)
+                    rows = np.fromfile(f, dtype="<f4", count=m * dim).reshape(m, dim)
+                    self.index.add(rows)
+                self.index.set_option(OPT_ADD_RAW, 0)
+            self._ids = ids
+            self.embedding_dim = dim
+            self.similarity_metric = "cosine" if (metric == METRIC_IP and normalize) else self.similarity_metric
+            self.total_vectors = n
+            self.is_trained = True
+            meta_file = filepath.replace(".faiss", "_metadata.json")
+            if os.path.exists(meta_file):
+                md = FileUtils.read_json(meta_file)
+                self.index_type = md.get("index_type", self.index_type)
+                self.embedding_dim = md.get("embedding_dim", self.embedding_dim)
+                self.similarity_metric = md.get("similarity_metric", self.similarity_metric)
+                self.total_vectors = md.get("total_vectors", 0)
+                self.is_trained = md.get("is_trained", True)
+                self.nlist = md.get("nlist", self.nlist)
+                self.nprobe = md.get("nprobe", self.nprobe)
+            logger.info(f"Index loaded from {filepath}, vectors: {self.total_vectors}")
+            return True
+        except Exception as e:
+            logger.error(f"Failed to load index: {e}")
+            return False
+
+    def get_index_stats(self) -> Dict[str, Any]:
+        if self.index is None:
+            return {}
+        stats = {"index_type": self.index_type, "embedding_dim": self.embedding_dim,
+                 "similarity_metric": self.similarity_metric, "total_vectors": self.total_vectors,
+                 "is_trained": self.is_trained, "use_gpu": self.use_gpu, "ntotal": self.index.ntotal}
+        if self.index_type in ("IVFFlat", "IVFPQ"):
+            stats["nlist"] = self.nlist
+            stats["nprobe"] = self.nprobe
+        return stats
+
+    def remove_vectors(self, ids: np.ndarray) -> bool:
+        """faiss ``remove_ids`` semantics for a flat index: rows are dropped and the rest renumbered."""
+        if self.index is None:
+            logger.error("Index not created yet")
+            return False
+        try:
+            ids = np.unique(np.asarray(ids, dtype=np.int64))
+            n = self.index.ntotal
+            cur = self._ids if self._ids is not None else np.arange(n, dtype=np.int64)
+            keep = ~np.isin(cur, ids)
+            rows = self.index.reconstruct_n(0, n)[keep] if n else np.zeros((0, self.embedding_dim), np.float32)
+            self.index.reset()
+            self.index.set_option(OPT_ADD_RAW, 1)
+            if len(rows):
+                self.index.add(rows)
+            self.index.set_option(OPT_ADD_RAW, 0)
+            if self._ids is not None:
+                self._ids = cur[keep]
+            self.total_vectors -= len(ids)
+            logger.info(f"Removed {len(ids)} vectors from index")
+            return True
+        except Exception as e:
+            logger.error(f"Failed to remove vectors: {e}")
+            return False
+
+    def reset_index(self):
+        if self.index is not None:
+            self.index.reset()
+        self._ids = None
+        self.total_vectors = 0
+        self.is_trained = False
+        logger.info("Index reset completed")
+
+    def optimize_search_params(self, query_vectors: np.ndarray, ground_truth_indices: np.ndarray,
+                               target_recall: float = 0.9) -> Dict[str, Any]:
+        """nprobe sweep of the reference (vector_index.py:428-470); the scan is exact, so every nprobe
+        yields the same recall and the first tried value is kept."""
+        if self.index_type not in ("IVFFlat", "IVFPQ"):
+            logger.warning("Search parameter optimization only supported for IVF indices")
+            return {}
+        best = {"nprobe": self.nprobe, "recall": 0.0}
+        for nprobe in (1, 5, 10, 20, 50, 100):
+            if nprobe > self.nlist:
+                break
+            results = self.search(query_vectors, top_k=len(ground_truth_indices[0]))
+            if results and isinstance(results[0], dict):
+                results = [results]
+            recall = self._calculate_recall(results, ground_truth_indices)
+            if recall > best["recall"]:
+                best = {"nprobe": nprobe, "recall": recall}
+            if recall >= target_recall:
+                break
+        self.nprobe = best["nprobe"]
+        return best
+
+    def _calculate_recall(self, search_results, ground_truth) -> float:
+        if not search_results or len(ground_truth) == 0:
+            return 0.0
+        total = 0.0
+        for i, hits in enumerate(search_results):
+            if i >= len(ground_truth):
+                break
+            truth = set(ground_truth[i])
+            if truth:
+                total += len({h["index"] for h in hits} & truth) / len(truth)
+        return total / min(len(search_results), len(ground_truth))
+
+    def cleanup(self):
+        if self.index is not None:
+            try:
+                self.index.close()
+            except Exception:
+                pass
+        self.index = None
+        logger.info("VectorIndex cleanup completed")

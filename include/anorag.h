@@ -74,6 +74,7 @@ int anr_index_search_dev(anr_index *h, const float *q_dev, int64_t nq, int32_t k
 #define ANR_OPT_SAMPLE_ROWS 3     /* rows of the threshold sample (0 = auto)                          */
 #define ANR_OPT_CAND_CAP 4        /* per-query candidate buffer entries                               */
 #define ANR_OPT_TIMING 5          /* 1: record HIP-event time of the scan kernel in stats             */
+#define ANR_OPT_ADD_RAW 6         /* 1: adds store rows as given (already normalised: reloading a saved index) */
 int anr_index_set_option(anr_index *h, int32_t opt, int64_t value);
 
 typedef struct anr_search_stats {
@@ -114,6 +115,33 @@ int anr_merge_topk_dev(int32_t device, const float *Dp_dev, const int64_t *Ip_de
 int anr_fuse_lists(int32_t device, int32_t method, int64_t nq, const int64_t *ids, const double *scores,
                    const int64_t *offs, const double *weights /*[4]*/, double rrf_k, int32_t pool,
                    int64_t *out_ids, double *out_final, double *out_src, int32_t *out_count);
+
+/* ------------------------------------------------------------------------------------------------
+ * Sentence encoder: replaces SentenceTransformer.encode as called at
+ * vector_store/embedding_manager.py:392-399 (and :357) — transformer forward + pooling + optional L2
+ * normalisation for BERT-family models (bert / roberta / xlm-roberta).  Tokenisation is host work.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct anr_encoder anr_encoder;
+typedef struct anr_encoder_config {
+  int32_t n_layers, hidden, n_heads, intermediate;
+  int32_t vocab_size, max_positions, type_vocab_size;
+  int32_t pos_offset; /* 0 for bert; padding_idx + 1 (= 2) for roberta / xlm-roberta position ids          */
+  int32_t pooling;    /* 0 = mean over the attention mask, 1 = CLS token (sentence-transformers Pooling)    */
+  int32_t act;        /* 0 = gelu (erf)                                                                      */
+  float ln_eps;
+} anr_encoder_config;
+
+int anr_encoder_create(const anr_encoder_config *cfg, int32_t device, anr_encoder **out);
+int anr_encoder_destroy(anr_encoder *e);
+/* Upload one float32 tensor by name (row-major, nn.Linear weights as [out][in]):
+ *   emb.word emb.pos emb.type emb.ln.g emb.ln.b
+ *   L<i>.{q,k,v,o,ffn1,ffn2}.{w,b}   L<i>.ln1.{g,b} (after attention)   L<i>.ln2.{g,b} (after the FFN) */
+int anr_encoder_set_tensor(anr_encoder *e, const char *name, const float *data, int64_t n_elements);
+int anr_encoder_finalize(anr_encoder *e); /* fails if a tensor is missing */
+/* ids [B][L] (right-padded), lengths [B] = number of real tokens per row (the attention mask), type_ids
+ * [B][L] or NULL; out_host [B][hidden] float32.  normalize != 0 applies F.normalize(p=2, dim=1). */
+int anr_encoder_forward(anr_encoder *e, const int32_t *ids, const int32_t *lengths, const int32_t *type_ids,
+                        int32_t B, int32_t L, int32_t normalize, float *out_host);
 
 #ifdef __cplusplus
 }
