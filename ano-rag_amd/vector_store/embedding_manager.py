@@ -1,0 +1,342 @@
+"""MI355X drop-in for the reference's ``vector_store/embedding_manager.py`` (class ``EmbeddingManager``).
+
+Process-wide singleton with the reference's attributes and methods (embedding_manager.py:57-779).  The object
+in ``self.model`` is an ``anorag_hip.encoder.SentenceEncoder`` — the HIP forward pass — where the reference
+holds a ``sentence_transformers.SentenceTransformer``; text assembly, truncation, query prefixing and the
+never-raise conventions are the reference's.  Similarity helpers (``compute_similarity`` /
+``find_most_similar``) run through the device index.
+
+Model discovery looks in the same places as the reference (``<root>/models/embedding/...``,
+embedding_manager.py:250-339) plus ``embedding.model_path`` / ``$ANORAG_MODEL_DIR``; there is no download
+path (no network) and no CPU forward: if no local model directory is found, construction raises
+``RuntimeError`` exactly like the reference does when every load attempt fails (:158-160, :248).
+"""
+from __future__ import annotations
+
+import os
+import re
+import threading
+import unicodedata
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+
+from anorag_hip.compat import FileUtils, config, default_tmp, hip_available, logger
+
+_QUERY_PREFIX = "Represent this sentence for searching relevant passages: "
+
+
+class _Batcher:
+    """placeholder for the reference's never-used BatchProcessor attribute (embedding_manager.py:94-97)"""
+
+    def __init__(self, batch_size, use_gpu=True):
+        self.batch_size, self.use_gpu = batch_size, use_gpu
+
+
+class EmbeddingManager:
+    """Embedding manager (local models only)."""
+
+    _instance = None
+    _model_loaded = False
+    _lock = None
+
+    def __new__(cls):
+        if cls._instance is None:
+            cls._instance = super(EmbeddingManager, cls).__new__(cls)
+            cls._lock = threading.Lock()
+        return cls._instance
+
+    def __init__(self):
+        if self._model_loaded:
+            return
+        with self._lock:
+            if self._model_loaded:
+                return
+            self.model_name = config.get("embedding.model_name", "BAAI/bge-m3")
+            self.batch_size = config.get("embedding.batch_size", 32)
+            # the reference reports 'cuda' when torch sees a GPU (utils/gpu_utils.py:46-55); on ROCm that
+            # string is what torch calls the HIP device too
+            self.device = "cuda" if hip_available() else "cpu"
+            self.hip_device = int(config.get("anorag_hip.device", 0) or 0)
+            self.max_length = config.get("embedding.max_length", 512)
+            self.normalize_embeddings = config.get("embedding.normalize", True)
+            self.model = None
+            self.embedding_dim = None
+            self._load_local_model()
+            self.batch_processor = _Batcher(self.batch_size, config.get("performance.use_gpu", True))
+            self.cache_dir = config.get("storage.embedding_cache_path")
+            if not self.cache_dir:
+                work_dir = config.get("storage.work_dir")
+                self.cache_dir = os.path.join(work_dir, "embeddings") if work_dir else default_tmp("anorag_embeddings")
+            FileUtils.ensure_dir(self.cache_dir)
+            self.consistency_checker = None  # utils.model_consistency is outside the hot path
+            logger.info(f"EmbeddingManager initialized with model: {self.model_name}, device: {self.device}")
+            EmbeddingManager._model_loaded = True
+
+    @classmethod
+    def _reset_singleton(cls):
+        """tests only: drop the process-wide instance"""
+        inst = cls._instance
+        if inst is not None and getattr(inst, "model", None) is not None:
+            try:
+                inst.model.close()
+            except Exception:
+                pass
+        cls._instance = None
+        cls._model_loaded = False
+
+    # -- model discovery ---------------------------------------------------------------------------
+    def _get_local_model_paths(self, local_models_dir: str) -> List[str]:
+        name = self.model_name
+        paths = []
+        for extra in (config.get("embedding.model_path"), os.environ.get("ANORAG_MODEL_DIR")):
+            if extra:
+                paths.append(extra)
+        if os.path.isdir(name):
+            paths.append(name)
+        paths += [os.path.join(local_models_dir, name), os.path.join(local_models_dir, name.replace("/", "_")),
+                  os.path.join(local_models_dir, f"models--{name.replace('/', '--')}")]
+        for cache in (os.path.join(local_models_dir, name.replace("/", "_")),
+                      os.path.join(local_models_dir, f"models--{name.replace('/', '--')}")):
+            snaps = os.path.join(cache, "snapshots")
+            if os.path.isdir(snaps):
+                for d in sorted(os.listdir(snaps), reverse=True):
+                    sp = os.path.join(snaps, d)
+                    if os.path.isdir(sp) and (os.path.exists(os.path.join(sp, "modules.json"))
+                                              or os.path.exists(os.path.join(sp, "config.json"))):
+                        paths.insert(0, sp)
+                        break
+        if "sentence-transformers" in name:
+            paths.append(os.path.join(local_models_dir, name.split("/")[-1]))
+        return paths
+
+    def _load_local_model(self):
+        try:
+            root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+            candidates = self._get_local_model_paths(os.path.join(root, "models/embedding"))
+            for path in candidates:
+                if self._try_load_model_from_path(path):
+                    return
+            raise FileNotFoundError(f"no local model directory among {candidates}; this build cannot download")
+        except Exception as e:
+            logger.error(f"Failed to load the embedding model: {e}")
+            raise RuntimeError(f"Unable to load the embedding model: {e}")
+
+    def _try_load_model_from_path(self, model_path: str) -> bool:
+        if not os.path.isdir(model_path):
+            return False
+        if not any(os.path.exists(os.path.join(model_path, f))
+                   for f in ("modules.json", "config_sentence_transformers.json", "config.json")):
+            return False
+        try:
+            from anorag_hip.encoder import SentenceEncoder
+            self.model = SentenceEncoder(model_path, device=self.hip_device, trust_remote_code=True)
+            self.embedding_dim = self.model.get_sentence_embedding_dimension()
+            self.model.max_seq_length = self.max_length            # embedding_manager.py:361-362
+            self.model_name = model_path                           # :365 — the name becomes the path
+            logger.info(f"Model loaded from {model_path}, embedding dim {self.embedding_dim}")
+            return True
+        except Exception as e:
+            logger.warning(f"Loading the model from {model_path} failed: {e}")
+            return False
+
+    # -- encoding ------------------------------------------------------------------------------------
+    def encode_texts(self, texts: List[str], batch_size: Optional[int] = None, show_progress: bool = True,
+                     normalize: Optional[bool] = None) -> np.ndarray:
+        if not texts:
+            return np.array([])
+        batch_size = batch_size or self.batch_size
+        normalize = normalize if normalize is not None else self.normalize_embeddings
+        try:
+            return self.model.encode(self._preprocess_texts(texts), batch_size=batch_size,
+                                     show_progress_bar=show_progress, convert_to_numpy=True,
+                                     normalize_embeddings=normalize, device=self.device)
+        except Exception as e:
+            logger.error(f"Text encoding failed: {e}")
+            return np.zeros((len(texts), self.embedding_dim))  # float64 zeros, as in the reference (:407)
+
+    def encode_atomic_notes(self, atomic_notes: List[Dict[str, Any]], content_field: str = "content",
+                            include_metadata: bool = True) -> np.ndarray:
+        if not atomic_notes:
+            return np.array([])
+        strat = (config.get("embedding_strategy", {}) or {}).get("atomic_note_embedding", {})
+        text_strategy = strat.get("text_strategy", "title_raw_span")
+        priority = strat.get("field_priority", ["title", "raw_span", "original_text", "content"])
+        combo = strat.get("text_combination", {})
+        prep = strat.get("preprocessing", {})
+        qc = strat.get("quality_control", {})
+        texts = []
+        for note in atomic_notes:
+            try:
+                if text_strategy == "content_only":
+                    text = note.get(content_field, "")
+                elif text_strategy == "title_content":
+                    text = self._extract_title_content_text(note, content_field, combo)
+                else:
+                    text = self._extract_title_raw_span_text(note, priority, combo)
+                text = self._preprocess_embedding_text(text, prep)
+                if self._should_skip_note(text, qc):
+                    text = "Empty note"
+                texts.append(text)
+            except Exception as e:
+                logger.warning(f"Note text assembly failed: {e}")
+                texts.append("Empty note" if qc.get("skip_invalid_encoding", True)
+                             else note.get(content_field, "Empty note"))
+        return self.encode_texts(texts)
+
+    def _extract_title_raw_span_text(self, note, field_priority, text_combination) -> str:
+        title = note.get("title", "").strip()
+        content = note.get("content", "").strip() or note.get("raw_span", "").strip()
+        entities = note.get("entities", [])
+        ent = ""
+        if entities:
+            ent = ", ".join(str(e) for e in entities if e) if isinstance(entities, list) else str(entities)
+        text = f"{title} || {content} || ENTITIES: {ent}"
+        limit = text_combination.get("max_combined_length", 512)
+        if len(text) > limit:
+            how = text_combination.get("truncate_strategy", "tail")
+            if how == "head":
+                text = text[:limit]
+            elif how == "tail":
+                text = text[-limit:]
+            elif how == "middle":
+                text = text[:limit // 2] + text[-(limit // 2):]
+        return text or "Empty note"
+
+    def _extract_title_content_text(self, note, content_field, text_combination) -> str:
+        parts = [p for p in (note.get("title", "").strip(), note.get(content_field, "").strip()) if p]
+        return text_combination.get("separator", " ").join(parts) or "Empty note"
+
+    def _preprocess_embedding_text(self, text: str, preprocessing: Dict[str, Any]) -> str:
+        if not text:
+            return text
+        if preprocessing.get("remove_extra_whitespace", True):
+            text = re.sub(r"\s+", " ", text).strip()
+        if preprocessing.get("normalize_unicode", True):
+            text = unicodedata.normalize("NFKC", text)
+        if preprocessing.get("remove_control_chars", True):
+            text = re.sub(r"[\x00-\x1f\x7f-\x9f]", "", text)
+        return text
+
+    def _should_skip_note(self, text: str, quality_control: Dict[str, Any]) -> bool:
+        if quality_control.get("skip_empty_notes", True) and not text.strip():
+            return True
+        return len(text.strip()) < quality_control.get("min_text_length", 3)
+
+    def encode_queries(self, queries: List[str], query_prefix: str = _QUERY_PREFIX) -> np.ndarray:
+        if not queries:
+            return np.array([])
+        if "bge" in self.model_name.lower() and query_prefix:  # tested against the *path* once loaded (:365, :558)
+            queries = [query_prefix + q for q in queries]
+        return self.encode_texts(queries)
+
+    def _preprocess_texts(self, texts: List[str]) -> List[str]:
+        out = []
+        for t in texts:
+            t = t.strip()
+            if len(t) > self.max_length * 4:
+                t = t[:self.max_length * 4]
+            out.append(t or "Empty content")
+        return out
+
+    # -- similarity helpers (embedding_manager.py:586-660) through the device index ---------------------
+    def compute_similarity(self, embeddings1: np.ndarray, embeddings2: np.ndarray, metric: str = "cosine") -> np.ndarray:
+        if embeddings1.size == 0 or embeddings2.size == 0:
+            return np.array([])
+        try:
+            a = embeddings1.reshape(1, -1) if embeddings1.ndim == 1 else embeddings1
+            b = embeddings2.reshape(1, -1) if embeddings2.ndim == 1 else embeddings2
+            if metric not in ("cosine", "dot", "euclidean"):
+                raise ValueError(f"unsupported similarity metric: {metric}")
+            from anorag_hip import METRIC_IP, METRIC_L2, FlatIndex
+            n = b.shape[0]
+            if metric == "cosine":
+                # reference: x / (||x|| + 1e-8) on both sides, then the dot product
+                a = a / (np.linalg.norm(a, axis=1, keepdims=True) + 1e-8)
+                b = b / (np.linalg.norm(b, axis=1, keepdims=True) + 1e-8)
+            idx = FlatIndex(b.shape[1], METRIC_L2 if metric == "euclidean" else METRIC_IP, normalize=False,
+                            device=self.hip_device)
+            try:
+                idx.add(b)
+                sim = np.empty((a.shape[0], n), dtype=np.float64)
+                kmax = 1024
+                if n <= kmax:
+                    D, I = idx.search(a, n)
+                    np.put_along_axis(sim, I, D.astype(np.float64), axis=1)
+                else:
+                    raise ValueError(f"compute_similarity handles at most {kmax} candidates on the device")
+            finally:
+                idx.close()
+            if metric == "euclidean":
+                sim = 1.0 / (1.0 + np.sqrt(np.maximum(sim, 0.0)))
+            return sim.astype(np.result_type(embeddings1.dtype, embeddings2.dtype), copy=False)
+        except Exception as e:
+            logger.error(f"Similarity computation failed: {e}")
+            return np.array([])
+
+    def find_most_similar(self, query_embedding: np.ndarray, candidate_embeddings: np.ndarray, top_k: int = 10,
+                          metric: str = "cosine") -> List[Dict[str, Any]]:
+        if query_embedding.size == 0 or candidate_embeddings.size == 0:
+            return []
+        try:
+            from anorag_hip import METRIC_IP, METRIC_L2, FlatIndex
+            q = query_embedding.reshape(1, -1)
+            c = candidate_embeddings.reshape(1, -1) if candidate_embeddings.ndim == 1 else candidate_embeddings
+            if metric not in ("cosine", "dot", "euclidean"):
+                raise ValueError(f"unsupported similarity metric: {metric}")
+            if metric == "cosine":
+                q = q / (np.linalg.norm(q, axis=1, keepdims=True) + 1e-8)
+                c = c / (np.linalg.norm(c, axis=1, keepdims=True) + 1e-8)
+            idx = FlatIndex(c.shape[1], METRIC_L2 if metric == "euclidean" else METRIC_IP, normalize=False,
+                            device=self.hip_device)
+            try:
+                idx.add(c)
+                k = min(int(top_k), c.shape[0], 1024)
+                D, I = idx.search(q, k)
+            finally:
+                idx.close()
+            out = []
+            for s, i in zip(D[0], I[0]):
+                if i < 0:
+                    continue
+                s = float(s)
+                out.append({"index": int(i), "similarity": 1.0 / (1.0 + s ** 0.5) if metric == "euclidean" else s})
+            return out
+        except Exception as e:
+            logger.error(f"find_most_similar failed: {e}")
+            return []
+
+    # -- metadata --------------------------------------------------------------------------------------
+    def get_model_info(self) -> Dict[str, Any]:
+        return {"model_name": self.model_name, "embedding_dim": self.embedding_dim, "device": str(self.device),
+                "max_length": self.max_length, "batch_size": self.batch_size,
+                "normalize_embeddings": self.normalize_embeddings}
+
+    def cleanup(self):
+        logger.info("EmbeddingManager cleanup completed")
+
+    def register_model_signature(self) -> None:
+        return None
+
+    def get_model_signature(self) -> Optional[Dict[str, Any]]:
+        if not self.model:
+            return None
+        return {"model_name": self.model_name, "model_type": "sentence_transformer", "dimension": self.embedding_dim,
+                "max_length": self.max_length, "normalize": self.normalize_embeddings,
+                "metadata": {"device": str(self.device), "batch_size": self.batch_size}}
+
+    def validate_model_consistency(self, other_signature: Optional[Dict[str, Any]] = None) -> Tuple[bool, Optional[str]]:
+        if not self.model:
+            return True, None
+        try:
+            cur = self.get_model_signature()
+            if not cur:
+                return False, "Failed to create model signature"
+            if other_signature:
+                for attr in ("model_name", "model_type", "dimension", "normalize"):
+                    if cur.get(attr) != other_signature.get(attr):
+                        return False, f"Inconsistent {attr}: {cur.get(attr)} vs {other_signature.get(attr)}"
+                return True, "Model signatures are consistent"
+            return True, "Model consistency validated"
+        except Exception as e:
+            return False, str(e)

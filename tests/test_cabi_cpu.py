@@ -1,0 +1,110 @@
+"""CPU tests (no GPU needed): the C-ABI shared library loads, exports every symbol include/anorag.h declares,
+fails loudly (no silent fallback) when there is no device; host-side logic of the drop-in classes."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    with open(os.path.join(ROOT, "include", "anorag.h")) as f:
+        text = f.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(anr_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from anorag_hip import _lib
+    lib = _lib.load()
+    names = _declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/anorag.h but not exported"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
+    assert lib.anr_version().startswith(b"anorag-hip")
+
+
+def test_no_device_fails_loudly():
+    from anorag_hip import AnoragError, FlatIndex, _lib
+    if _lib.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(AnoragError) as e:
+        FlatIndex(64)
+    assert "no HIP device" in str(e.value)
+    # argument validation happens before any device work
+    lib = _lib.load()
+    h = C.c_void_p()
+    assert lib.anr_index_create(0, 0, 1, 0, C.byref(h)) == -1 and b"dim" in lib.anr_last_error()
+    assert lib.anr_index_create(64, 7, 1, 0, C.byref(h)) == -1
+    assert lib.anr_index_search(None, None, 1, 1, None, None) == -1
+    from retrieval.hybrid_search import HybridSearcher
+    hs = HybridSearcher({"retrieval": {"hybrid": {"weights": {"dense": 1.0}}}})
+    with pytest.raises(AnoragError):
+        hs.fuse(dense=[("a", 1.0)])          # the product path never falls back to Python arithmetic
+    from vector_store.vector_index import VectorIndex
+    vi = VectorIndex(32)
+    assert vi.use_gpu is False and vi.create_index("Flat") is False and vi.search(np.zeros((1, 32))) == []
+
+
+def test_hybrid_searcher_config_surface():
+    from retrieval.hybrid_search import HybridSearcher, create_hybrid_searcher
+    hs = create_hybrid_searcher({})
+    assert (hs.candidate_pool, hs.enabled, hs.fusion_method, hs.weights, hs.rrf_k) == (50, True, "linear", {}, 60)
+
+    class Obj:
+        def load_config(self):
+            return {"retrieval": {"candidate_pool": 80, "hybrid": {"enabled": False, "fusion_method": "rrf",
+                                                                    "weights": {"dense": 1.0}, "rrf_k": 10}}}
+    hs = HybridSearcher(Obj())
+    assert hs.candidate_pool == 80 and hs.fusion_method == "rrf" and hs.rrf_k == 10
+    assert hs.fuse(dense=[("a", 1.0)]) == []       # disabled -> [] without touching the device
+    assert hs._normalize({}) == {} and hs._normalize({"a": 0.0}) == {"a": 0.0}
+    assert hs._normalize({"a": 2.0, "b": 1.0}) == {"a": 1.0, "b": 0.5}
+
+
+def test_vector_index_host_view_matches_oracle_preprocess():
+    from oracle import flat_index as orc
+    from vector_store.vector_index import VectorIndex
+    vi = VectorIndex(16)
+    x = np.random.default_rng(0).standard_normal((20, 16))
+    x[3] = 0
+    a = vi._preprocess_vectors(np.asfortranarray(x))
+    b = orc.preprocess_vectors(x)
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"] and np.array_equal(a, b)
+    assert vi.index_type == "IVFFlat" and vi.similarity_metric == "cosine" and vi.nlist == 100 and vi.nprobe == 10
+    assert vi.add_vectors(x) is False and vi.save_index() == "" and vi.get_index_stats() == {}
+    assert vi.train_index(x) is False and vi.remove_vectors(np.array([1])) is False
+    assert vi._calculate_recall([[{"index": 1}, {"index": 2}]], np.array([[1, 3]])) == 0.5
+
+
+def test_embedding_manager_text_rules_without_model():
+    from vector_store.embedding_manager import EmbeddingManager
+    em = object.__new__(EmbeddingManager)   # text helpers only; the constructor needs a model + device
+    em.max_length = 8
+    assert em._preprocess_texts([" ab ", "", "x" * 40]) == ["ab", "Empty content", "x" * 32]
+    note = {"title": " T ", "content": "", "raw_span": " body ", "entities": ["a", "", "b"]}
+    assert em._extract_title_raw_span_text(note, [], {}) == "T || body || ENTITIES: a, b"
+    long = {"title": "t", "content": "c" * 600}
+    assert len(em._extract_title_raw_span_text(long, [], {})) == 512
+    assert em._extract_title_raw_span_text(long, [], {})[-14:] == " || ENTITIES: "
+    assert em._preprocess_embedding_text("a \n  b\x07 Ａ", {}) == "a b A"
+    assert em._should_skip_note("ab", {}) and not em._should_skip_note("abc", {})
+    assert em._extract_title_content_text({"title": "a", "content": "b"}, "content", {}) == "a b"
+
+
+def test_model_dir_reader_and_name_map(tmp_path):
+    from anorag_hip.encoder import map_hf_name, read_model_dir
+    from oracle import encoder as oenc
+    d = oenc.make_synthetic_model(str(tmp_path / "m"), layers=1, hidden=64, heads=2, intermediate=128, vocab=300,
+                                  max_pos=64, pooling="cls")
+    info = read_model_dir(d)
+    assert info["pooling"] == "cls" and info["normalize_module"] and info["pos_offset"] == 0
+    assert info["max_seq_length"] == 64
+    assert map_hf_name("bert.encoder.layer.3.attention.self.query.weight") == "L3.q.w"
+    assert map_hf_name("encoder.layer.0.output.LayerNorm.bias") == "L0.ln2.b"
+    assert map_hf_name("roberta.embeddings.word_embeddings.weight") == "emb.word"
+    assert map_hf_name("pooler.dense.weight") is None

@@ -1,0 +1,161 @@
+"""GPU tests of the drop-in classes (reference API surface): VectorIndex result shaping and persistence,
+EmbeddingManager text handling, VectorRetriever build/search/retrieve against the oracle pipeline."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import encoder as oenc
+from oracle import flat_index as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def cfg(tmp_path):
+    from anorag_hip.compat import config
+    config.reset()
+    config.set("storage.vector_index_path", str(tmp_path / "vidx"))
+    config.set("storage.vector_store_path", str(tmp_path / "vstore"))
+    config.set("storage.embedding_cache_path", str(tmp_path / "ecache"))
+    config.set("vector_store.index_type", "Flat")
+    yield config
+    config.reset()
+
+
+def test_vector_index_surface(cfg, tmp_path):
+    from vector_store import VectorIndex
+    x = np.random.default_rng(0).standard_normal((500, 96)).astype(np.float64)   # float64 in, cast like the reference
+    q = np.random.default_rng(1).standard_normal((3, 96)).astype(np.float32)
+    vi = VectorIndex(96)
+    assert vi.search(q) == []                     # no index yet
+    assert vi.create_index() is True and vi.is_trained
+    assert vi.search(q) == []                     # empty index
+    assert vi.add_vectors(x, np.arange(500)) is True and vi.total_vectors == 500
+    res = vi.search(q, top_k=7)
+    xn, qn = orc.preprocess_vectors(x), orc.preprocess_vectors(q)
+    Dr, Ir = orc.flat_search(qn, xn, 7, "ip")
+    exp = orc.shape_results(Dr, Ir, "cosine")
+    assert [[h["index"] for h in r] for r in res] == [[h["index"] for h in r] for r in exp]
+    for r, e in zip(res, exp):
+        for a, b in zip(r, e):
+            assert set(a) == {"index", "score", "rank", "similarity"}
+            assert a["rank"] == b["rank"] and abs(a["score"] - b["score"]) <= 1e-4 and a["similarity"] == a["score"]
+    single = vi.search(q[:1], top_k=3)            # one query -> flat list (vector_index.py:255-257)
+    assert isinstance(single[0], dict) and len(single) == 3
+    assert vi.search(q[0], top_k=3) == []         # 1-D input fails inside -> [] like the reference
+    assert vi.add_vectors(x[0]) is False
+    big = vi.search(q[:1], top_k=600)             # k > ntotal: -1 ids dropped
+    assert len(big) == 500
+    # persistence under the reference's file names
+    path = vi.save_index()
+    assert path.endswith("index_Flat_96d.faiss") and os.path.exists(path.replace(".faiss", "_metadata.json"))
+    vi2 = VectorIndex(96)
+    assert vi2.load_index("index_Flat_96d.faiss") is True and vi2.total_vectors == 500
+    assert [h["index"] for h in vi2.search(q[:1], top_k=7)] == [h["index"] for h in res[0]]
+    assert vi2.load_index("missing.faiss") is False
+    st = vi.get_index_stats()
+    assert st["ntotal"] == 500 and st["index_type"] == "Flat"
+    assert vi.remove_vectors(np.array([0, 1])) is True and vi.index.ntotal == 498
+    vi.reset_index()
+    assert vi.total_vectors == 0 and vi.is_trained is False
+    # IVF bookkeeping: training shrinks nlist for tiny corpora, custom ids are honoured
+    cfg.set("vector_store.index_type", "IVFFlat")
+    iv = VectorIndex(96)
+    assert iv.create_index() and not iv.is_trained
+    assert iv.add_vectors(x[:50], np.arange(1000, 1050)) and iv.is_trained and iv.nlist == 25
+    assert iv.search(q[:1], top_k=1)[0]["index"] >= 1000
+    # L2: any metric other than 'cosine' (vector_index.py:69-74)
+    cfg.set("vector_store.similarity_metric", "dot_product")
+    l2 = VectorIndex(96)
+    l2.create_index("Flat")
+    l2.add_vectors(x)
+    r = l2.search(q[:1], top_k=2)
+    Dl, Il = orc.flat_search(q[:1], x.astype(np.float32), 2, "l2")
+    assert [h["index"] for h in r] == Il[0].tolist()
+    assert abs(r[0]["similarity"] - 1.0 / (1.0 + r[0]["score"])) < 1e-12
+    assert l2.create_index("Bogus") is False
+    for v in (vi, vi2, iv, l2):
+        v.cleanup()
+
+
+@pytest.fixture()
+def model_dir(tmp_path):
+    return oenc.make_synthetic_model(str(tmp_path / "bge-small-synth"), layers=2, hidden=128, heads=4,
+                                     intermediate=512, pooling="cls", max_pos=128)
+
+
+def test_embedding_manager_and_retriever(cfg, model_dir):
+    from vector_store import EmbeddingManager, VectorRetriever
+    EmbeddingManager._reset_singleton()
+    cfg.set("embedding.model_path", model_dir)
+    cfg.set("embedding.max_length", 64)
+    cfg.set("embedding.batch_size", 8)
+    cfg.set("vector_store.similarity_threshold", 0.0001)
+    em = EmbeddingManager()
+    assert em is EmbeddingManager() and em.embedding_dim == 128 and em.model_name == model_dir
+    assert em.encode_texts([]).size == 0 and em.encode_queries([]).size == 0
+    words = oenc.synthetic_sentences(model_dir, 40, seed=11, min_words=4, max_words=12)
+    e1 = em.encode_texts(words[:5])
+    ref = oenc.encode(model_dir, words[:5], normalize=True, max_seq_length=64)
+    assert e1.dtype == np.float32 and np.sum(e1 * ref, axis=1).min() > 0.9995
+    # 'bge' in the *path* -> queries get the instruction prefix (embedding_manager.py:552-559)
+    qe = em.encode_queries(words[:2])
+    qref = oenc.encode(model_dir, ["Represent this sentence for searching relevant passages: " + w for w in words[:2]],
+                       normalize=True, max_seq_length=64)
+    assert np.sum(qe * qref, axis=1).min() > 0.9995
+    assert em._preprocess_texts(["  x  ", "", "a" * 1000]) == ["x", "Empty content", "a" * 256]
+    notes = [{"note_id": f"n{i}", "title": f"t{i}", "content": w, "entities": ["e1", "e2"]} for i, w in enumerate(words)]
+    notes[3]["content"] = ""
+    t = em._extract_title_raw_span_text(notes[0], [], {})
+    assert t == f"t0 || {words[0]} || ENTITIES: e1, e2"
+    sim = em.compute_similarity(e1, e1)
+    assert sim.shape == (5, 5) and np.allclose(np.diag(sim), 1.0, atol=1e-4)
+    top = em.find_most_similar(e1[0], e1, top_k=2)
+    assert top[0]["index"] == 0 and set(top[0]) == {"index", "similarity"}
+    ok, _ = em.validate_model_consistency()
+    assert ok
+
+    vr = VectorRetriever()
+    assert vr.search(["x"]) == [[]] and vr.retrieve("x") == []
+    assert vr.build_index([]) is False
+    assert vr.build_index(notes) is True
+    assert vr.note_embeddings.shape == (40, 128) and vr.note_id_to_index["n7"] == 7
+    assert not hasattr(vr, "id_to_index")          # reference quirk kept
+    for f in ("atomic_notes.json", "note_embeddings.npz", "id_mappings.json", "index_Flat_128d.faiss"):
+        assert os.path.exists(os.path.join(vr.data_dir if "faiss" not in f else vr.vector_index.index_dir, f))
+    res = vr.search(words[:3], top_k=5)
+    assert len(res) == 3 and all(len(r) <= 5 for r in res)
+    # expected ids from the oracle pipeline: oracle encoder of the same texts + oracle flat search
+    note_texts = [em._preprocess_embedding_text(em._extract_title_raw_span_text(n, [], {}), {}) for n in notes]
+    xn = oenc.encode(model_dir, [s if len(s.strip()) >= 3 else "Empty note" for s in note_texts], normalize=True,
+                     max_seq_length=64)
+    qn = oenc.encode(model_dir, ["Represent this sentence for searching relevant passages: " + w for w in words[:3]],
+                     normalize=True, max_seq_length=64)
+    s64 = orc.exact_scores(orc.preprocess_vectors(qn), orc.preprocess_vectors(xn), "ip")
+    for qi, hits in enumerate(res):
+        info = hits[0]["retrieval_info"]
+        assert set(info) == {"similarity", "score", "rank", "query", "retrieval_method"}
+        assert info["query"] == words[qi] and info["retrieval_method"] == "vector_search"
+        got = [vr.note_id_to_index[h["note_id"]] for h in hits]
+        # f16 encoder vs f32 oracle embeddings: compare through the oracle scores with a tolerance
+        best = np.sort(s64[qi])[::-1][:5]
+        assert np.allclose([s64[qi][g] for g in got], best[:len(got)], atol=5e-3)
+        assert all(abs(h["retrieval_info"]["similarity"] - s64[qi][g]) < 5e-3 for h, g in zip(hits, got))
+    slim = vr.search_single(words[0], top_k=2, include_metadata=False)
+    assert set(slim[0]) == {"note_id", "content", "paragraph_idxs", "retrieval_info"}
+    boosted = vr.retrieve(words[0], top_k=3, boost_entities=[words[0].split()[0]], must_have_terms=["zzzz"])
+    assert boosted and "original_similarity" in boosted[0]["retrieval_info"]
+    assert "downweighted_missing_terms" in boosted[0]["retrieval_info"]["adjustments"]
+    assert vr.add_notes([{"note_id": "new1", "title": "x", "content": words[0]}]) is True
+    assert vr.vector_index.total_vectors == 41 and vr.note_embeddings.shape[0] == 41
+    assert vr.get_similar_notes("n0", top_k=3) is not None
+    assert vr.remove_notes(["new1"]) is True and len(vr.atomic_notes) == 40
+    vr2 = VectorRetriever()
+    vr2.data_dir, vr2.vector_index.index_dir = vr.data_dir, vr.vector_index.index_dir
+    assert vr2.build_index(notes) is True            # reloads the saved index (same count + first id)
+    assert vr2.vector_index.total_vectors == 40
+    vr.clear_index()
+    assert vr.search(["x"]) == [[]]
+    vr.cleanup()
+    EmbeddingManager._reset_singleton()

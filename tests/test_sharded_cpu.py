@@ -1,0 +1,62 @@
+"""CPU (gloo, world_size 2) test of the row-sharded search orchestration: partition, local top-k, id offsets,
+all-gather of the partials and the host merge reproduce the single-index oracle result.  The per-shard search
+is the oracle here (no GPU in this container); on the GPU the same class wraps FlatIndex.search."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from anorag_hip.sharded import ShardedSearcher, merge_topk_host, shard_bounds
+from oracle import flat_index as orc
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n, d, nq, k, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    x = orc.preprocess_vectors(np.random.default_rng(1234).standard_normal((n, d), dtype=np.float32))
+    x[n // 2 + 3] = x[5]   # a duplicate row straddling the shard boundary: tie must go to the lower global id
+    q = orc.preprocess_vectors(np.random.default_rng(4321).standard_normal((nq, d), dtype=np.float32))
+    lo, hi = shard_bounds(n, world, rank)
+    shard = x[lo:hi]
+    s = ShardedSearcher(lambda qq, kk: orc.flat_search(qq, shard, kk, "ip"), lo, True)
+    D, I = s.search(q, k)
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), D=D, I=I)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_search_matches_single_index(tmp_path):
+    n, d, nq, k, world = 5001, 64, 9, 20, 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, n, d, nq, k, str(tmp_path)), nprocs=world, join=True)
+    x = orc.preprocess_vectors(np.random.default_rng(1234).standard_normal((n, d), dtype=np.float32))
+    x[n // 2 + 3] = x[5]
+    q = orc.preprocess_vectors(np.random.default_rng(4321).standard_normal((nq, d), dtype=np.float32))
+    Dr, Ir = orc.flat_search(q, x, k, "ip")
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), f"r{r}.npz"))
+        assert np.array_equal(got["I"], Ir)
+        assert np.array_equal(got["D"], Dr)
+
+
+def test_shard_bounds_and_merge_edges():
+    assert [shard_bounds(10, 4, r) for r in range(4)] == [(0, 3), (3, 6), (6, 9), (9, 10)]
+    assert shard_bounds(2, 4, 3) == (2, 2)          # empty trailing shard
+    # padding (-1) sorts last, ties by id, L2 order
+    Dp = np.array([[[0.9, 0.5, -orc.FLT_MAX]], [[0.9, 0.7, 0.1]]], dtype=np.float32)
+    Ip = np.array([[[7, 2, -1]], [[3, 11, 12]]], dtype=np.int64)
+    D, I = merge_topk_host(Dp, Ip, 4, True)
+    assert I.tolist() == [[3, 7, 11, 2]] and D.tolist()[0][:2] == [np.float32(0.9)] * 2
+    D, I = merge_topk_host(Dp[:, :, :2], Ip[:, :, :2], 6, False)
+    assert I.tolist() == [[2, 11, 3, 7, -1, -1]] and D[0, 4] == orc.FLT_MAX
