@@ -23,6 +23,7 @@ OPT_SAMPLE_ROWS = 3
 OPT_CAND_CAP = 4
 OPT_TIMING = 5
 OPT_ADD_RAW = 6
+OPT_RESERVE_CUS = 7
 
 
 class AnoragError(RuntimeError):
@@ -77,6 +78,12 @@ SIGNATURES = {
         C.c_int,
         [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],
     ),
+    "anr_index_search_dev_async": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],
+    ),
+    "anr_index_sync": (C.c_int, [C.c_void_p]),
+    "anr_index_reset_stats": (C.c_int, [C.c_void_p]),
     "anr_index_set_option": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64]),
     "anr_index_last_stats": (C.c_int, [C.c_void_p, C.POINTER(SearchStats)]),
     "anr_normalize_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32]),

@@ -81,6 +81,20 @@ class FlatIndex:
             "anr_index_search_dev",
         )
 
+    def search_device_async(self, q_ptr: int, nq: int, k: int, d_ptr: int, i_ptr: int, stream: int = 0) -> None:
+        """enqueue only; results are final after ``sync()`` (see include/anorag.h)"""
+        _lib.check(
+            self._lib.anr_index_search_dev_async(self._h, C.c_void_p(q_ptr), int(nq), int(k), C.c_void_p(d_ptr),
+                                                 C.c_void_p(i_ptr), C.c_void_p(stream)),
+            "anr_index_search_dev_async",
+        )
+
+    def sync(self) -> None:
+        _lib.check(self._lib.anr_index_sync(self._h), "anr_index_sync")
+
+    def reset_stats(self) -> None:
+        _lib.check(self._lib.anr_index_reset_stats(self._h), "anr_index_reset_stats")
+
     def set_option(self, opt: int, value: int) -> None:
         _lib.check(self._lib.anr_index_set_option(self._h, int(opt), int(value)), "anr_index_set_option")
 

@@ -2,11 +2,15 @@
 // index_kernels.hpp.  Replaces faiss.IndexFlatIP / IndexFlatL2 at the call sites of the reference's
 // vector_store/vector_index.py (:77-80 create, :196 add, :223 search, :415-426 reset).
 //
-// Search pipeline for one batch of <= 64 queries:
-//   prepq -> [sample: scan<DENSE> on a strided tile sample -> select -> threshold ladder]
-//         -> scan (f16 MFMA, threshold-gated candidate append) -> select top-K' -> rescore (f32 rows,
-//         f64 accumulate) -> finalize (sort, write top-k, certificate)
-//   queries whose certificate fails are answered by the dense exact path (k_exact_dense + select).
+// Search pipeline for one batch of <= 64 queries, three stages on three streams:
+//   pre  : prepq -> scan<DENSE> on a strided tile sample -> select -> threshold ladder
+//   scan : the f16 MFMA scan (threshold-gated candidate append) — the only HBM-heavy kernel
+//   post : select top-K' -> rescore (f32 rows, f64 accumulate) -> finalize (sort, top-k, certificate)
+// Batches rotate over kWorkspaces workspaces, so the pre/post stages of neighbouring batches run beside
+// the scan of the current one (the scan leaves `reserve_cus` CUs free for them when searches are issued
+// asynchronously).  Queries whose certificate fails are answered by the dense exact path
+// (k_exact_dense + select) when the batch is retired.
+#include <algorithm>
 #include <mutex>
 #include <vector>
 
@@ -14,6 +18,41 @@
 #include "index_kernels.hpp"
 
 using namespace anr;
+
+namespace {
+constexpr int kWorkspaces = 3;
+
+struct Workspace {
+  // device buffers of one in-flight batch
+  float *q32 = nullptr;
+  _Float16 *q16 = nullptr;
+  float *qstat = nullptr;
+  float *qstage = nullptr;  // [64][dim] staging of host queries
+  float *dense = nullptr;
+  int64_t dense_ld = 0;
+  float *ladder = nullptr;
+  unsigned *lcum = nullptr;   // [64][kLadder][kCumStride]
+  unsigned *cntb = nullptr;   // [64][n_cu]
+  unsigned *ncand = nullptr;  // [64] candidates, then [64] overflow flags
+  uint2 *cand = nullptr;      // [n_cu][64][cand_cap]
+  int64_t cand_alloc = 0;
+  float *sel_rank = nullptr;
+  unsigned *sel_row = nullptr;
+  int *sel_m = nullptr;
+  float *exact = nullptr;
+  int *flags = nullptr;
+  int *flags_host = nullptr;       // pinned [64]
+  unsigned *cnt_host = nullptr;    // pinned [128]
+  hipEvent_t ev_in = nullptr, ev_pre = nullptr, ev_scan = nullptr, ev_done = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+  // the batch in flight
+  bool in_flight = false;
+  bool sparse = false, timed = false, exact_all = false;
+  int nq = 0, k = 0, M = 0;
+  int64_t out_off = 0, sample_rows = 0, scan_bytes = 0;
+  float *D = nullptr;
+  int64_t *I = nullptr;
+};
+}  // namespace
 
 struct anr_index {
   int dim = 0, dimp = 0, kb = 0;
@@ -24,7 +63,8 @@ struct anr_index {
   _Float16 *x16 = nullptr;
   float *rowbias = nullptr;
   unsigned *xstat = nullptr;  // [4]
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;                        // adds, exact path, copies
+  hipStream_t s_pre = nullptr, s_scan = nullptr, s_post = nullptr;
   std::mutex mu;
 
   // options
@@ -34,34 +74,20 @@ struct anr_index {
   int64_t cand_cap = 512;   // entries per (block, query) candidate list
   int timing = 0;
   int add_raw = 0;          // adds store the rows as given (already preprocessed, e.g. a reloaded index)
+  int reserve_cus = 16;     // CUs the scan leaves to the pre/post stages of other batches (async searches)
 
-  // workspace (one batch)
-  float *q32 = nullptr;
-  _Float16 *q16 = nullptr;
-  float *qstat = nullptr;
-  float *qstage = nullptr;   // device staging of host queries [64][dim]
-  float *dense = nullptr;
-  int64_t dense_ld = 0;
-  float *ladder = nullptr;
-  unsigned *lcum = nullptr;   // [64][kLadder][kCumStride]
-  unsigned *cntb = nullptr;   // [64][n_cu]
-  unsigned *ncand = nullptr;  // [64]
-  uint2 *cand = nullptr;      // [n_cu][64][cand_cap]
-  int64_t cand_alloc = 0;
-  float *sel_rank = nullptr;
-  unsigned *sel_row = nullptr;
-  int *sel_m = nullptr;
-  unsigned *overflow = nullptr;
-  float *exact = nullptr;
-  int *flags = nullptr;
-  int *flags_host = nullptr;   // pinned
-  unsigned *cnt_host = nullptr;  // pinned [64]
+  Workspace ws[kWorkspaces];
+  bool ws_ready = false;
+  int next_ws = 0;
+  bool f16_unusable = false;  // a stored value left the f16 range (L2 metric with large inputs)
+  bool xstat_dirty = true;
+
   float *xdense = nullptr;      // exact dense path [4][xdense_ld]
   int64_t xdense_ld = 0;
   float *d_out = nullptr;       // staging for host-pointer searches
   int64_t *i_out = nullptr;
   int64_t out_alloc = 0;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_call[2] = {nullptr, nullptr};
 
   anr_search_stats stats{};
 };
@@ -83,8 +109,11 @@ void dev_free(T *&p) {
   p = nullptr;
 }
 
+int drain(anr_index *h);  // retire every in-flight batch
+
 int grow_storage(anr_index *h, int64_t need_rows) {
   if (need_rows <= h->cap) return ANR_OK;
+  ANR_TRY(drain(h));
   int64_t ncap = h->cap ? h->cap : 1024;
   while (ncap < need_rows) ncap = ncap + ncap / 2 + 1024;
   ncap = round_up(ncap, kTileRows);
@@ -116,41 +145,49 @@ int grow_storage(anr_index *h, int64_t need_rows) {
   return ANR_OK;
 }
 
-int ensure_workspace(anr_index *h) {
-  if (h->q32) return ANR_OK;
-  ANR_TRY(dev_alloc(&h->q32, (int64_t)kQB * h->dimp, true));
-  ANR_TRY(dev_alloc(&h->q16, (int64_t)kQB * h->dimp, true));
-  ANR_TRY(dev_alloc(&h->qstat, kQB * 4, true));
-  ANR_TRY(dev_alloc(&h->qstage, (int64_t)kQB * h->dim, true));
-  ANR_TRY(dev_alloc(&h->ladder, kQB * kLadder, true));
-  ANR_TRY(dev_alloc(&h->lcum, (int64_t)kQB * kLadder * kCumStride, true));
-  ANR_TRY(dev_alloc(&h->cntb, (int64_t)kQB * h->n_cu, true));
-  ANR_TRY(dev_alloc(&h->ncand, kQB, true));
-  ANR_TRY(dev_alloc(&h->sel_rank, kQB * kMaxSel, true));
-  ANR_TRY(dev_alloc(&h->sel_row, kQB * kMaxSel, true));
-  ANR_TRY(dev_alloc(&h->sel_m, kQB, true));
-  ANR_TRY(dev_alloc(&h->overflow, kQB, true));
-  ANR_TRY(dev_alloc(&h->exact, kQB * kMaxSel, true));
-  ANR_TRY(dev_alloc(&h->flags, kQB, true));
-  ANR_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->flags_host), kQB * sizeof(int), hipHostMallocDefault));
-  ANR_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->cnt_host), 2 * kQB * sizeof(unsigned), hipHostMallocDefault));
-  for (auto &e : h->ev) ANR_HIP(hipEventCreate(&e));
+int ensure_workspaces(anr_index *h) {
+  if (h->ws_ready) return ANR_OK;
+  for (auto &w : h->ws) {
+    ANR_TRY(dev_alloc(&w.q32, (int64_t)kQB * h->dimp, true));
+    ANR_TRY(dev_alloc(&w.q16, (int64_t)kQB * h->dimp, true));
+    ANR_TRY(dev_alloc(&w.qstat, kQB * 4, true));
+    ANR_TRY(dev_alloc(&w.qstage, (int64_t)kQB * h->dim, true));
+    ANR_TRY(dev_alloc(&w.ladder, kQB * kLadder, true));
+    ANR_TRY(dev_alloc(&w.lcum, (int64_t)kQB * kLadder * kCumStride, true));
+    ANR_TRY(dev_alloc(&w.cntb, (int64_t)kQB * h->n_cu, true));
+    ANR_TRY(dev_alloc(&w.ncand, 3 * kQB, true));
+    ANR_TRY(dev_alloc(&w.sel_rank, kQB * kMaxSel, true));
+    ANR_TRY(dev_alloc(&w.sel_row, kQB * kMaxSel, true));
+    ANR_TRY(dev_alloc(&w.sel_m, kQB, true));
+    ANR_TRY(dev_alloc(&w.exact, kQB * kMaxSel, true));
+    ANR_TRY(dev_alloc(&w.flags, kQB, true));
+    ANR_HIP(hipHostMalloc(reinterpret_cast<void **>(&w.flags_host), kQB * sizeof(int), hipHostMallocDefault));
+    ANR_HIP(hipHostMalloc(reinterpret_cast<void **>(&w.cnt_host), 3 * kQB * sizeof(unsigned), hipHostMallocDefault));
+    ANR_HIP(hipEventCreateWithFlags(&w.ev_in, hipEventDisableTiming));
+    ANR_HIP(hipEventCreateWithFlags(&w.ev_pre, hipEventDisableTiming));
+    ANR_HIP(hipEventCreateWithFlags(&w.ev_scan, hipEventDisableTiming));
+    ANR_HIP(hipEventCreateWithFlags(&w.ev_done, hipEventDisableTiming));
+    ANR_HIP(hipEventCreate(&w.ev_t0));
+    ANR_HIP(hipEventCreate(&w.ev_t1));
+  }
+  for (auto &e : h->ev_call) ANR_HIP(hipEventCreate(&e));
+  h->ws_ready = true;
   return ANR_OK;
 }
 
-int ensure_cand(anr_index *h) {
-  if (h->cand && h->cand_alloc == h->cand_cap) return ANR_OK;
-  dev_free(h->cand);
-  ANR_TRY(dev_alloc(&h->cand, (int64_t)h->n_cu * kQB * h->cand_cap, false));
-  h->cand_alloc = h->cand_cap;
+int ensure_cand(anr_index *h, Workspace &w) {
+  if (w.cand && w.cand_alloc == h->cand_cap) return ANR_OK;
+  dev_free(w.cand);
+  ANR_TRY(dev_alloc(&w.cand, (int64_t)h->n_cu * kQB * h->cand_cap, false));
+  w.cand_alloc = h->cand_cap;
   return ANR_OK;
 }
 
-int ensure_dense(anr_index *h, int64_t ld) {
-  if (h->dense && h->dense_ld >= ld) return ANR_OK;
-  dev_free(h->dense);
-  h->dense_ld = round_up(ld, 32);
-  return dev_alloc(&h->dense, (int64_t)kQB * h->dense_ld, false);
+int ensure_dense(Workspace &w, int64_t ld) {
+  if (w.dense && w.dense_ld >= ld) return ANR_OK;
+  dev_free(w.dense);
+  w.dense_ld = round_up(ld, 32);
+  return dev_alloc(&w.dense, (int64_t)kQB * w.dense_ld, false);
 }
 
 int launch_select(int nblocks, const SelParams &sp, hipStream_t st) {
@@ -166,27 +203,39 @@ int launch_select(int nblocks, const SelParams &sp, hipStream_t st) {
   return ANR_OK;
 }
 
+template <typename K>
+int set_max_lds(K kern) {
+  ANR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024));
+  return ANR_OK;
+}
+
 template <bool DENSE>
-int launch_scan(anr_index *h, const ScanParams &p, hipStream_t st, int *grid_out = nullptr) {
+int launch_scan(anr_index *h, const ScanParams &p, hipStream_t st, int max_grid, int *grid_out = nullptr) {
   if (p.n_tiles <= 0) return ANR_OK;
   const size_t lds = (size_t)2 * p.kb * 64 * 16 + kQB * kLadder * 8 + kQB * 8;
   // 16 waves per block when there is enough work for every CU, else smaller blocks on more CUs
   int nwaves = 16;
-  while (nwaves > 4 && ceil_div(p.n_tiles, nwaves) < h->n_cu) nwaves >>= 1;
+  while (nwaves > 4 && ceil_div(p.n_tiles, nwaves) < max_grid) nwaves >>= 1;
   const int nt = nwaves * 64;
   int64_t grid = ceil_div(p.n_tiles, nwaves);
-  if (grid > h->n_cu) grid = h->n_cu;
+  if (grid > max_grid) grid = max_grid;
   if (grid_out) *grid_out = (int)grid;
-  if (p.kb % 16 == 0) {
-    auto kern = k_scan<DENSE, 8, 1024>;
-    ANR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(nt), lds, st, p);
+  static const bool force_ch4 = getenv("ANORAG_SCAN_CH4") != nullptr;  // developer switch
+  if (p.kb % 16 == 0 && !force_ch4) {
+    static bool done = false;
+    if (!done) {
+      ANR_TRY(set_max_lds(k_scan<DENSE, 8, 1024>));
+      done = true;
+    }
+    hipLaunchKernelGGL((k_scan<DENSE, 8, 1024>), dim3((unsigned)grid), dim3(nt), lds, st, p);
   } else {
-    auto kern = k_scan<DENSE, 4, 1024>;
-    ANR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(nt), lds, st, p);
+    static bool done = false;
+    if (!done) {
+      ANR_TRY(set_max_lds(k_scan<DENSE, 4, 1024>));
+      done = true;
+    }
+    hipLaunchKernelGGL((k_scan<DENSE, 4, 1024>), dim3((unsigned)grid), dim3(nt), lds, st, p);
   }
   ANR_HIP(hipGetLastError());
   return ANR_OK;
@@ -202,20 +251,20 @@ int auto_overfetch(const anr_index *h, int k) {
   return m > kMaxSel ? kMaxSel : m;
 }
 
-// dense exact path for the listed batch-local query slots
-int run_exact(anr_index *h, const std::vector<int> &slots, int64_t out_off, int k, float *D_dev, int64_t *I_dev,
-              hipStream_t st) {
+// dense exact path for the listed batch-local query slots of workspace w (runs on h->stream, synchronous)
+int run_exact(anr_index *h, Workspace &w, const std::vector<int> &slots) {
   const int64_t ld = round_up(h->ntotal, 32);
   if (!h->xdense || h->xdense_ld < ld) {
     dev_free(h->xdense);
     h->xdense_ld = ld;
     ANR_TRY(dev_alloc(&h->xdense, 4 * ld, false));
   }
+  hipStream_t st = h->stream;
   for (size_t b = 0; b < slots.size(); b += 4) {
     const int nf = (int)std::min<size_t>(4, slots.size() - b);
     ExactParams ep{};
     ep.x32 = h->x32;
-    ep.q32 = h->q32;
+    ep.q32 = w.q32;
     ep.dim = h->dim;
     ep.dimp = h->dimp;
     ep.metric = h->metric;
@@ -227,7 +276,6 @@ int run_exact(anr_index *h, const std::vector<int> &slots, int64_t out_off, int 
     int64_t grid = ceil_div(h->ntotal, 4);
     if (grid > (int64_t)h->n_cu * 16) grid = (int64_t)h->n_cu * 16;
     hipLaunchKernelGGL(k_exact_dense, dim3((unsigned)grid), dim3(256), 0, st, ep);
-    // select straight from the exact values; slots f of the select output are reused (0..nf-1)
     SelParams sp{};
     sp.dense = h->xdense;
     sp.dense_ld = h->xdense_ld;
@@ -235,34 +283,98 @@ int run_exact(anr_index *h, const std::vector<int> &slots, int64_t out_off, int 
     sp.row0 = 0;
     sp.row_tile_stride = 1;
     sp.negate = h->metric == ANR_METRIC_L2;
-    sp.M = k;
-    sp.out_rank = h->sel_rank;
-    sp.out_row = h->sel_row;
-    sp.out_m = h->sel_m;
+    sp.M = w.k;
+    sp.out_rank = w.sel_rank;
+    sp.out_row = w.sel_row;
+    sp.out_m = w.sel_m;
     ANR_TRY(launch_select(nf, sp, st));
     EmitParams mp{};
-    mp.rank = h->sel_rank;
-    mp.row = h->sel_row;
-    mp.m = h->sel_m;
+    mp.rank = w.sel_rank;
+    mp.row = w.sel_row;
+    mp.m = w.sel_m;
     mp.nf = nf;
     for (int f = 0; f < nf; ++f) {
       mp.slot[f] = f;
-      mp.outq[f] = out_off + slots[b + f];
+      mp.outq[f] = w.out_off + slots[b + f];
     }
-    mp.k = k;
+    mp.k = w.k;
     mp.metric = h->metric;
-    mp.D = D_dev;
-    mp.I = I_dev;
+    mp.D = w.D;
+    mp.I = w.I;
     mp.id_offset = 0;
     hipLaunchKernelGGL(k_emit, dim3(nf), dim3(256), 0, st, mp);
     ANR_HIP(hipGetLastError());
   }
+  ANR_HIP(hipStreamSynchronize(st));
   return ANR_OK;
 }
 
-// one batch of nq <= 64 queries already on the device
-int search_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_off, float *D_dev, int64_t *I_dev,
-                 hipStream_t st) {
+// wait for a workspace's batch, fold its statistics, run the exact path where the certificate failed
+int retire(anr_index *h, Workspace &w) {
+  if (!w.in_flight) return ANR_OK;
+  w.in_flight = false;
+  ANR_HIP(hipEventSynchronize(w.ev_done));
+  std::vector<int> fallback;
+  if (w.exact_all) {
+    for (int q = 0; q < w.nq; ++q) fallback.push_back(q);
+  } else {
+    if (w.timed) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, w.ev_t0, w.ev_t1) == hipSuccess) h->stats.scan_ms += ms;
+    }
+    h->stats.scan_bytes += w.scan_bytes;
+    h->stats.overfetch = w.M;
+    h->stats.sample_rows = (int)w.sample_rows;
+    for (int q = 0; q < w.nq; ++q) {
+      if (w.sparse) {
+        h->stats.n_candidates += w.cnt_host[q];
+        if (w.cnt_host[kQB + q]) h->stats.n_overflow += 1;
+      }
+      if (w.cnt_host[2 * kQB + q]) fallback.push_back(q);
+    }
+  }
+  if (!fallback.empty()) {
+    h->stats.n_fallback += (int64_t)fallback.size();
+    ANR_TRY(run_exact(h, w, fallback));
+  }
+  return ANR_OK;
+}
+
+int drain(anr_index *h) {
+  if (!h->ws_ready) return ANR_OK;
+  // oldest first
+  for (int i = 0; i < kWorkspaces; ++i) ANR_TRY(retire(h, h->ws[(h->next_ws + i) % kWorkspaces]));
+  return ANR_OK;
+}
+
+// enqueue one batch of nq <= 64 device-resident queries; returns without waiting
+int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_off, float *D_dev, int64_t *I_dev,
+                  hipStream_t user, bool pipelined) {  // NOLINT
+  Workspace &w = h->ws[h->next_ws];
+  h->next_ws = (h->next_ws + 1) % kWorkspaces;
+  ANR_TRY(retire(h, w));  // back-pressure: the workspace's previous batch must be complete
+  w.in_flight = true;
+  w.nq = nq;
+  w.k = k;
+  w.out_off = out_off;
+  w.D = D_dev;
+  w.I = I_dev;
+  w.sparse = false;
+  w.timed = h->timing != 0;
+  w.scan_bytes = 0;
+  w.sample_rows = 0;
+  w.exact_all = h->force_exact != 0 || h->f16_unusable;
+
+  // pipelined: three stages on three streams; otherwise everything on the scan stream
+  static const bool one_stream = getenv("ANORAG_ONE_STREAM") != nullptr;  // developer switch
+  if (one_stream) pipelined = false;
+  hipStream_t s_pre = pipelined ? h->s_pre : h->s_scan;
+  hipStream_t s_scan = h->s_scan;
+  hipStream_t s_post = pipelined ? h->s_post : h->s_scan;
+  // the queries are ready once everything already enqueued on the caller's stream has run
+  ANR_HIP(hipEventRecord(w.ev_in, user));
+  ANR_HIP(hipStreamWaitEvent(s_pre, w.ev_in, 0));
+
   PrepQParams qp{};
   qp.qin = q_dev;
   qp.nq = nq;
@@ -270,133 +382,142 @@ int search_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_of
   qp.dimp = h->dimp;
   qp.kb = h->kb;
   qp.normalize = h->normalize;
-  qp.q32 = h->q32;
-  qp.q16 = h->q16;
-  qp.qstat = h->qstat;
-  hipLaunchKernelGGL(k_prepq, dim3(kQB), dim3(256), 0, st, qp);
+  qp.q32 = w.q32;
+  qp.q16 = w.q16;
+  qp.qstat = w.qstat;
+  hipLaunchKernelGGL(k_prepq, dim3(kQB), dim3(256), 0, s_pre, qp);
 
-  unsigned xstat_host[4] = {0, 0, 0, 0};
-  bool exact_all = h->force_exact != 0;
-  if (!exact_all && h->metric == ANR_METRIC_L2) {
-    // f16 image unusable when a stored value left the f16 range
-    ANR_HIP(hipMemcpyAsync(xstat_host, h->xstat, sizeof xstat_host, hipMemcpyDeviceToHost, st));
-    ANR_HIP(hipStreamSynchronize(st));
-    if (xstat_host[2]) exact_all = true;
-  }
-  std::vector<int> fallback;
-  if (exact_all) {
-    for (int q = 0; q < nq; ++q) fallback.push_back(q);
-    h->stats.n_fallback += nq;
-    return run_exact(h, fallback, out_off, k, D_dev, I_dev, st);
+  if (w.exact_all) {
+    ANR_HIP(hipEventRecord(w.ev_done, s_pre));
+    ANR_HIP(hipStreamWaitEvent(user, w.ev_done, 0));
+    return ANR_OK;
   }
 
   const int M = auto_overfetch(h, k);
+  w.M = M;
   const int64_t n_tiles = ceil_div(h->ntotal, kTileRows);
   const int64_t full_tiles = h->ntotal / kTileRows;
-  // threshold sample: ~1/64 of the rows, between 4K and 32K (more rows -> tighter first threshold)
-  int64_t auto_sample = round_up(std::min<int64_t>(32768, std::max<int64_t>(4096, h->ntotal / 64)), 1024);
+  // threshold sample: ~1/64 of the rows, between 4K and 16K (more rows -> tighter first threshold)
+  const int64_t auto_sample = round_up(std::min<int64_t>(16384, std::max<int64_t>(4096, h->ntotal / 64)), 1024);
   int64_t sample_tiles = (h->sample_rows > 0 ? h->sample_rows : auto_sample) / kTileRows;
   if (sample_tiles * kTileRows < 2 * M) sample_tiles = ceil_div(2 * M, kTileRows);
   const bool sparse = full_tiles >= 8 * sample_tiles;
+  w.sparse = sparse;
+  const int side_grid = h->n_cu;
+  const int scan_grid_max = pipelined ? std::max(h->n_cu / 2, h->n_cu - h->reserve_cus) : h->n_cu;
 
   ScanParams sc{};
   sc.x16 = reinterpret_cast<const uint4 *>(h->x16);
-  sc.q16 = reinterpret_cast<const uint4 *>(h->q16);
+  sc.q16 = reinterpret_cast<const uint4 *>(w.q16);
   sc.kb = h->kb;
   sc.n_rows = h->ntotal;
   sc.rowbias = h->rowbias;
 
   SelParams sp{};
   sp.M = M;
-  sp.out_rank = h->sel_rank;
-  sp.out_row = h->sel_row;
-  sp.out_m = h->sel_m;
+  sp.out_rank = w.sel_rank;
+  sp.out_row = w.sel_row;
+  sp.out_m = w.sel_m;
 
   if (!sparse) {
     // small corpus: dense scores of every row, select the candidates from them
-    ANR_TRY(ensure_dense(h, n_tiles * kTileRows));
+    ANR_TRY(ensure_dense(w, n_tiles * kTileRows));
     sc.tile0 = 0;
     sc.tile_stride = 1;
     sc.n_tiles = n_tiles;
-    sc.dense = h->dense;
-    sc.dense_ld = h->dense_ld;
-    if (h->timing) ANR_HIP(hipEventRecord(h->ev[0], st));
-    ANR_TRY(launch_scan<true>(h, sc, st));
-    if (h->timing) ANR_HIP(hipEventRecord(h->ev[1], st));
-    h->stats.scan_bytes += n_tiles * kTileRows * (int64_t)h->dimp * 2;
-    sp.dense = h->dense;
-    sp.dense_ld = h->dense_ld;
+    sc.dense = w.dense;
+    sc.dense_ld = w.dense_ld;
+    if (pipelined) {
+      ANR_HIP(hipEventRecord(w.ev_pre, s_pre));
+      ANR_HIP(hipStreamWaitEvent(s_scan, w.ev_pre, 0));
+    }
+    if (w.timed) ANR_HIP(hipEventRecord(w.ev_t0, s_scan));
+    ANR_TRY(launch_scan<true>(h, sc, s_scan, scan_grid_max));
+    if (w.timed) ANR_HIP(hipEventRecord(w.ev_t1, s_scan));
+    w.scan_bytes = n_tiles * kTileRows * (int64_t)h->dimp * 2;
+    if (pipelined) {
+      ANR_HIP(hipEventRecord(w.ev_scan, s_scan));
+      ANR_HIP(hipStreamWaitEvent(s_post, w.ev_scan, 0));
+    }
+    sp.dense = w.dense;
+    sp.dense_ld = w.dense_ld;
     sp.n = h->ntotal;
     sp.row0 = 0;
     sp.row_tile_stride = 1;
-    sp.overflow = nullptr;
-    ANR_TRY(launch_select(nq, sp, st));
+    ANR_TRY(launch_select(nq, sp, s_post));
   } else {
-    ANR_TRY(ensure_dense(h, sample_tiles * kTileRows));
-    ANR_TRY(ensure_cand(h));
-    // 1) strided sample -> ladder of valid thresholds
+    ANR_TRY(ensure_dense(w, sample_tiles * kTileRows));
+    ANR_TRY(ensure_cand(h, w));
+    w.sample_rows = sample_tiles * kTileRows;
+    // pre: strided sample -> ladder of valid thresholds (also clears the level counters)
     sc.tile0 = 0;
     sc.tile_stride = full_tiles / sample_tiles;
     sc.n_tiles = sample_tiles;
-    sc.dense = h->dense;
-    sc.dense_ld = h->dense_ld;
-    ANR_TRY(launch_scan<true>(h, sc, st));
+    sc.dense = w.dense;
+    sc.dense_ld = w.dense_ld;
+    ANR_TRY(launch_scan<true>(h, sc, s_pre, side_grid));
     SelParams ss = sp;
-    ss.dense = h->dense;
-    ss.dense_ld = h->dense_ld;
+    ss.dense = w.dense;
+    ss.dense_ld = w.dense_ld;
     ss.n = sample_tiles * kTileRows;
     ss.row0 = 0;
     ss.row_tile_stride = sc.tile_stride;
-    ss.ladder = h->ladder;
-    ss.lcum_zero = h->lcum;
-    ANR_TRY(launch_select(kQB, ss, st));
-    // 2) the full scan
+    ss.ladder = w.ladder;
+    ss.lcum_zero = w.lcum;
+    ANR_TRY(launch_select(kQB, ss, s_pre));
+    // scan
+    if (pipelined) {
+      ANR_HIP(hipEventRecord(w.ev_pre, s_pre));
+      ANR_HIP(hipStreamWaitEvent(s_scan, w.ev_pre, 0));
+    }
     sc.tile0 = 0;
     sc.tile_stride = 1;
     sc.n_tiles = n_tiles;
     sc.dense = nullptr;
-    sc.ladder = h->ladder;
-    sc.lcum = h->lcum;
-    sc.cntb = h->cntb;
-    sc.cand = h->cand;
+    sc.ladder = w.ladder;
+    sc.lcum = w.lcum;
+    sc.cntb = w.cntb;
+    sc.cand = w.cand;
     sc.capb = (unsigned)h->cand_cap;
     sc.kprime = (unsigned)M;
-    if (h->timing) ANR_HIP(hipEventRecord(h->ev[0], st));
     int scan_grid = 0;
-    ANR_TRY(launch_scan<false>(h, sc, st, &scan_grid));
-    if (h->timing) ANR_HIP(hipEventRecord(h->ev[1], st));
-    h->stats.scan_bytes += n_tiles * kTileRows * (int64_t)h->dimp * 2;
-    // 3) top-M of the candidates
-    sp.cand = h->cand;
-    sp.cntb = h->cntb;
+    if (w.timed) ANR_HIP(hipEventRecord(w.ev_t0, s_scan));
+    ANR_TRY(launch_scan<false>(h, sc, s_scan, scan_grid_max, &scan_grid));
+    if (w.timed) ANR_HIP(hipEventRecord(w.ev_t1, s_scan));
+    w.scan_bytes = n_tiles * kTileRows * (int64_t)h->dimp * 2;
+    // post
+    if (pipelined) {
+      ANR_HIP(hipEventRecord(w.ev_scan, s_scan));
+      ANR_HIP(hipStreamWaitEvent(s_post, w.ev_scan, 0));
+    }
+    sp.cand = w.cand;
+    sp.cntb = w.cntb;
     sp.G = scan_grid;
     sp.capb = (unsigned)h->cand_cap;
-    sp.overflow = h->overflow;
-    sp.ncand = h->ncand;
-    ANR_TRY(launch_select(nq, sp, st));
-    ANR_HIP(hipMemcpyAsync(h->cnt_host, h->ncand, kQB * sizeof(unsigned), hipMemcpyDeviceToHost, st));
-    ANR_HIP(hipMemcpyAsync(h->cnt_host + kQB, h->overflow, kQB * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    sp.overflow = w.ncand + kQB;
+    sp.ncand = w.ncand;
+    ANR_TRY(launch_select(nq, sp, s_post));
   }
 
   RescoreParams rp{};
   rp.x32 = h->x32;
-  rp.q32 = h->q32;
+  rp.q32 = w.q32;
   rp.dim = h->dim;
   rp.dimp = h->dimp;
   rp.metric = h->metric;
-  rp.sel_row = h->sel_row;
-  rp.sel_m = h->sel_m;
-  rp.exact = h->exact;
+  rp.sel_row = w.sel_row;
+  rp.sel_m = w.sel_m;
+  rp.exact = w.exact;
   rp.M = M;
-  hipLaunchKernelGGL(k_rescore, dim3((unsigned)ceil_div((int64_t)nq * M, 4)), dim3(256), 0, st, rp);
+  hipLaunchKernelGGL(k_rescore, dim3((unsigned)ceil_div((int64_t)nq * M, 4)), dim3(256), 0, s_post, rp);
 
   FinalParams fp{};
-  fp.exact = h->exact;
-  fp.approx = h->sel_rank;
-  fp.sel_row = h->sel_row;
-  fp.sel_m = h->sel_m;
-  fp.overflow = sparse ? h->overflow : nullptr;
-  fp.qstat = h->qstat;
+  fp.exact = w.exact;
+  fp.approx = w.sel_rank;
+  fp.sel_row = w.sel_row;
+  fp.sel_m = w.sel_m;
+  fp.overflow = sparse ? w.ncand + kQB : nullptr;
+  fp.qstat = w.qstat;
   fp.xstat = h->xstat;
   fp.metric = h->metric;
   fp.dimp = h->dimp;
@@ -407,60 +528,62 @@ int search_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_of
   fp.out_off = out_off;
   fp.D = D_dev;
   fp.I = I_dev;
-  fp.flags = h->flags;
+  fp.flags = reinterpret_cast<int *>(w.ncand + 2 * kQB);
   fp.id_offset = 0;
-  hipLaunchKernelGGL(k_finalize, dim3(nq), dim3(256), 0, st, fp);
+  hipLaunchKernelGGL(k_finalize, dim3(nq), dim3(256), 0, s_post, fp);
   ANR_HIP(hipGetLastError());
+  ANR_HIP(hipMemcpyAsync(w.cnt_host, w.ncand, 3 * kQB * sizeof(unsigned), hipMemcpyDeviceToHost, s_post));
+  ANR_HIP(hipEventRecord(w.ev_done, s_post));
+  ANR_HIP(hipStreamWaitEvent(user, w.ev_done, 0));
+  return ANR_OK;
+}
 
-  ANR_HIP(hipMemcpyAsync(h->flags_host, h->flags, kQB * sizeof(int), hipMemcpyDeviceToHost, st));
-  ANR_HIP(hipStreamSynchronize(st));
-  if (h->timing) {
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, h->ev[0], h->ev[1]) == hipSuccess) h->stats.scan_ms += ms;
-  }
-  h->stats.overfetch = M;
-  h->stats.sample_rows = sparse ? (int)(sample_tiles * kTileRows) : 0;
-  if (sparse)
-    for (int q = 0; q < nq; ++q) {
-      h->stats.n_candidates += h->cnt_host[q];
-      if (h->cnt_host[kQB + q]) h->stats.n_overflow += 1;
-    }
-  for (int q = 0; q < nq; ++q)
-    if (h->flags_host[q]) fallback.push_back(q);
-  if (!fallback.empty()) {
-    h->stats.n_fallback += (int64_t)fallback.size();
-    ANR_TRY(run_exact(h, fallback, out_off, k, D_dev, I_dev, st));
-    ANR_HIP(hipStreamSynchronize(st));
+int refresh_xstat(anr_index *h) {
+  if (!h->xstat_dirty) return ANR_OK;
+  unsigned host[4] = {0, 0, 0, 0};
+  ANR_HIP(hipStreamSynchronize(h->stream));
+  ANR_HIP(hipMemcpy(host, h->xstat, sizeof host, hipMemcpyDeviceToHost));
+  h->f16_unusable = host[2] != 0;
+  h->xstat_dirty = false;
+  return ANR_OK;
+}
+
+int write_empty(const anr_index *h, int64_t nq, int32_t k, float *D, int64_t *I, bool on_host) {
+  // faiss returns -1 ids and the neutral score for an empty index
+  std::vector<float> dd((size_t)nq * k, h->metric == 0 ? -3.402823466e+38f : 3.402823466e+38f);
+  std::vector<int64_t> ii((size_t)nq * k, -1);
+  if (on_host) {
+    memcpy(D, dd.data(), dd.size() * sizeof(float));
+    memcpy(I, ii.data(), ii.size() * sizeof(int64_t));
+  } else {
+    ANR_HIP(hipMemcpy(D, dd.data(), dd.size() * sizeof(float), hipMemcpyHostToDevice));
+    ANR_HIP(hipMemcpy(I, ii.data(), ii.size() * sizeof(int64_t), hipMemcpyHostToDevice));
   }
   return ANR_OK;
 }
 
-int search_impl(anr_index *h, const float *q, bool q_on_host, int64_t nq, int32_t k, float *D, int64_t *I,
-                bool out_on_host, hipStream_t st) {
+int check_search_args(const anr_index *h, const void *q, int64_t nq, int32_t k, const void *D, const void *I) {
   if (!h || !q || !D || !I) return fail(ANR_EINVAL, "null argument");
   if (nq < 0 || k <= 0) return fail(ANR_EINVAL, "nq must be >= 0 and k > 0");
   if (k > kMaxSel) return fail(ANR_EINVAL, "k = %d exceeds the supported maximum %d", k, kMaxSel);
+  return ANR_OK;
+}
+
+// synchronous search (host or device buffers): enqueue every batch, then retire them all
+int search_impl(anr_index *h, const float *q, bool q_on_host, int64_t nq, int32_t k, float *D, int64_t *I,
+                bool out_on_host, hipStream_t st) {
+  ANR_TRY(check_search_args(h, q, nq, k, D, I));
   DeviceGuard g(h->device);
   if (!g.ok) return fail(ANR_EHIP, "hipSetDevice(%d) failed", h->device);
   std::lock_guard<std::mutex> lk(h->mu);
   if (!st) st = h->stream;
+  ANR_TRY(drain(h));
   h->stats = anr_search_stats{};
   h->stats.n_queries = nq;
   if (nq == 0) return ANR_OK;
-  if (h->ntotal == 0) {
-    // faiss returns -1 ids and the neutral score for an empty index
-    std::vector<float> dd((size_t)nq * k, h->metric == 0 ? -3.402823466e+38f : 3.402823466e+38f);
-    std::vector<int64_t> ii((size_t)nq * k, -1);
-    if (out_on_host) {
-      memcpy(D, dd.data(), dd.size() * sizeof(float));
-      memcpy(I, ii.data(), ii.size() * sizeof(int64_t));
-    } else {
-      ANR_HIP(hipMemcpy(D, dd.data(), dd.size() * sizeof(float), hipMemcpyHostToDevice));
-      ANR_HIP(hipMemcpy(I, ii.data(), ii.size() * sizeof(int64_t), hipMemcpyHostToDevice));
-    }
-    return ANR_OK;
-  }
-  ANR_TRY(ensure_workspace(h));
+  if (h->ntotal == 0) return write_empty(h, nq, k, D, I, out_on_host);
+  ANR_TRY(ensure_workspaces(h));
+  ANR_TRY(refresh_xstat(h));
   float *Dd = D;
   int64_t *Id = I;
   if (out_on_host) {
@@ -474,21 +597,25 @@ int search_impl(anr_index *h, const float *q, bool q_on_host, int64_t nq, int32_
     Dd = h->d_out;
     Id = h->i_out;
   }
-  if (h->timing) ANR_HIP(hipEventRecord(h->ev[2], st));
+  if (h->timing) ANR_HIP(hipEventRecord(h->ev_call[0], st));
+  const bool pipelined = nq > kQB;  // several batches in one call overlap their pre/post stages
   for (int64_t q0 = 0; q0 < nq; q0 += kQB) {
     const int nb = (int)std::min<int64_t>(kQB, nq - q0);
     const float *qd = q + q0 * h->dim;
     if (q_on_host) {
-      ANR_HIP(hipMemcpyAsync(h->qstage, qd, (size_t)nb * h->dim * sizeof(float), hipMemcpyHostToDevice, st));
-      qd = h->qstage;
+      Workspace &w = h->ws[h->next_ws];
+      ANR_TRY(retire(h, w));  // its staging buffer is about to be overwritten
+      ANR_HIP(hipMemcpyAsync(w.qstage, qd, (size_t)nb * h->dim * sizeof(float), hipMemcpyHostToDevice, st));
+      qd = w.qstage;
     }
-    ANR_TRY(search_batch(h, qd, nb, k, q0, Dd, Id, st));
+    ANR_TRY(enqueue_batch(h, qd, nb, k, q0, Dd, Id, st, pipelined));
   }
+  ANR_TRY(drain(h));
   if (h->timing) {
-    ANR_HIP(hipEventRecord(h->ev[3], st));
-    ANR_HIP(hipEventSynchronize(h->ev[3]));
+    ANR_HIP(hipEventRecord(h->ev_call[1], st));
+    ANR_HIP(hipEventSynchronize(h->ev_call[1]));
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, h->ev[2], h->ev[3]) == hipSuccess) h->stats.total_ms = ms;
+    if (hipEventElapsedTime(&ms, h->ev_call[0], h->ev_call[1]) == hipSuccess) h->stats.total_ms = ms;
   }
   if (out_on_host) {
     ANR_HIP(hipMemcpyAsync(D, Dd, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, st));
@@ -500,6 +627,7 @@ int search_impl(anr_index *h, const float *q, bool q_on_host, int64_t nq, int32_
 
 int add_impl(anr_index *h, const float *x_dev, int64_t n, hipStream_t st) {
   ANR_TRY(grow_storage(h, h->ntotal + n));
+  ANR_TRY(drain(h));
   AddParams ap{};
   ap.xin = x_dev;
   ap.n = n;
@@ -516,7 +644,20 @@ int add_impl(anr_index *h, const float *x_dev, int64_t n, hipStream_t st) {
   hipLaunchKernelGGL(k_add, dim3((unsigned)(t1 - t0)), dim3(256), 0, st, ap);
   ANR_HIP(hipGetLastError());
   h->ntotal += n;
+  h->xstat_dirty = true;
   return ANR_OK;
+}
+
+void free_workspaces(anr_index *h) {
+  for (auto &w : h->ws) {
+    dev_free(w.q32); dev_free(w.q16); dev_free(w.qstat); dev_free(w.qstage); dev_free(w.dense);
+    dev_free(w.ladder); dev_free(w.lcum); dev_free(w.cntb); dev_free(w.ncand); dev_free(w.cand);
+    dev_free(w.sel_rank); dev_free(w.sel_row); dev_free(w.sel_m); dev_free(w.exact); dev_free(w.flags);
+    if (w.flags_host) (void)hipHostFree(w.flags_host);
+    if (w.cnt_host) (void)hipHostFree(w.cnt_host);
+    for (hipEvent_t *e : {&w.ev_in, &w.ev_pre, &w.ev_scan, &w.ev_done, &w.ev_t0, &w.ev_t1})
+      if (*e) (void)hipEventDestroy(*e);
+  }
 }
 
 }  // namespace
@@ -545,15 +686,17 @@ int anr_index_create(int32_t dim, int32_t metric, int32_t normalize, int32_t dev
   h->normalize = normalize ? 1 : 0;
   h->device = device;
   h->n_cu = device_cu_count(device);
-  hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
-  if (e != hipSuccess) {
-    delete h;
-    return fail(ANR_EHIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+  hipStream_t *streams[4] = {&h->stream, &h->s_pre, &h->s_scan, &h->s_post};
+  for (auto s : streams) {
+    hipError_t e = hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      anr_index_destroy(h);
+      return fail(ANR_EHIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+    }
   }
   int r = dev_alloc(&h->xstat, 4, true);
   if (r != ANR_OK) {
-    (void)hipStreamDestroy(h->stream);
-    delete h;
+    anr_index_destroy(h);
     return r;
   }
   *out = h;
@@ -563,35 +706,20 @@ int anr_index_create(int32_t dim, int32_t metric, int32_t normalize, int32_t dev
 int anr_index_destroy(anr_index *h) {
   if (!h) return ANR_OK;
   DeviceGuard g(h->device);
-  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (hipStream_t s : {h->s_pre, h->s_scan, h->s_post, h->stream})
+    if (s) (void)hipStreamSynchronize(s);
   dev_free(h->x32);
   dev_free(h->x16);
   dev_free(h->rowbias);
   dev_free(h->xstat);
-  dev_free(h->q32);
-  dev_free(h->q16);
-  dev_free(h->qstat);
-  dev_free(h->qstage);
-  dev_free(h->dense);
-  dev_free(h->ladder);
-  dev_free(h->lcum);
-  dev_free(h->cntb);
-  dev_free(h->ncand);
-  dev_free(h->cand);
-  dev_free(h->sel_rank);
-  dev_free(h->sel_row);
-  dev_free(h->sel_m);
-  dev_free(h->overflow);
-  dev_free(h->exact);
-  dev_free(h->flags);
+  free_workspaces(h);
   dev_free(h->xdense);
   dev_free(h->d_out);
   dev_free(h->i_out);
-  if (h->flags_host) (void)hipHostFree(h->flags_host);
-  if (h->cnt_host) (void)hipHostFree(h->cnt_host);
-  for (auto &e : h->ev)
+  for (auto &e : h->ev_call)
     if (e) (void)hipEventDestroy(e);
-  if (h->stream) (void)hipStreamDestroy(h->stream);
+  for (hipStream_t s : {h->s_pre, h->s_scan, h->s_post, h->stream})
+    if (s) (void)hipStreamDestroy(s);
   delete h;
   return ANR_OK;
 }
@@ -647,11 +775,13 @@ int anr_index_reset(anr_index *h) {
   if (!h) return fail(ANR_EINVAL, "null handle");
   DeviceGuard g(h->device);
   std::lock_guard<std::mutex> lk(h->mu);
+  ANR_TRY(drain(h));
   ANR_HIP(hipStreamSynchronize(h->stream));
   if (h->x16) ANR_HIP(hipMemset(h->x16, 0, (size_t)h->cap * h->dimp * sizeof(_Float16)));
   if (h->rowbias) ANR_HIP(hipMemset(h->rowbias, 0, (size_t)h->cap * sizeof(float)));
   ANR_HIP(hipMemset(h->xstat, 0, 4 * sizeof(unsigned)));
   h->ntotal = 0;
+  h->xstat_dirty = true;
   return ANR_OK;
 }
 
@@ -674,9 +804,37 @@ int anr_index_search_dev(anr_index *h, const float *q_dev, int64_t nq, int32_t k
   return search_impl(h, q_dev, false, nq, k, D_dev, I_dev, false, reinterpret_cast<hipStream_t>(stream));
 }
 
+int anr_index_search_dev_async(anr_index *h, const float *q_dev, int64_t nq, int32_t k, float *D_dev,
+                               int64_t *I_dev, void *stream) {
+  ANR_TRY(check_search_args(h, q_dev, nq, k, D_dev, I_dev));
+  DeviceGuard g(h->device);
+  if (!g.ok) return fail(ANR_EHIP, "hipSetDevice(%d) failed", h->device);
+  std::lock_guard<std::mutex> lk(h->mu);
+  hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : h->stream;
+  h->stats.n_queries += nq;
+  if (nq == 0) return ANR_OK;
+  if (h->ntotal == 0) return write_empty(h, nq, k, D_dev, I_dev, false);
+  ANR_TRY(ensure_workspaces(h));
+  ANR_TRY(refresh_xstat(h));
+  for (int64_t q0 = 0; q0 < nq; q0 += kQB) {
+    const int nb = (int)std::min<int64_t>(kQB, nq - q0);
+    ANR_TRY(enqueue_batch(h, q_dev + q0 * h->dim, nb, k, q0, D_dev, I_dev, st, true));
+  }
+  return ANR_OK;
+}
+
+int anr_index_sync(anr_index *h) {
+  if (!h) return fail(ANR_EINVAL, "null handle");
+  DeviceGuard g(h->device);
+  std::lock_guard<std::mutex> lk(h->mu);
+  return drain(h);
+}
+
 int anr_index_set_option(anr_index *h, int32_t opt, int64_t value) {
   if (!h) return fail(ANR_EINVAL, "null handle");
+  DeviceGuard g(h->device);
   std::lock_guard<std::mutex> lk(h->mu);
+  ANR_TRY(drain(h));
   switch (opt) {
     case ANR_OPT_FORCE_EXACT: h->force_exact = value != 0; break;
     case ANR_OPT_OVERFETCH:
@@ -693,6 +851,10 @@ int anr_index_set_option(anr_index *h, int32_t opt, int64_t value) {
       break;
     case ANR_OPT_TIMING: h->timing = value != 0; break;
     case ANR_OPT_ADD_RAW: h->add_raw = value != 0; break;
+    case ANR_OPT_RESERVE_CUS:
+      if (value < 0 || value > h->n_cu / 2) return fail(ANR_EINVAL, "reserved CUs must be in 0..%d", h->n_cu / 2);
+      h->reserve_cus = (int)value;
+      break;
     default: return fail(ANR_EINVAL, "unknown option %d", opt);
   }
   return ANR_OK;
@@ -702,6 +864,13 @@ int anr_index_last_stats(anr_index *h, anr_search_stats *out) {
   if (!h || !out) return fail(ANR_EINVAL, "null argument");
   std::lock_guard<std::mutex> lk(h->mu);
   *out = h->stats;
+  return ANR_OK;
+}
+
+int anr_index_reset_stats(anr_index *h) {
+  if (!h) return fail(ANR_EINVAL, "null handle");
+  std::lock_guard<std::mutex> lk(h->mu);
+  h->stats = anr_search_stats{};
   return ANR_OK;
 }
 

@@ -453,6 +453,7 @@ struct SelParams {
 struct SelShared {
   unsigned long long keys[kSelLds];
   unsigned long long sel[kMaxSel];
+  unsigned long long srt[kMaxSel];
   unsigned long long red[16][2];
   unsigned offs[kSelMaxLists + 1];
   unsigned hist[256];
@@ -530,28 +531,36 @@ __global__ __launch_bounds__(1024) void k_select(SelParams p) {
     return;
   }
   const bool staged = n <= kSelLds;
+  // stage the keys in LDS (when they fit) and find the common leading bytes of all keys on the way -> those
+  // radix passes are skipped (this also avoids one-bin LDS atomic storms)
+  unsigned long long kmin = ~0ull, kmax = 0ull;
   if (staged) {
     if (p.dense) {
-      for (int64_t i = tid; i < n; i += 1024) sh.keys[i] = sel_key(p, sh, q, i, false);
+      for (int64_t i = tid; i < n; i += 1024) {
+        const unsigned long long k = sel_key(p, sh, q, i, false);
+        sh.keys[i] = k;
+        kmin = k < kmin ? k : kmin;
+        kmax = k > kmax ? k : kmax;
+      }
     } else {
       for (int b = wave; b < p.G; b += 16) {
         const unsigned o = sh.offs[b], c = sh.offs[b + 1] - o;
         const uint2 *list = p.cand + ((int64_t)b * kQB + q) * p.capb;
         for (unsigned j = lane; j < c; j += 64) {
           const uint2 e = list[j];
-          sh.keys[o + j] = make_key(__uint_as_float(e.x), e.y);
+          const unsigned long long k = make_key(__uint_as_float(e.x), e.y);
+          sh.keys[o + j] = k;
+          kmin = k < kmin ? k : kmin;
+          kmax = k > kmax ? k : kmax;
         }
       }
     }
-    __syncthreads();
-  }
-
-  // common leading bytes of all keys -> skip those passes (also avoids one-bin LDS atomic storms)
-  unsigned long long kmin = ~0ull, kmax = 0ull;
-  for (int64_t i = tid; i < n; i += 1024) {
-    const unsigned long long k = sel_key(p, sh, q, i, staged);
-    kmin = k < kmin ? k : kmin;
-    kmax = k > kmax ? k : kmax;
+  } else {
+    for (int64_t i = tid; i < n; i += 1024) {
+      const unsigned long long k = sel_key(p, sh, q, i, false);
+      kmin = k < kmin ? k : kmin;
+      kmax = k > kmax ? k : kmax;
+    }
   }
   for (int off = 32; off > 0; off >>= 1) {
     const unsigned long long a = __shfl_xor(kmin, off), b = __shfl_xor(kmax, off);
@@ -623,29 +632,16 @@ __global__ __launch_bounds__(1024) void k_select(SelParams p) {
     }
   }
   __syncthreads();
-  int Mp = 1;
-  while (Mp < M) Mp <<= 1;
-  for (int i = M + tid; i < Mp; i += 1024) sh.sel[i] = 0ull;
-  __syncthreads();
-  // bitonic sort, descending
-  for (int k2 = 2; k2 <= Mp; k2 <<= 1) {
-    for (int j = k2 >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < Mp; i += 1024) {
-        const int ixj = i ^ j;
-        if (ixj > i) {
-          const unsigned long long a = sh.sel[i], b = sh.sel[ixj];
-          const bool desc = ((i & k2) == 0);
-          if (desc ? (a < b) : (a > b)) {
-            sh.sel[i] = b;
-            sh.sel[ixj] = a;
-          }
-        }
-      }
-      __syncthreads();
-    }
-  }
+  // order the M gathered keys by rank counting (keys are distinct): M*M/1024 compares per thread, one barrier
   for (int i = tid; i < M; i += 1024) {
     const unsigned long long k = sh.sel[i];
+    int rank = 0;
+    for (int j = 0; j < M; ++j) rank += (sh.sel[j] > k) ? 1 : 0;
+    sh.srt[rank] = k;
+  }
+  __syncthreads();
+  for (int i = tid; i < M; i += 1024) {
+    const unsigned long long k = sh.srt[i];
     float v = ord2f((unsigned)(k >> 32));
     p.out_rank[q * kMaxSel + i] = p.negate ? -v : v;
     p.out_row[q * kMaxSel + i] = 0xffffffffu - (unsigned)(k & 0xffffffffu);
@@ -655,7 +651,7 @@ __global__ __launch_bounds__(1024) void k_select(SelParams p) {
     // level j = value of rank max(1, M >> j) (1-based) of the sample: ascending in j
     int rk = M >> tid;
     if (rk < 1 || tid == kLadder - 1) rk = 1;
-    p.ladder[q * kLadder + tid] = ord2f((unsigned)(sh.sel[rk - 1] >> 32));
+    p.ladder[q * kLadder + tid] = ord2f((unsigned)(sh.srt[rk - 1] >> 32));
   }
 }
 
@@ -719,36 +715,22 @@ struct FinalParams {
 
 __global__ __launch_bounds__(256) void k_finalize(FinalParams p) {
   __shared__ unsigned long long sel[kMaxSel];
+  __shared__ unsigned long long srt[kMaxSel];
   const int q = blockIdx.x, tid = threadIdx.x;
   if (q >= p.nq) return;
   const int m = p.sel_m[q];
-  int Mp = 1;
-  while (Mp < m) Mp <<= 1;
-  for (int i = tid; i < Mp; i += 256) {
-    unsigned long long k = 0ull;
-    if (i < m) {
-      const float e = p.exact[q * kMaxSel + i];
-      k = make_key(p.metric == 0 ? e : -e, p.sel_row[q * kMaxSel + i]);
-    }
-    sel[i] = k;
+  for (int i = tid; i < m; i += 256) {
+    const float e = p.exact[q * kMaxSel + i];
+    srt[i] = make_key(p.metric == 0 ? e : -e, p.sel_row[q * kMaxSel + i]);
   }
   __syncthreads();
-  for (int k2 = 2; k2 <= Mp; k2 <<= 1) {
-    for (int j = k2 >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < Mp; i += 256) {
-        const int ixj = i ^ j;
-        if (ixj > i) {
-          const unsigned long long a = sel[i], b = sel[ixj];
-          const bool desc = ((i & k2) == 0);
-          if (desc ? (a < b) : (a > b)) {
-            sel[i] = b;
-            sel[ixj] = a;
-          }
-        }
-      }
-      __syncthreads();
-    }
+  for (int i = tid; i < m; i += 256) {
+    const unsigned long long k = srt[i];
+    int rank = 0;
+    for (int j = 0; j < m; ++j) rank += (srt[j] > k) ? 1 : 0;
+    sel[rank] = k;
   }
+  __syncthreads();
   const int kk = p.k < m ? p.k : m;
   float *D = p.D + (p.out_off + q) * (int64_t)p.k;
   int64_t *I = p.I + (p.out_off + q) * (int64_t)p.k;

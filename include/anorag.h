@@ -68,6 +68,17 @@ int anr_index_search(anr_index *h, const float *q_host, int64_t nq, int32_t k, f
 int anr_index_search_dev(anr_index *h, const float *q_dev, int64_t nq, int32_t k, float *D_dev,
                          int64_t *I_dev, void *stream);
 
+/* Asynchronous form: enqueues the search and returns; results are complete for work enqueued on `stream`
+ * after the call (the stream is made to wait on them).  Successive calls overlap: the query preparation /
+ * threshold sample of one batch and the candidate selection / exact re-score of another run beside the
+ * corpus scan of a third (three rotating workspaces; the scan leaves ANR_OPT_RESERVE_CUS compute units
+ * free for them).  D_dev / I_dev of calls still in flight must be distinct buffers.  anr_index_sync()
+ * waits for everything enqueued, runs the exact path for the queries whose certificate failed (patching
+ * D_dev / I_dev) and folds the statistics: results are FINAL only after it returns. */
+int anr_index_search_dev_async(anr_index *h, const float *q_dev, int64_t nq, int32_t k, float *D_dev,
+                               int64_t *I_dev, void *stream);
+int anr_index_sync(anr_index *h);
+
 /* tuning / introspection */
 #define ANR_OPT_FORCE_EXACT 1     /* 1: skip the f16 scan, run the dense exact path for every query  */
 #define ANR_OPT_OVERFETCH 2       /* candidates kept per query before the exact re-score (0 = auto)  */
@@ -75,6 +86,7 @@ int anr_index_search_dev(anr_index *h, const float *q_dev, int64_t nq, int32_t k
 #define ANR_OPT_CAND_CAP 4        /* per-query candidate buffer entries                               */
 #define ANR_OPT_TIMING 5          /* 1: record HIP-event time of the scan kernel in stats             */
 #define ANR_OPT_ADD_RAW 6         /* 1: adds store rows as given (already normalised: reloading a saved index) */
+#define ANR_OPT_RESERVE_CUS 7     /* compute units the scan leaves free during asynchronous searches (default 16) */
 int anr_index_set_option(anr_index *h, int32_t opt, int64_t value);
 
 typedef struct anr_search_stats {
@@ -88,7 +100,10 @@ typedef struct anr_search_stats {
   float scan_ms;            /* HIP-event time of the main scan launches (ANR_OPT_TIMING)              */
   float total_ms;           /* HIP-event time of the whole call on the stream (ANR_OPT_TIMING)        */
 } anr_search_stats;
+/* statistics of the last synchronous search, or accumulated over the asynchronous searches retired since
+ * anr_index_reset_stats() */
 int anr_index_last_stats(anr_index *h, anr_search_stats *out);
+int anr_index_reset_stats(anr_index *h);
 
 /* In-place row normalisation on host memory through the device (vector_index.py:276-280): rows with
  * zero norm are left unchanged. */

@@ -136,3 +136,36 @@ def test_duplicates_and_zero_rows_tie_order():
     assert I[0][0] == 17 and list(I[0][1:10]) == list(range(5000, 5009))
     assert np.all(idx.reconstruct_n(42, 1) == 0.0)
     idx.close()
+
+
+def test_async_pipelined_search_equals_sync():
+    """anr_index_search_dev_async + anr_index_sync: overlapping batches on rotating streams give the same
+    answers as the synchronous call; a multi-batch synchronous call (nq > 64) uses the same pipeline."""
+    import torch
+    from anorag_hip import FlatIndex, METRIC_IP
+    x, q = _data(150_000, 256, 64 * 5 + 7)
+    idx = FlatIndex(256, METRIC_IP, normalize=True)
+    idx.add(x)
+    D_all, I_all = idx.search(q, 30)                      # 6 batches through the pipelined path
+    xm, qm = orc.preprocess_vectors(x), orc.preprocess_vectors(q)
+    Dr, Ir = orc.flat_search(qm, xm, 30, "ip")
+    assert orc.near_tie_equal(I_all, Ir, orc.exact_scores(qm, xm, "ip"), 30, 1e-6)
+    assert np.max(np.abs(D_all - Dr)) <= SCORE_TOL
+    dev = torch.device("cuda", 0)
+    qt = torch.from_numpy(q).to(dev)
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    outs = []
+    idx.reset_stats()
+    for b in range(5):
+        D = torch.empty((64, 30), device=dev)
+        I = torch.empty((64, 30), device=dev, dtype=torch.int64)
+        idx.search_device_async(qt[b * 64:(b + 1) * 64].data_ptr(), 64, 30, D.data_ptr(), I.data_ptr(),
+                                streams[b % 3].cuda_stream)
+        outs.append((D, I))
+    idx.sync()
+    torch.cuda.synchronize()
+    for b, (D, I) in enumerate(outs):
+        assert np.array_equal(I.cpu().numpy(), I_all[b * 64:(b + 1) * 64])
+        assert np.array_equal(D.cpu().numpy(), D_all[b * 64:(b + 1) * 64])
+    assert idx.last_stats()["n_queries"] == 320
+    idx.close()

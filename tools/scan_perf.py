@@ -15,6 +15,8 @@ ap.add_argument("--k", type=int, default=100)
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--sample", type=int, default=0)
 ap.add_argument("--overfetch", type=int, default=0)
+ap.add_argument("--reserve", type=int, default=-1)
+ap.add_argument("--mode", default="both")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 idx = FlatIndex(a.dim, METRIC_IP, normalize=True)
@@ -44,6 +46,30 @@ for i in range(2, a.steps + 2):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.steps
 byt = st["scan_bytes"]
-print(f"rows={a.rows} wall/step={dt*1e3:.3f} ms  scan={tot_scan/a.steps:.3f} ms  gpu-total={tot_all/a.steps:.3f} ms  "
+if a.mode in ("both", "sync"):
+  print(f"[sync ] rows={a.rows} wall/step={dt*1e3:.3f} ms  scan={tot_scan/a.steps:.3f} ms  gpu-total={tot_all/a.steps:.3f} ms  "
       f"scan GB/s={byt/1e9/(tot_scan/a.steps/1e3):.0f}  qps={a.batch/dt:.0f}  cand/q={cand/a.steps/a.batch:.0f} fallback={fb} "
       f"sample={st['sample_rows']} overfetch={st['overfetch']}")
+if a.mode in ("both", "async"):
+    from anorag_hip._lib import OPT_RESERVE_CUS
+    if a.reserve >= 0: idx.set_option(OPT_RESERVE_CUS, a.reserve)
+    NS = 3
+    strs = [torch.cuda.Stream() for _ in range(NS)]
+    Ds = [torch.empty_like(D) for _ in range(NS)]; Is = [torch.empty_like(I) for _ in range(NS)]
+    for rep in range(2):
+        idx.sync(); idx.reset_stats(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(2, a.steps + 2):
+            s = i % NS
+            idx.search_device_async(Q[i].data_ptr(), a.batch, a.k, Ds[s].data_ptr(), Is[s].data_ptr(), strs[s].cuda_stream)
+        idx.sync(); torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / a.steps
+    st = idx.last_stats()
+    print(f"[async] rows={a.rows} wall/step={dt*1e3:.3f} ms  scan={st['scan_ms']/a.steps:.3f} ms  "
+          f"scan GB/s={st['scan_bytes']/1e9/(st['scan_ms']/1e3):.0f}  qps={a.batch/dt:.0f}  cand/q={st['n_candidates']/a.steps/a.batch:.0f} "
+          f"fallback={st['n_fallback']}")
+    # same answers as the synchronous path
+    idx.search_device(Q[a.steps + 1].data_ptr(), a.batch, a.k, D.data_ptr(), I.data_ptr())
+    torch.cuda.synchronize()
+    s = (a.steps + 1) % NS
+    assert torch.equal(I, Is[s]) and torch.equal(D, Ds[s]), "async result differs from sync"
