@@ -74,7 +74,9 @@ struct anr_index {
   int64_t cand_cap = 512;   // entries per (block, query) candidate list
   int timing = 0;
   int add_raw = 0;          // adds store the rows as given (already preprocessed, e.g. a reloaded index)
-  int reserve_cus = 16;     // CUs the scan leaves to the pre/post stages of other batches (async searches)
+  int reserve_cus = 0;      // > 0: asynchronous searches run their pre/post stages on separate streams and the
+                            // scan leaves this many CUs free for them (measured: no gain on MI355X, the scan
+                            // saturates HBM and starves the small kernels — kept as an experiment switch)
 
   Workspace ws[kWorkspaces];
   bool ws_ready = false;
@@ -198,7 +200,11 @@ int launch_select(int nblocks, const SelParams &sp, hipStream_t st) {
     attr_set = true;
   }
   if (sp.G > kSelMaxLists) return fail(ANR_EINTERNAL, "select: too many candidate lists (%d)", sp.G);
-  hipLaunchKernelGGL(k_select, dim3(nblocks), dim3(1024), sizeof(SelShared), st, sp);
+  // small inputs (threshold sample, candidate lists) use a 256-thread block: barriers are 4x cheaper
+  const int64_t n_hint = sp.dense ? sp.n : (int64_t)sp.G * 16;
+  const int nt = 1024;
+  (void)n_hint;
+  hipLaunchKernelGGL(k_select, dim3(nblocks), dim3(nt), sizeof(SelShared), st, sp);
   ANR_HIP(hipGetLastError());
   return ANR_OK;
 }
@@ -366,8 +372,7 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
   w.exact_all = h->force_exact != 0 || h->f16_unusable;
 
   // pipelined: three stages on three streams; otherwise everything on the scan stream
-  static const bool one_stream = getenv("ANORAG_ONE_STREAM") != nullptr;  // developer switch
-  if (one_stream) pipelined = false;
+  if (h->reserve_cus <= 0) pipelined = false;  // one stream, full grid: batches still queue without host syncs
   hipStream_t s_pre = pipelined ? h->s_pre : h->s_scan;
   hipStream_t s_scan = h->s_scan;
   hipStream_t s_post = pipelined ? h->s_post : h->s_scan;
@@ -400,7 +405,7 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
   // threshold sample: ~1/64 of the rows, between 4K and 16K (more rows -> tighter first threshold)
   const int64_t auto_sample = round_up(std::min<int64_t>(16384, std::max<int64_t>(4096, h->ntotal / 64)), 1024);
   int64_t sample_tiles = (h->sample_rows > 0 ? h->sample_rows : auto_sample) / kTileRows;
-  if (sample_tiles * kTileRows < 2 * M) sample_tiles = ceil_div(2 * M, kTileRows);
+  if (sample_tiles < 2 * M) sample_tiles = 2 * M;  // tile maxima: the M-th largest is backed by M distinct rows
   const bool sparse = full_tiles >= 8 * sample_tiles;
   w.sparse = sparse;
   const int side_grid = h->n_cu;
@@ -455,13 +460,15 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
     sc.n_tiles = sample_tiles;
     sc.dense = w.dense;
     sc.dense_ld = w.dense_ld;
+    sc.groupmax = 1;  // one value per 32-row tile: the K'-th largest tile maximum is a valid threshold
     ANR_TRY(launch_scan<true>(h, sc, s_pre, side_grid));
+    sc.groupmax = 0;
     SelParams ss = sp;
     ss.dense = w.dense;
     ss.dense_ld = w.dense_ld;
-    ss.n = sample_tiles * kTileRows;
+    ss.n = sample_tiles;
     ss.row0 = 0;
-    ss.row_tile_stride = sc.tile_stride;
+    ss.row_tile_stride = 1;
     ss.ladder = w.ladder;
     ss.lcum_zero = w.lcum;
     ANR_TRY(launch_select(kQB, ss, s_pre));
@@ -496,6 +503,13 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
     sp.capb = (unsigned)h->cand_cap;
     sp.overflow = w.ncand + kQB;
     sp.ncand = w.ncand;
+    sp.lcum_in = w.lcum;
+    sp.ladder_in = w.ladder;
+    sp.kprime = (unsigned)M;
+    {
+      static const char *dbg = getenv("ANORAG_SEL_STOP");
+      sp.debug_stop = dbg ? atoi(dbg) : 0;
+    }
     ANR_TRY(launch_select(nq, sp, s_post));
   }
 

@@ -236,6 +236,7 @@ struct ScanParams {
   // DENSE
   float *dense;      // [64][dense_ld], column = i*32 + row-in-tile
   int64_t dense_ld;
+  int groupmax;      // DENSE: write only the maximum of each 32-row tile: dense[q][i]
   // sparse
   const float *ladder;   // [64][kLadder] ascending thresholds from the sample
   unsigned *lcum;        // [64][kLadder][kCumStride] emitted rows with score >= ladder level
@@ -368,7 +369,21 @@ __global__ __launch_bounds__(NT) void k_scan(ScanParams p) {
       }
     }
 
-    if (DENSE) {
+    if (DENSE && p.groupmax) {
+      // threshold sample: one value per (32-row tile, query) — the tile's best score
+      float m0 = acc0[0], m1 = acc1[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) {
+        m0 = fmaxf(m0, acc0[r]);
+        m1 = fmaxf(m1, acc1[r]);
+      }
+      m0 = fmaxf(m0, __shfl_xor(m0, 32));
+      m1 = fmaxf(m1, __shfl_xor(m1, 32));
+      if (half == 0) {
+        p.dense[(int64_t)q0 * p.dense_ld + i] = m0;
+        p.dense[(int64_t)(q0 + 32) * p.dense_ld + i] = m1;
+      }
+    } else if (DENSE) {
       const float ninf = -__builtin_inff();
       float *d0 = p.dense + (int64_t)q0 * p.dense_ld + i * kTileRows + 4 * half;
       float *d1 = d0 + 32 * p.dense_ld;
@@ -448,6 +463,12 @@ struct SelParams {
   unsigned *overflow;    // optional [64]: set when a list overflowed
   unsigned *ncand;       // optional [64]: candidates seen
   unsigned *lcum_zero;   // optional: ladder mode also clears this query's level counters
+  // list input, optional pre-filter: the highest ladder level reached by >= kprime emitted rows bounds the
+  // K'-th best from below, so only candidates at or above it need to be ranked
+  const unsigned *lcum_in;
+  const float *ladder_in;
+  unsigned kprime;
+  int debug_stop;        // developer switch: leave the kernel early (timing experiments only)
 };
 
 struct SelShared {
@@ -486,6 +507,7 @@ __global__ __launch_bounds__(1024) void k_select(SelParams p) {
   extern __shared__ unsigned char sel_smem[];
   SelShared &sh = *reinterpret_cast<SelShared *>(sel_smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int NT = blockDim.x, NW = NT >> 6;
   const int q = blockIdx.x;
   int64_t n;
   if (p.dense) {
@@ -493,7 +515,7 @@ __global__ __launch_bounds__(1024) void k_select(SelParams p) {
   } else {
     if (tid == 0) sh.ovf = 0;
     __syncthreads();
-    for (int b = tid; b < p.G; b += 1024) {
+    for (int b = tid; b < p.G; b += NT) {
       unsigned c = p.cntb[(int64_t)q * p.G + b];
       if (c > p.capb) {
         sh.ovf = 1;
@@ -502,20 +524,21 @@ __global__ __launch_bounds__(1024) void k_select(SelParams p) {
       sh.offs[b + 1] = c;
     }
     __syncthreads();
-    {
-      // inclusive scan of the (<= 1024) list lengths: wave scan + wave totals
-      unsigned v = tid < p.G ? sh.offs[tid + 1] : 0u;
+    if (tid == 0) sh.offs[0] = 0;
+    for (int base_i = 0; base_i < p.G; base_i += NT) {
+      // inclusive scan of one chunk of list lengths: wave scan + wave totals, carried across chunks
+      const int i = base_i + tid;
+      unsigned v = i < p.G ? sh.offs[i + 1] : 0u;
       for (int off = 1; off < 64; off <<= 1) {
         const unsigned t = __shfl_up(v, off);
         if (lane >= off) v += t;
       }
       if (lane == 63) sh.hist[wave] = v;
       __syncthreads();
-      unsigned base = 0;
-      for (int w = 0; w < wave; ++w) base += sh.hist[w];
+      unsigned carry = sh.offs[base_i];
+      for (int w = 0; w < wave; ++w) carry += sh.hist[w];
       __syncthreads();
-      if (tid < p.G) sh.offs[tid + 1] = v + base;
-      if (tid == 0) sh.offs[0] = 0;
+      if (i < p.G) sh.offs[i + 1] = v + carry;
       __syncthreads();
     }
     n = sh.offs[p.G];
@@ -524,39 +547,61 @@ __global__ __launch_bounds__(1024) void k_select(SelParams p) {
       if (p.ncand) p.ncand[q] = (unsigned)n;
     }
   }
-  const int M = (int)((int64_t)p.M < n ? (int64_t)p.M : n);
-  if (tid == 0) p.out_m[q] = M;
+  if (p.debug_stop == 1) return;
+  int M = (int)((int64_t)p.M < n ? (int64_t)p.M : n);
   if (M == 0) {
+    if (tid == 0) p.out_m[q] = 0;
     if (p.ladder && tid < kLadder) p.ladder[q * kLadder + tid] = -__builtin_inff();
     return;
   }
   const bool staged = n <= kSelLds;
+  if (tid == 0) sh.cnt = 0;
+  __syncthreads();
   // stage the keys in LDS (when they fit) and find the common leading bytes of all keys on the way -> those
   // radix passes are skipped (this also avoids one-bin LDS atomic storms)
   unsigned long long kmin = ~0ull, kmax = 0ull;
   if (staged) {
     if (p.dense) {
-      for (int64_t i = tid; i < n; i += 1024) {
+      for (int64_t i = tid; i < n; i += NT) {
         const unsigned long long k = sel_key(p, sh, q, i, false);
         sh.keys[i] = k;
         kmin = k < kmin ? k : kmin;
         kmax = k > kmax ? k : kmax;
       }
     } else {
-      for (int b = wave; b < p.G; b += 16) {
-        const unsigned o = sh.offs[b], c = sh.offs[b + 1] - o;
-        const uint2 *list = p.cand + ((int64_t)b * kQB + q) * p.capb;
-        for (unsigned j = lane; j < c; j += 64) {
-          const uint2 e = list[j];
-          const unsigned long long k = make_key(__uint_as_float(e.x), e.y);
-          sh.keys[o + j] = k;
+      // pre-filter threshold: highest ladder level reached by >= kprime emitted rows (levels read in parallel)
+      if (tid < kLadder) {
+        bool ok = false;
+        if (p.lcum_in && tid >= 1) ok = p.lcum_in[(int64_t)(q * kLadder + tid) * kCumStride] >= p.kprime;
+        sh.hist[tid] = ok ? 1u : 0u;
+      }
+      __syncthreads();
+      float thr = -__builtin_inff();
+      for (int j = kLadder - 1; j >= 1; --j)
+        if (sh.hist[j]) {
+          thr = p.ladder_in[q * kLadder + j];
+          break;
+        }
+      // one thread per candidate over the flattened lists, so every list read is in flight at once
+      for (int64_t i = tid; i < n; i += NT) {
+        int lo = 0, hi = p.G;  // offs[lo] <= i < offs[hi]
+        while (hi - lo > 1) {
+          const int mid = (lo + hi) >> 1;
+          if (sh.offs[mid] <= (unsigned)i) lo = mid;
+          else hi = mid;
+        }
+        const uint2 e = p.cand[((int64_t)lo * kQB + q) * p.capb + ((unsigned)i - sh.offs[lo])];
+        const float sc = __uint_as_float(e.x);
+        if (sc >= thr) {
+          const unsigned long long k = make_key(sc, e.y);
+          sh.keys[atomicAdd(&sh.cnt, 1u)] = k;  // order is irrelevant: the keys are ranked afterwards
           kmin = k < kmin ? k : kmin;
           kmax = k > kmax ? k : kmax;
         }
       }
     }
   } else {
-    for (int64_t i = tid; i < n; i += 1024) {
+    for (int64_t i = tid; i < n; i += NT) {
       const unsigned long long k = sel_key(p, sh, q, i, false);
       kmin = k < kmin ? k : kmin;
       kmax = k > kmax ? k : kmax;
@@ -572,21 +617,42 @@ __global__ __launch_bounds__(1024) void k_select(SelParams p) {
     sh.red[wave][1] = kmax;
   }
   __syncthreads();
+  if (staged && !p.dense) {
+    n = sh.cnt;  // candidates that survived the pre-filter (>= K' of them unless a list overflowed)
+    M = (int)((int64_t)p.M < n ? (int64_t)p.M : n);
+    if (p.debug_stop == 9 && tid == 0 && p.ncand) p.ncand[q] = (unsigned)n;
+  }
+  if (tid == 0) p.out_m[q] = M;
+  if (M == 0) return;
+  if (p.debug_stop == 2) return;
   kmin = sh.red[0][0];
   kmax = sh.red[0][1];
-  for (int w = 1; w < 16; ++w) {
+  for (int w = 1; w < NW; ++w) {
     kmin = sh.red[w][0] < kmin ? sh.red[w][0] : kmin;
     kmax = sh.red[w][1] > kmax ? sh.red[w][1] : kmax;
   }
+  if (staged && n <= kMaxSel) {
+    // small input: rank every key directly (distinct keys), n*n/NT compares per thread
+    for (int i = tid; i < (int)n; i += NT) {
+      const unsigned long long kk = sh.keys[i];
+      int rank = 0;
+#pragma unroll 16
+      for (int j = 0; j < (int)n; ++j) rank += (sh.keys[j] > kk) ? 1 : 0;
+      if (rank < M) sh.sel[rank] = kk;
+    }
+    __syncthreads();
+    for (int i = tid; i < M; i += NT) sh.srt[i] = sh.sel[i];
+    __syncthreads();
+  } else {
   int bits = 0;
   while (bits < 64 && (kmin >> (56 - bits)) == (kmax >> (56 - bits))) bits += 8;
   unsigned long long prefix = bits ? (kmax >> (64 - bits)) : 0ull;
   unsigned need = (unsigned)M;
   bool whole = (bits == 64);
   while (!whole && bits < 64) {
-    for (int i = tid; i < 256; i += 1024) sh.hist[i] = 0;
+    for (int i = tid; i < 256; i += NT) sh.hist[i] = 0;
     __syncthreads();
-    for (int64_t i = tid; i < n; i += 1024) {
+    for (int64_t i = tid; i < n; i += NT) {
       const unsigned long long k = sel_key(p, sh, q, i, staged);
       if (bits == 0 || (k >> (64 - bits)) == prefix) atomicAdd(&sh.hist[(unsigned)(k >> (56 - bits)) & 255u], 1u);
     }
@@ -624,7 +690,7 @@ __global__ __launch_bounds__(1024) void k_select(SelParams p) {
   // gather keys whose leading `bits` bits are >= prefix: exactly M of them
   if (tid == 0) sh.cnt = 0;
   __syncthreads();
-  for (int64_t i = tid; i < n; i += 1024) {
+  for (int64_t i = tid; i < n; i += NT) {
     const unsigned long long k = sel_key(p, sh, q, i, staged);
     if (bits == 0 || (k >> (64 - bits)) >= prefix) {
       const unsigned pos = atomicAdd(&sh.cnt, 1u);
@@ -633,14 +699,17 @@ __global__ __launch_bounds__(1024) void k_select(SelParams p) {
   }
   __syncthreads();
   // order the M gathered keys by rank counting (keys are distinct): M*M/1024 compares per thread, one barrier
-  for (int i = tid; i < M; i += 1024) {
+  for (int i = tid; i < M; i += NT) {
     const unsigned long long k = sh.sel[i];
     int rank = 0;
+#pragma unroll 16
     for (int j = 0; j < M; ++j) rank += (sh.sel[j] > k) ? 1 : 0;
     sh.srt[rank] = k;
   }
   __syncthreads();
-  for (int i = tid; i < M; i += 1024) {
+  }
+  if (p.debug_stop == 3) return;
+  for (int i = tid; i < M; i += NT) {
     const unsigned long long k = sh.srt[i];
     float v = ord2f((unsigned)(k >> 32));
     p.out_rank[q * kMaxSel + i] = p.negate ? -v : v;
@@ -727,6 +796,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinalParams p) {
   for (int i = tid; i < m; i += 256) {
     const unsigned long long k = srt[i];
     int rank = 0;
+#pragma unroll 16
     for (int j = 0; j < m; ++j) rank += (srt[j] > k) ? 1 : 0;
     sel[rank] = k;
   }

@@ -69,10 +69,9 @@ int anr_index_search_dev(anr_index *h, const float *q_dev, int64_t nq, int32_t k
                          int64_t *I_dev, void *stream);
 
 /* Asynchronous form: enqueues the search and returns; results are complete for work enqueued on `stream`
- * after the call (the stream is made to wait on them).  Successive calls overlap: the query preparation /
- * threshold sample of one batch and the candidate selection / exact re-score of another run beside the
- * corpus scan of a third (three rotating workspaces; the scan leaves ANR_OPT_RESERVE_CUS compute units
- * free for them).  D_dev / I_dev of calls still in flight must be distinct buffers.  anr_index_sync()
+ * after the call (the stream is made to wait on them).  Up to three batches are in flight (rotating
+ * workspaces), so successive calls queue back to back on the device with no host synchronisation in between.
+ * D_dev / I_dev of calls still in flight must be distinct buffers.  anr_index_sync()
  * waits for everything enqueued, runs the exact path for the queries whose certificate failed (patching
  * D_dev / I_dev) and folds the statistics: results are FINAL only after it returns. */
 int anr_index_search_dev_async(anr_index *h, const float *q_dev, int64_t nq, int32_t k, float *D_dev,
@@ -86,7 +85,7 @@ int anr_index_sync(anr_index *h);
 #define ANR_OPT_CAND_CAP 4        /* per-query candidate buffer entries                               */
 #define ANR_OPT_TIMING 5          /* 1: record HIP-event time of the scan kernel in stats             */
 #define ANR_OPT_ADD_RAW 6         /* 1: adds store rows as given (already normalised: reloading a saved index) */
-#define ANR_OPT_RESERVE_CUS 7     /* compute units the scan leaves free during asynchronous searches (default 16) */
+#define ANR_OPT_RESERVE_CUS 7     /* > 0: async searches use 3 streams and the scan leaves this many CUs free (default 0) */
 int anr_index_set_option(anr_index *h, int32_t opt, int64_t value);
 
 typedef struct anr_search_stats {
