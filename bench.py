@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--cpu-rows", type=int, default=200_000, help="rows of the CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--recall-queries", type=int, default=4)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsal)")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     return ap.parse_args()
 
 
@@ -105,14 +107,14 @@ def cpu_baseline(args, world):
     }
 
 
-def recall_vs_oracle(args, shards_host_iter, q_host, I_gpu):
-    """recall@k of the GPU ids against the float64-arbitrated oracle for a few queries (full corpus)."""
+def oracle_partial_topk(args, shards_host_iter, q_host, row0):
+    """float64-arbitrated top-k of a few queries over this rank's rows (global ids): (scores [nq,k], ids [nq,k])"""
     from oracle import flat_index as orc
     nq = q_host.shape[0]
     qn = orc.preprocess_vectors(q_host)
     best_s = np.full((nq, 0), 0.0)
     best_i = np.zeros((nq, 0), dtype=np.int64)
-    base = 0
+    base = row0
     for xb in shards_host_iter():
         xn = orc.preprocess_vectors(xb)
         s = qn.astype(np.float64) @ xn.astype(np.float64).T
@@ -124,10 +126,29 @@ def recall_vs_oracle(args, shards_host_iter, q_host, I_gpu):
         best_s = np.take_along_axis(best_s, o, axis=1)
         best_i = np.take_along_axis(best_i, o, axis=1)
         base += xb.shape[0]
-    hits = 0
-    for i in range(nq):
-        hits += len(set(best_i[i].tolist()) & set(I_gpu[i].tolist()))
-    return hits / float(nq * args.k)
+    return best_s, best_i
+
+
+def recall_from_partials(parts, I_gpu, k):
+    s = np.concatenate([p[0] for p in parts], axis=1)
+    i = np.concatenate([p[1] for p in parts], axis=1)
+    o = np.argsort(-s, axis=1, kind="stable")[:, :k]
+    ref = np.take_along_axis(i, o, axis=1)
+    hits = sum(len(set(ref[r].tolist()) & set(I_gpu[r].tolist())) for r in range(ref.shape[0]))
+    return hits / float(ref.shape[0] * k)
+
+
+def pmc_traffic(rows_total, rows_per_gpu, dim):
+    """HBM bytes per k_scan launch from the committed PMC pass (profiles/r01_pmc_traffic_k_scan.json: FETCH_SIZE
+    doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE), scaled by rows when the shard differs."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_k_scan.json")) as f:
+            p = json.load(f)
+        if p["dim"] != dim:
+            return None
+        return p["traffic_bytes_per_launch"] * rows_per_gpu / p["rows"]
+    except Exception:
+        return None
 
 
 def main():
@@ -143,9 +164,13 @@ def main():
         import torch.distributed as dist  # noqa: F811
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if args.one_device:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -193,8 +218,17 @@ def main():
         if world > 1:
             with torch.cuda.stream(st):
                 Il[s].add_(row0)  # local -> global ids (no -1 padding: every shard holds >= k rows)
-                dist.all_gather_into_tensor(Dg[s], Dl[s])
-                dist.all_gather_into_tensor(Ig[s], Il[s])
+                if args.backend == "nccl":
+                    dist.all_gather_into_tensor(Dg[s], Dl[s])
+                    dist.all_gather_into_tensor(Ig[s], Il[s])
+                else:  # rehearsal path (gloo has no all_gather_into_tensor for device tensors)
+                    st.synchronize()
+                    dh = [torch.empty_like(Dl[s], device="cpu") for _ in range(world)]
+                    ih = [torch.empty_like(Il[s], device="cpu") for _ in range(world)]
+                    dist.all_gather(dh, Dl[s].cpu())
+                    dist.all_gather(ih, Il[s].cpu())
+                    Dg[s].copy_(torch.stack(dh))
+                    Ig[s].copy_(torch.stack(ih))
                 _lib.check(lib.anr_merge_topk_dev(local_rank, C.c_void_p(Dg[s].data_ptr()),
                                                   C.c_void_p(Ig[s].data_ptr()), world, args.batch, args.k, 1,
                                                   C.c_void_p(Dm[s].data_ptr()), C.c_void_p(Im[s].data_ptr()),
@@ -225,14 +259,14 @@ def main():
     scan_ms, scan_bytes = st_all["scan_ms"], st_all["scan_bytes"]
     n_fallback, n_cand = st_all["n_fallback"], st_all["n_candidates"]
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # recall@k of the last batch's first few queries vs the oracle (single-GPU run only: the oracle needs
-    # the rows on the host)
+    # recall@k of the last batch's first few queries vs the oracle: every rank ranks its own rows on the CPU
+    # (float64), rank 0 merges the partial lists and compares with the ids the GPU path returned
     recall = None
-    if world == 1 and rank == 0 and args.recall_queries > 0:
+    if args.recall_queries > 0:
         nrq = min(args.recall_queries, args.batch)
         I_gpu = Ires[:nrq].cpu().numpy()
         qh = Q[nb - 1, :nrq].cpu().numpy()
@@ -241,7 +275,14 @@ def main():
             for xb in gen_shard(my_rows, args.dim, rank, dev, chunk=524_288):
                 yield xb.cpu().numpy()
 
-        recall = recall_vs_oracle(args, shards, qh, I_gpu)
+        part = oracle_partial_topk(args, shards, qh, row0)
+        if world > 1:
+            parts = [None] * world
+            dist.all_gather_object(parts, part)
+        else:
+            parts = [part]
+        if rank == 0:
+            recall = recall_from_partials(parts, I_gpu, args.k)
 
     if rank == 0:
         qps = args.batch * args.steps / dt
@@ -279,7 +320,7 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
-                "traffic": None,
+                "traffic": pmc_traffic(rows_total, per, args.dim),
                 "bytes_per_launch": scan_bytes / max(1, args.steps),
                 "ms_per_launch": scan_ms / max(1, args.steps),
             },

@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""Measure the BASELINE.json configs other than the headline one (C1, C2, C4, C5) on one MI355X and write
+gpurun_out/configs.json.  Developer/report tool (bench.py is the driver-facing benchmark)."""
+import json, os, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "ano-rag_amd")); sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from anorag_hip import FlatIndex, METRIC_IP
+from oracle import flat_index as orc
+
+out = {}
+dev = torch.device("cuda", 0)
+
+# ---- C1: 10k x 384, batch-1 top-10, host buffers (what VectorIndex.search does) -------------------------
+x = np.random.default_rng(1234).standard_normal((10_000, 384), dtype=np.float32)
+q = np.random.default_rng(4321).standard_normal((200, 384), dtype=np.float32)
+idx = FlatIndex(384, METRIC_IP, normalize=True); idx.add(x)
+for i in range(5): idx.search(q[i:i + 1], 10)
+t0 = time.perf_counter()
+for i in range(200): D, I = idx.search(q[i:i + 1], 10)
+gpu_us = (time.perf_counter() - t0) / 200 * 1e6
+xn = orc.preprocess_vectors(x)
+t0 = time.perf_counter()
+for i in range(200):
+    qn = orc.preprocess_vectors(q[i:i + 1]); s = qn @ xn.T
+    part = np.argpartition(-s, 9, axis=1)[:, :10]; o = np.argsort(-np.take_along_axis(s, part, 1), axis=1)
+cpu_us = (time.perf_counter() - t0) / 200 * 1e6
+Dr, Ir = orc.flat_search(orc.preprocess_vectors(q[199:200]), xn, 10, "ip")
+out["C1"] = {"config": "10k x 384, batch-1 top-10 (host in/out, synchronous)", "gpu_us_per_query": gpu_us,
+             "cpu_oracle_us_per_query": cpu_us, "ids_match_oracle": bool(np.array_equal(I, Ir))}
+idx.close()
+
+# ---- C2: 1M x 768, batch-64 top-100 ----------------------------------------------------------------------
+def build(rows, dim):
+    ix = FlatIndex(dim, METRIC_IP, normalize=True); ix.reserve(rows)
+    g = torch.Generator(device=dev); g.manual_seed(1234)
+    done = 0
+    while done < rows:
+        m = min(262144, rows - done)
+        xb = torch.randn((m, dim), generator=g, device=dev); torch.cuda.synchronize()
+        ix.add_device(xb.data_ptr(), m); done += m
+    return ix
+idx = build(1_000_000, 768)
+g = torch.Generator(device=dev); g.manual_seed(4321)
+Q = torch.randn((43, 64, 768), generator=g, device=dev)
+NS = 3
+S = [torch.cuda.Stream() for _ in range(NS)]
+Ds = [torch.empty((64, 100), device=dev) for _ in range(NS)]; Is = [torch.empty((64, 100), device=dev, dtype=torch.int64) for _ in range(NS)]
+from anorag_hip._lib import OPT_TIMING
+idx.set_option(OPT_TIMING, 1)
+for i in range(3): idx.search_device_async(Q[i].data_ptr(), 64, 100, Ds[i % NS].data_ptr(), Is[i % NS].data_ptr(), S[i % NS].cuda_stream)
+idx.sync(); torch.cuda.synchronize(); idx.reset_stats()
+t0 = time.perf_counter()
+for i in range(3, 43): idx.search_device_async(Q[i].data_ptr(), 64, 100, Ds[i % NS].data_ptr(), Is[i % NS].data_ptr(), S[i % NS].cuda_stream)
+idx.sync(); torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / 40
+st = idx.last_stats()
+out["C2"] = {"config": "1M x 768, batch-64 top-100, device buffers", "qps": 64 / dt, "ms_per_batch": dt * 1e3,
+             "scan_ms": st["scan_ms"] / 40, "scan_GBps": st["scan_bytes"] / 1e9 / (st["scan_ms"] / 1e3),
+             "fallback": st["n_fallback"]}
+
+# ---- C4: encode 256 queries (bge-base-en shape, seeded weights) + search over the 1M corpus ---------------
+from oracle import encoder as oenc
+from anorag_hip.encoder import SentenceEncoder
+tmp = tempfile.mkdtemp()
+md = oenc.make_synthetic_model(os.path.join(tmp, "bge-base-synth"), layers=12, hidden=768, heads=12, intermediate=3072,
+                               vocab=30522, max_pos=512, pooling="cls", weight_std=0.03)
+enc = SentenceEncoder(md)
+prefix = "Represent this sentence for searching relevant passages: "
+sents = [prefix + s for s in oenc.synthetic_sentences(md, 256, seed=7, min_words=8, max_words=24)]
+ids, lens, _ = enc.tokenize(sents)
+enc.encode(sents[:64], batch_size=64, normalize_embeddings=True)
+t0 = time.perf_counter()
+for _ in range(5): E = enc.encode(sents, batch_size=256, normalize_embeddings=True)
+t_enc = (time.perf_counter() - t0) / 5
+t0 = time.perf_counter()
+for _ in range(5): ids, lens, types = enc.tokenize(sents)
+t_tok = (time.perf_counter() - t0) / 5
+tokens = int(ids.shape[0] * ((ids.shape[1] + 31) // 32 * 32))
+flops = 12 * (2 * tokens * (4 * 768 * 768 + 2 * 768 * 3072)) + 12 * 4 * ids.shape[0] * (ids.shape[1] ** 2) * 768
+t0 = time.perf_counter()
+for _ in range(5): D, I = idx.search(E, 100)
+t_search = (time.perf_counter() - t0) / 5
+ref = oenc.encode(md, sents[:16], batch_size=16, normalize=True)
+cos = float(np.sum(E[:16] * ref, axis=1).min())
+out["C4"] = {"config": "bge-base-en shape (12L, H768, 12 heads, I3072, vocab 30522, CLS), 256 queries + search 1M x 768 top-100",
+             "padded_seq_len": int(ids.shape[1]), "encode_ms_total": t_enc * 1e3, "tokenize_ms": t_tok * 1e3,
+             "encoder_device_ms": (t_enc - t_tok) * 1e3, "encoder_TFLOPs_per_s": flops / max(1e-9, (t_enc - t_tok)) / 1e12,
+             "search_ms_256_queries": t_search * 1e3, "end_to_end_qps": 256 / (t_enc + t_search),
+             "min_cosine_vs_f32_oracle_16": cos}
+enc.close(); idx.close()
+
+# ---- C5: dense + BM25 fusion, 200 queries, pool 80 ---------------------------------------------------------
+from retrieval.hybrid_search import HybridSearcher
+from oracle import fusion as ofu
+rng = np.random.default_rng(99)
+queries = []
+for _ in range(200):
+    did = rng.choice(1_000_000, 100, replace=False); ds = np.sort(rng.random(100))[::-1]
+    bid = rng.choice(1_000_000, 1000, replace=False); bs = np.abs(rng.standard_normal(1000)); bs /= bs.max()
+    queries.append(([(int(i), float(s)) for i, s in zip(did, ds)], [(int(i), float(s)) for i, s in zip(bid, bs)], None, None))
+res = {}
+for method in ("linear", "rrf"):
+    hs = HybridSearcher({"retrieval": {"candidate_pool": 80, "hybrid": {"fusion_method": method, "rrf_k": 60,
+                                                                        "weights": {"dense": 1.0, "bm25": 0.5, "graph": 0.5, "path": 0.1}}}})
+    hs.fuse_batch(queries[:8])
+    t0 = time.perf_counter(); got = hs.fuse_batch(queries); t_gpu = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    exp = [ofu.fuse(*qq, candidate_pool=80, fusion_method=method, weights=hs.weights, rrf_k=60) for qq in queries]
+    t_cpu = time.perf_counter() - t0
+    same = all([r["final_similarity"] for r in a] == [r["final_similarity"] for r in b] for a, b in zip(got, exp))
+    res[method] = {"device_path_ms_200_queries_incl_python_marshalling": t_gpu * 1e3, "python_reference_algorithm_ms": t_cpu * 1e3,
+                   "finals_bit_identical": bool(same)}
+out["C5"] = {"config": "200 queries: dense top-100 + 1000 BM25 hits over 1M note ids, pool 80", **res}
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "configs.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
