@@ -144,25 +144,24 @@ __global__ __launch_bounds__(256) void k_layernorm(LnParams p) {
   const int64_t tb = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (tb >= p.TB) return;
   const int h = lane >> 5;
-  float s = 0.f;
+  // one statistics pass: sums of (x - c) and (x - c)^2 with c = the token's first value (shifted, so the
+  // single-pass variance does not cancel), then the normalising pass: two reads of the row instead of three
+  const float c = __shfl(p.in[(tb * p.KB * 64 + (lane & 31)) * 8], lane & 31);
+  float s = 0.f, s2 = 0.f;
   for (int kb = 0; kb < p.KB; ++kb) {
     const float4 *x = reinterpret_cast<const float4 *>(p.in + ((tb * p.KB + kb) * 64 + lane) * 8);
-    const float4 a = x[0], c = x[1];
-    s += (a.x + a.y) + (a.z + a.w) + (c.x + c.y) + (c.z + c.w);
+    const float4 a = x[0], b = x[1];
+    const float d0 = a.x - c, d1 = a.y - c, d2 = a.z - c, d3 = a.w - c, d4 = b.x - c, d5 = b.y - c, d6 = b.z - c,
+                d7 = b.w - c;
+    s += (d0 + d1) + (d2 + d3) + (d4 + d5) + (d6 + d7);
+    s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3) + (d4 * d4 + d5 * d5) + (d6 * d6 + d7 * d7);
   }
   s += __shfl_xor(s, 32);
-  const float mean = s / p.H;
-  float v = 0.f;
-  for (int kb = 0; kb < p.KB; ++kb) {
-    const float *x = p.in + ((tb * p.KB + kb) * 64 + lane) * 8;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float d = x[j] - mean;
-      v += d * d;
-    }
-  }
-  v += __shfl_xor(v, 32);
-  const float rstd = rsqrtf(v / p.H + p.eps);
+  s2 += __shfl_xor(s2, 32);
+  const float md = s / p.H;                       // mean - c
+  const float var = fmaxf(s2 / p.H - md * md, 0.f);
+  const float mean = c + md;
+  const float rstd = rsqrtf(var + p.eps);
   for (int kb = 0; kb < p.KB; ++kb) {
     const int64_t e = ((tb * p.KB + kb) * 64 + lane) * 8;
     const int o = (kb * 2 + h) * 8;

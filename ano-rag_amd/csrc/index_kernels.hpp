@@ -484,8 +484,8 @@ struct SelShared {
 };
 
 __device__ __forceinline__ unsigned long long sel_key(const SelParams &p, const SelShared &sh, int q, int64_t i,
-                                                      bool staged) {
-  if (staged) return sh.keys[i];
+                                                      bool staged, int koff = 0) {
+  if (staged) return sh.keys[koff + i];
   if (p.dense) {
     float v = p.dense[(int64_t)q * p.dense_ld + i];
     if (p.negate) v = -v;
@@ -622,6 +622,7 @@ __global__ __launch_bounds__(1024) void k_select(SelParams p) {
     M = (int)((int64_t)p.M < n ? (int64_t)p.M : n);
     if (p.debug_stop == 9 && tid == 0 && p.ncand) p.ncand[q] = (unsigned)n;
   }
+  int koff = 0;
   if (tid == 0) p.out_m[q] = M;
   if (M == 0) return;
   if (p.debug_stop == 2) return;
@@ -631,13 +632,61 @@ __global__ __launch_bounds__(1024) void k_select(SelParams p) {
     kmin = sh.red[w][0] < kmin ? sh.red[w][0] : kmin;
     kmax = sh.red[w][1] > kmax ? sh.red[w][1] : kmax;
   }
+  if (staged && n > 256 && n <= kSelLds / 2) {
+    // shrink the ranking problem: 256 linear score bins between the smallest and largest staged score, keep the
+    // keys from the top bins that together hold >= M keys (typically M plus a few dozen)
+    const float smin = ord2f((unsigned)(kmin >> 32)), smax = ord2f((unsigned)(kmax >> 32));
+    const float scale = smax > smin ? 255.0f / (smax - smin) : 0.0f;
+    for (int i = tid; i < 256; i += NT) sh.hist[i] = 0;
+    if (tid == 0) sh.cnt = 0;
+    __syncthreads();
+    for (int64_t i = tid; i < n; i += NT) {
+      const float sc = ord2f((unsigned)(sh.keys[i] >> 32));
+      int bin = (int)((sc - smin) * scale);
+      bin = bin < 0 ? 0 : (bin > 255 ? 255 : bin);
+      atomicAdd(&sh.hist[bin], 1u);
+    }
+    __syncthreads();
+    if (wave == 0) {
+      const int dtop = 255 - 4 * lane;
+      const unsigned h0 = sh.hist[dtop], h1 = sh.hist[dtop - 1], h2 = sh.hist[dtop - 2], h3 = sh.hist[dtop - 3];
+      const unsigned own = h0 + h1 + h2 + h3;
+      unsigned incl = own;
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+      }
+      const unsigned excl = incl - own, need = (unsigned)M;
+      if (excl < need && need <= incl) {
+        unsigned c = excl;
+        int d = dtop;
+        if (c + h0 < need) { c += h0; d = dtop - 1;
+          if (c + h1 < need) { c += h1; d = dtop - 2;
+            if (c + h2 < need) { d = dtop - 3; } } }
+        sh.d = d;
+      }
+    }
+    __syncthreads();
+    const int cut = sh.d;
+    for (int64_t i = tid; i < n; i += NT) {
+      const unsigned long long k = sh.keys[i];
+      const float sc = ord2f((unsigned)(k >> 32));
+      int bin = (int)((sc - smin) * scale);
+      bin = bin < 0 ? 0 : (bin > 255 ? 255 : bin);
+      if (bin >= cut) sh.keys[kSelLds / 2 + atomicAdd(&sh.cnt, 1u)] = k;
+    }
+    __syncthreads();
+    n = sh.cnt;
+    koff = kSelLds / 2;
+    __syncthreads();
+  }
   if (staged && n <= kMaxSel) {
     // small input: rank every key directly (distinct keys), n*n/NT compares per thread
     for (int i = tid; i < (int)n; i += NT) {
-      const unsigned long long kk = sh.keys[i];
+      const unsigned long long kk = sh.keys[koff + i];
       int rank = 0;
 #pragma unroll 16
-      for (int j = 0; j < (int)n; ++j) rank += (sh.keys[j] > kk) ? 1 : 0;
+      for (int j = 0; j < (int)n; ++j) rank += (sh.keys[koff + j] > kk) ? 1 : 0;
       if (rank < M) sh.sel[rank] = kk;
     }
     __syncthreads();
@@ -653,7 +702,7 @@ __global__ __launch_bounds__(1024) void k_select(SelParams p) {
     for (int i = tid; i < 256; i += NT) sh.hist[i] = 0;
     __syncthreads();
     for (int64_t i = tid; i < n; i += NT) {
-      const unsigned long long k = sel_key(p, sh, q, i, staged);
+      const unsigned long long k = sel_key(p, sh, q, i, staged, koff);
       if (bits == 0 || (k >> (64 - bits)) == prefix) atomicAdd(&sh.hist[(unsigned)(k >> (56 - bits)) & 255u], 1u);
     }
     __syncthreads();
@@ -691,7 +740,7 @@ __global__ __launch_bounds__(1024) void k_select(SelParams p) {
   if (tid == 0) sh.cnt = 0;
   __syncthreads();
   for (int64_t i = tid; i < n; i += NT) {
-    const unsigned long long k = sel_key(p, sh, q, i, staged);
+    const unsigned long long k = sel_key(p, sh, q, i, staged, koff);
     if (bits == 0 || (k >> (64 - bits)) >= prefix) {
       const unsigned pos = atomicAdd(&sh.cnt, 1u);
       if (pos < (unsigned)kMaxSel) sh.sel[pos] = k;

@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp
-for st in 1 2 3 0; do
+for st in 5 6 7 4; do
   export ANORAG_SEL_STOP=$st
   rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/sel$st -- python3 $GRAFT_REPO_ROOT/tools/scan_perf.py --rows 1250000 --steps 10 --mode sync > /dev/null 2>&1
   python3 - <<PY
