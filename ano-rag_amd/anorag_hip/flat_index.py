@@ -57,6 +57,18 @@ class FlatIndex:
         )
         return D, I
 
+    def score_rows(self, q, ids):
+        """exact score of query i against each stored row ids[i][j] (float32 [nq, per]; NaN for bad ids)"""
+        q = _f32_matrix(q, self.d, "score_rows")
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        if ids.ndim != 2 or ids.shape[0] != q.shape[0]:
+            raise ValueError("ids must be [nq, per_query]")
+        out = np.empty(ids.shape, dtype=np.float32)
+        _lib.check(self._lib.anr_index_score_rows(self._h, q.ctypes.data_as(C.c_void_p), q.shape[0],
+                                                  ids.ctypes.data_as(C.c_void_p), ids.shape[1],
+                                                  out.ctypes.data_as(C.c_void_p)), "anr_index_score_rows")
+        return out
+
     def reset(self) -> None:
         _lib.check(self._lib.anr_index_reset(self._h), "anr_index_reset")
 

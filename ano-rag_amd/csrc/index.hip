@@ -844,6 +844,68 @@ int anr_index_sync(anr_index *h) {
   return drain(h);
 }
 
+int anr_index_score_rows(anr_index *h, const float *q_host, int64_t nq, const int64_t *ids_host, int32_t per_query,
+                         float *out_host) {
+  if (!h || !q_host || !ids_host || !out_host || nq < 0 || per_query < 0) return fail(ANR_EINVAL, "bad argument");
+  const int64_t total = nq * per_query;
+  if (total == 0) return ANR_OK;
+  DeviceGuard g(h->device);
+  if (!g.ok) return fail(ANR_EHIP, "hipSetDevice(%d) failed", h->device);
+  std::lock_guard<std::mutex> lk(h->mu);
+  ANR_TRY(drain(h));
+  float *dq = nullptr, *dout = nullptr, *dqn = nullptr;
+  int64_t *dids = nullptr;
+  _Float16 *dq16 = nullptr;
+  float *dqs = nullptr;
+  int rc = ANR_OK;
+  auto cleanup = [&]() {
+    dev_free(dq); dev_free(dout); dev_free(dqn); dev_free(dids); dev_free(dq16); dev_free(dqs);
+  };
+  // queries go through the same preprocessing as searches (normalisation for cosine) in blocks of 64
+  if ((rc = dev_alloc(&dq, nq * h->dim, false)) || (rc = dev_alloc(&dout, total, false)) ||
+      (rc = dev_alloc(&dids, total, false)) || (rc = dev_alloc(&dqn, (int64_t)round_up(nq, kQB) * h->dim, false)) ||
+      (rc = dev_alloc(&dq16, (int64_t)kQB * h->dimp, false)) || (rc = dev_alloc(&dqs, kQB * 4, false))) {
+    cleanup();
+    return rc;
+  }
+  hipStream_t st = h->stream;
+  float *dq32 = nullptr;
+  if ((rc = dev_alloc(&dq32, (int64_t)kQB * h->dimp, false))) {
+    cleanup();
+    return rc;
+  }
+  hipError_t e = hipMemcpyAsync(dq, q_host, (size_t)nq * h->dim * sizeof(float), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(dids, ids_host, (size_t)total * sizeof(int64_t), hipMemcpyHostToDevice, st);
+  for (int64_t q0 = 0; q0 < nq && e == hipSuccess; q0 += kQB) {
+    const int nb = (int)std::min<int64_t>(kQB, nq - q0);
+    PrepQParams qp{};
+    qp.qin = dq + q0 * h->dim;
+    qp.nq = nb;
+    qp.dim = h->dim;
+    qp.dimp = h->dimp;
+    qp.kb = h->kb;
+    qp.normalize = h->normalize;
+    qp.q32 = dq32;
+    qp.q16 = dq16;
+    qp.qstat = dqs;
+    hipLaunchKernelGGL(k_prepq, dim3(kQB), dim3(256), 0, st, qp);
+    // compact the padded [64][dimp] block back to [nb][dim]
+    e = hipMemcpy2DAsync(dqn + q0 * h->dim, (size_t)h->dim * sizeof(float), dq32, (size_t)h->dimp * sizeof(float),
+                         (size_t)h->dim * sizeof(float), (size_t)nb, hipMemcpyDeviceToDevice, st);
+  }
+  if (e == hipSuccess) {
+    ScoreRowsParams sp{h->x32, dqn, h->dim, h->metric, h->ntotal, dids, per_query, total, dout};
+    hipLaunchKernelGGL(k_score_rows, dim3((unsigned)ceil_div(total, 4)), dim3(256), 0, st, sp);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(out_host, dout, (size_t)total * sizeof(float), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  dev_free(dq32);
+  cleanup();
+  if (e != hipSuccess) return fail(ANR_EHIP, "score_rows failed: %s", hipGetErrorString(e));
+  return ANR_OK;
+}
+
 int anr_index_set_option(anr_index *h, int32_t opt, int64_t value) {
   if (!h) return fail(ANR_EINVAL, "null handle");
   DeviceGuard g(h->device);

@@ -808,6 +808,43 @@ __global__ __launch_bounds__(256) void k_rescore(RescoreParams p) {
   if (lane == 0) p.exact[q * kMaxSel + j] = (float)acc;
 }
 
+// score_rows: exact value of given (query, row) pairs — the gather(note_embeddings, ids) . q the reference
+// recomputes per candidate (query/query_processor.py:3492-3589); one wave per pair, f64 accumulation
+struct ScoreRowsParams {
+  const float *x32;
+  const float *q;      // [nq][dim] (already preprocessed like index queries)
+  int dim, metric;
+  int64_t n_rows;
+  const int64_t *ids;  // [nq][per]
+  int per;
+  int64_t total;       // nq * per
+  float *out;          // [nq][per]; rows outside [0, n_rows) give NaN
+};
+
+__global__ __launch_bounds__(256) void k_score_rows(ScoreRowsParams p) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= p.total) return;
+  const int64_t row = p.ids[w];
+  if (row < 0 || row >= p.n_rows) {
+    if (lane == 0) p.out[w] = __builtin_nanf("");
+    return;
+  }
+  const float *x = p.x32 + row * p.dim;
+  const float *qv = p.q + (w / p.per) * p.dim;
+  double acc = 0.0;
+  if (p.metric == 0) {
+    for (int k = lane; k < p.dim; k += 64) acc += (double)x[k] * (double)qv[k];
+  } else {
+    for (int k = lane; k < p.dim; k += 64) {
+      const double d = (double)qv[k] - (double)x[k];
+      acc += d * d;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if (lane == 0) p.out[w] = (float)acc;
+}
+
 // ------------------------------------------------------------------------------------------------
 // finalize: per query sort the re-scored candidates, write the top-k, decide the certificate
 // ------------------------------------------------------------------------------------------------

@@ -290,6 +290,26 @@ class VectorRetriever:
             logger.error(f"Enhanced retrieval failed: {e}")
             return self.search_single(query, top_k, similarity_threshold, include_metadata)
 
+    def score_candidates(self, queries: List[str], candidates: List[List[Any]]) -> List[List[float]]:
+        """EXTENSION (not in the reference; opt-in): cosine similarity of query i with each of its candidate notes
+        (note ids) from the embeddings already on the device — what query_processor.py:3492-3589 obtains by
+        re-encoding every candidate's text.  Not wired into any reference call path: using stored embeddings
+        instead of re-encoded text changes the scores.  Unknown ids score 0.0; negative
+        similarities are clamped to 0.0 as there."""
+        if not queries:
+            return []
+        per = max((len(c) for c in candidates), default=0)
+        if per == 0 or self.vector_index.index is None:
+            return [[0.0] * len(c) for c in candidates]
+        q_emb = self.embedding_manager.encode_queries(queries)
+        ids = np.full((len(queries), per), -1, dtype=np.int64)
+        for i, cand in enumerate(candidates):
+            for j, nid in enumerate(cand):
+                ids[i, j] = self.note_id_to_index.get(nid, -1)
+        sims = self.vector_index.index.score_rows(q_emb, ids)
+        return [[0.0 if (ids[i, j] < 0 or not np.isfinite(sims[i, j])) else max(0.0, float(sims[i, j]))
+                 for j in range(len(cand))] for i, cand in enumerate(candidates)]
+
     # -- incremental maintenance --------------------------------------------------------------------
     def add_notes(self, new_notes: List[Dict[str, Any]], rebuild_index: bool = False) -> bool:
         if not new_notes:

@@ -78,6 +78,13 @@ int anr_index_search_dev_async(anr_index *h, const float *q_dev, int64_t nq, int
                                int64_t *I_dev, void *stream);
 int anr_index_sync(anr_index *h);
 
+/* Exact scores of given rows: out[q][j] = score(query q, stored row ids[q][j]) — the
+ * gather(note_embeddings, ids) . q that query/query_processor.py:3543-3589 recomputes per candidate
+ * (there by re-encoding every candidate).  Queries are preprocessed like search queries; ids outside
+ * [0, ntotal) give NaN.  Opt-in helper: the reference never takes this path. */
+int anr_index_score_rows(anr_index *h, const float *q_host, int64_t nq, const int64_t *ids_host,
+                         int32_t per_query, float *out_host);
+
 /* tuning / introspection */
 #define ANR_OPT_FORCE_EXACT 1     /* 1: skip the f16 scan, run the dense exact path for every query  */
 #define ANR_OPT_OVERFETCH 2       /* candidates kept per query before the exact re-score (0 = auto)  */

@@ -169,3 +169,74 @@ def test_async_pipelined_search_equals_sync():
         assert np.array_equal(D.cpu().numpy(), D_all[b * 64:(b + 1) * 64])
     assert idx.last_stats()["n_queries"] == 320
     idx.close()
+
+
+def test_c2_full_size_1m_x_768_batch64_top100():
+    """BASELINE config C2 at full size: 1M x 768, batch-64 top-100, against the float64 oracle, plus the
+    size-independent properties (sortedness, unique in-range ids, agreement with the independent dense exact
+    path, self-retrieval)."""
+    import torch
+    from anorag_hip import FlatIndex, METRIC_IP
+    from anorag_hip._lib import OPT_FORCE_EXACT
+    n, d, nq, k = 1_000_000, 768, 64, 100
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234)
+    idx = FlatIndex(d, METRIC_IP, normalize=True)
+    idx.reserve(n)
+    host = np.empty((n, d), dtype=np.float32)
+    for s in range(0, n, 250_000):
+        xb = torch.randn((250_000, d), generator=g, device=dev)
+        torch.cuda.synchronize()
+        idx.add_device(xb.data_ptr(), xb.shape[0])
+        host[s:s + 250_000] = xb.cpu().numpy()
+    del xb
+    q = np.random.default_rng(4321).standard_normal((nq, d), dtype=np.float32)
+    q[7] = host[123_456]                                  # self-retrieval probe
+    D, I = idx.search(q, k)
+    st = idx.last_stats()
+    assert st["n_overflow"] == 0 and st["n_fallback"] <= 2, st
+    # properties
+    assert np.all(np.diff(D, axis=1) <= 0)
+    assert all(len(set(r)) == k for r in I.tolist()) and I.min() >= 0 and I.max() < n
+    assert I[7, 0] == 123_456 and abs(D[7, 0] - 1.0) < 1e-5
+    # oracle (float64 arbitration) at full size
+    xn, qn = orc.preprocess_vectors(host), orc.preprocess_vectors(q)
+    del host
+    s64 = orc.exact_scores(qn, xn, "ip", block=100_000)
+    for i in range(nq):
+        kth = np.partition(s64[i], n - k)[n - k]
+        ref = set(np.nonzero(s64[i] >= kth)[0].tolist())
+        got = set(I[i].tolist())
+        assert all(abs(s64[i][r] - kth) <= 1e-6 for r in got ^ ref), f"query {i}: id set differs beyond near-ties"
+        assert np.max(np.abs(D[i] - s64[i][I[i]].astype(np.float32))) <= SCORE_TOL
+    # the dense exact path is an independent algorithm: identical output
+    idx.set_option(OPT_FORCE_EXACT, 1)
+    D2, I2 = idx.search(q[:8], k)
+    assert np.array_equal(I2, I[:8]) and np.array_equal(D2, D[:8])
+    idx.close()
+
+
+def test_score_rows_matches_oracle():
+    """anr_index_score_rows: gather(rows, ids) . q with the index's query preprocessing (cosine / L2)."""
+    from anorag_hip import FlatIndex, METRIC_IP, METRIC_L2
+    x, q = _data(5000, 200, 70)
+    ids = np.random.default_rng(3).integers(0, 5000, size=(70, 13))
+    ids[0, 0] = -1
+    ids[1, 1] = 5000
+    idx = FlatIndex(200, METRIC_IP, normalize=True)
+    idx.add(x)
+    got = idx.score_rows(q, ids)
+    xn, qn = orc.preprocess_vectors(x), orc.preprocess_vectors(q)
+    ref = np.einsum("qd,qjd->qj", qn.astype(np.float64), xn[np.clip(ids, 0, 4999)].astype(np.float64))
+    assert np.isnan(got[0, 0]) and np.isnan(got[1, 1])
+    ok = np.ones_like(got, dtype=bool)
+    ok[0, 0] = ok[1, 1] = False
+    assert np.max(np.abs(got[ok] - ref[ok])) <= 1e-6
+    idx.close()
+    l2 = FlatIndex(200, METRIC_L2, normalize=False)
+    l2.add(x)
+    got = l2.score_rows(q, ids)
+    ref = ((q[:, None, :].astype(np.float64) - x[np.clip(ids, 0, 4999)].astype(np.float64)) ** 2).sum(-1)
+    assert np.max(np.abs(got[ok] - ref[ok]) / ref[ok]) <= 1e-6
+    l2.close()
