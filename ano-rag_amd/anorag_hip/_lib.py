@@ -98,6 +98,12 @@ SIGNATURES = {
         [C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int32,
          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     ),
+    "anr_bm25_create": (C.c_int, [C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.POINTER(C.c_void_p)]),
+    "anr_bm25_destroy": (C.c_int, [C.c_void_p]),
+    "anr_bm25_scores": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "anr_bm25_nonzero": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                   C.c_void_p, C.c_void_p]),
     "anr_encoder_create": (C.c_int, [C.POINTER(EncoderConfig), C.c_int32, C.POINTER(C.c_void_p)]),
     "anr_encoder_destroy": (C.c_int, [C.c_void_p]),
     "anr_encoder_set_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),

@@ -1,0 +1,284 @@
+// Device BM25 scoring behind anr_bm25_* (include/anorag.h): the per-query scoring loop of the reference's
+// SimpleBM25.get_scores / bm25_scores (utils/bm25_search.py:43-63, :286-340) as a CSR postings scatter.
+//
+// The host precomputes, in float64 and with the reference's own expression, the weight of every posting
+//   w(t, d) = idf_t * (tf * (k1 + 1) / (tf + k1 * (1 - b + b * (dl_d / avgdl))))
+// so that score(q, d) = sum over the query tokens (with repetition, in query order) of w(token, d).
+// One workgroup per query walks the query's tokens in order; inside one token every document occurs at most
+// once, so its postings are added concurrently (float64 L2 atomics) and a barrier separates the tokens: every
+// document receives its additions in exactly the reference's order -> bit-identical float64 scores.
+// Then max-normalisation (scores / max when max > 0) as bm25_scores does.
+#include <algorithm>
+#include <mutex>
+#include <vector>
+
+#include "common.hpp"
+
+namespace anr {
+
+struct Bm25Params {
+  const int64_t *indptr;   // [n_terms + 1]
+  const int32_t *docs;     // [nnz]
+  const double *weights;   // [nnz]
+  int64_t n_docs;
+  const int64_t *q_indptr; // [nq + 1]
+  const int32_t *q_terms;
+  double *scores;          // [nq][n_docs], zeroed
+  int normalize;
+};
+
+__global__ __launch_bounds__(1024) void k_bm25(Bm25Params p) {
+  __shared__ double s_red[16];
+  __shared__ double s_max;
+  const int q = blockIdx.x, tid = threadIdx.x;
+  double *sc = p.scores + (int64_t)q * p.n_docs;
+  for (int64_t t = p.q_indptr[q]; t < p.q_indptr[q + 1]; ++t) {
+    const int term = p.q_terms[t];
+    const int64_t lo = p.indptr[term], hi = p.indptr[term + 1];
+    for (int64_t e = lo + tid; e < hi; e += 1024) atomicAdd(sc + p.docs[e], p.weights[e]);
+    __syncthreads();  // token order == the reference's addition order
+  }
+  if (!p.normalize) return;
+  __threadfence_block();
+  double m = 0.0;
+  bool any = false;
+  for (int64_t d = tid; d < p.n_docs; d += 1024) {
+    const double v = __hip_atomic_load(sc + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    m = (!any || v > m) ? v : m;
+    any = true;
+  }
+  if (!any) m = -__builtin_inf();
+  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+  if ((tid & 63) == 0) s_red[tid >> 6] = m;
+  __syncthreads();
+  if (tid == 0) {
+    double mm = s_red[0];
+    for (int w = 1; w < 16; ++w) mm = fmax(mm, s_red[w]);
+    s_max = mm;
+  }
+  __syncthreads();
+  const double mx = s_max;
+  if (mx > 0.0)
+    for (int64_t d = tid; d < p.n_docs; d += 1024) {
+      const double v = __hip_atomic_load(sc + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      sc[d] = v / mx;
+    }
+}
+
+// compaction of the non-zero scores of each query: (doc, score) pairs, unordered
+struct NzParams {
+  const double *scores;
+  int64_t n_docs;
+  int cap;
+  int32_t *out_docs;   // [nq][cap]
+  double *out_scores;  // [nq][cap]
+  int *out_count;      // [nq] (may exceed cap: truncated)
+};
+
+__global__ __launch_bounds__(1024) void k_bm25_nonzero(NzParams p) {
+  __shared__ int s_cnt;
+  const int q = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) s_cnt = 0;
+  __syncthreads();
+  const double *sc = p.scores + (int64_t)q * p.n_docs;
+  for (int64_t d = tid; d < p.n_docs; d += 1024) {
+    const double v = sc[d];
+    if (v != 0.0) {
+      const int pos = atomicAdd(&s_cnt, 1);
+      if (pos < p.cap) {
+        p.out_docs[(int64_t)q * p.cap + pos] = (int32_t)d;
+        p.out_scores[(int64_t)q * p.cap + pos] = v;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) p.out_count[q] = s_cnt;
+}
+
+}  // namespace anr
+
+using namespace anr;
+
+struct anr_bm25 {
+  int device = 0;
+  int64_t n_docs = 0, n_terms = 0, nnz = 0;
+  int64_t *indptr = nullptr;
+  int32_t *docs = nullptr;
+  double *weights = nullptr;
+  hipStream_t stream = nullptr;
+  std::mutex mu;
+};
+
+namespace {
+template <typename T>
+int b_alloc(T **p, int64_t n) {
+  *p = nullptr;
+  ANR_HIP(hipMalloc(reinterpret_cast<void **>(p), (size_t)(n > 0 ? n : 1) * sizeof(T)));
+  return ANR_OK;
+}
+template <typename T>
+void b_free(T *&p) {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+}
+
+int validate_queries(const anr_bm25 *h, int64_t nq, const int64_t *q_indptr, const int32_t *q_terms) {
+  if (!h || nq < 0 || !q_indptr) return fail(ANR_EINVAL, "bad argument");
+  if (q_indptr[0] != 0) return fail(ANR_EINVAL, "q_indptr[0] must be 0");
+  for (int64_t i = 0; i < nq; ++i)
+    if (q_indptr[i + 1] < q_indptr[i]) return fail(ANR_EINVAL, "q_indptr must be non-decreasing");
+  if (q_indptr[nq] > 0 && !q_terms) return fail(ANR_EINVAL, "null q_terms");
+  for (int64_t e = 0; e < q_indptr[nq]; ++e)
+    if (q_terms[e] < 0 || q_terms[e] >= h->n_terms) return fail(ANR_EINVAL, "query term id %d out of range", q_terms[e]);
+  return ANR_OK;
+}
+
+// runs the scoring of one chunk of queries into a fresh device buffer; caller frees *d_scores
+int score_chunk(anr_bm25 *h, int64_t nq, const int64_t *q_indptr, const int32_t *q_terms, int normalize,
+                double **d_scores) {
+  int64_t *dq = nullptr;
+  int32_t *dt = nullptr;
+  const int64_t nt = q_indptr[nq] - q_indptr[0];
+  std::vector<int64_t> rel(nq + 1);
+  for (int64_t i = 0; i <= nq; ++i) rel[i] = q_indptr[i] - q_indptr[0];
+  ANR_TRY(b_alloc(&dq, nq + 1));
+  int rc = b_alloc(&dt, nt);
+  if (rc == ANR_OK) rc = b_alloc(d_scores, nq * h->n_docs);
+  hipError_t e = hipSuccess;
+  if (rc == ANR_OK) {
+    e = hipMemcpyAsync(dq, rel.data(), (size_t)(nq + 1) * 8, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess && nt > 0)
+      e = hipMemcpyAsync(dt, q_terms + q_indptr[0], (size_t)nt * 4, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(*d_scores, 0, (size_t)nq * h->n_docs * 8, h->stream);
+    if (e == hipSuccess) {
+      Bm25Params p{h->indptr, h->docs, h->weights, h->n_docs, dq, dt, *d_scores, normalize};
+      hipLaunchKernelGGL(k_bm25, dim3((unsigned)nq), dim3(1024), 0, h->stream, p);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  }
+  b_free(dq);
+  b_free(dt);
+  if (rc != ANR_OK) return rc;
+  if (e != hipSuccess) return fail(ANR_EHIP, "bm25 scoring failed: %s", hipGetErrorString(e));
+  return ANR_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int anr_bm25_create(int32_t device, int64_t n_docs, int64_t n_terms, const int64_t *indptr, const int32_t *doc_ids,
+                    const double *weights, anr_bm25 **out) {
+  if (!out) return fail(ANR_EINVAL, "out is null");
+  *out = nullptr;
+  if (n_docs < 0 || n_terms < 0 || !indptr) return fail(ANR_EINVAL, "bad argument");
+  if (n_docs > 0x7fffffffll) return fail(ANR_EINVAL, "at most 2^31-1 documents");
+  const int64_t nnz = indptr[n_terms];
+  if (indptr[0] != 0 || nnz < 0 || (nnz > 0 && (!doc_ids || !weights))) return fail(ANR_EINVAL, "bad CSR arrays");
+  for (int64_t t = 0; t < n_terms; ++t)
+    if (indptr[t + 1] < indptr[t]) return fail(ANR_EINVAL, "indptr must be non-decreasing");
+  for (int64_t e = 0; e < nnz; ++e)
+    if (doc_ids[e] < 0 || doc_ids[e] >= n_docs) return fail(ANR_EINVAL, "posting %lld: document id out of range", (long long)e);
+  int ndev = anr_device_count();
+  if (ndev <= 0) return fail(ANR_EHIP, "no HIP device is visible");
+  if (device < 0 || device >= ndev) return fail(ANR_EINVAL, "device %d out of range", device);
+  DeviceGuard g(device);
+  anr_bm25 *h = new anr_bm25();
+  h->device = device;
+  h->n_docs = n_docs;
+  h->n_terms = n_terms;
+  h->nnz = nnz;
+  int rc = ANR_OK;
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) rc = fail(ANR_EHIP, "hipStreamCreate failed");
+  if (rc == ANR_OK) rc = b_alloc(&h->indptr, n_terms + 1);
+  if (rc == ANR_OK) rc = b_alloc(&h->docs, nnz);
+  if (rc == ANR_OK) rc = b_alloc(&h->weights, nnz);
+  if (rc == ANR_OK) {
+    hipError_t e = hipMemcpy(h->indptr, indptr, (size_t)(n_terms + 1) * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess && nnz > 0) e = hipMemcpy(h->docs, doc_ids, (size_t)nnz * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess && nnz > 0) e = hipMemcpy(h->weights, weights, (size_t)nnz * 8, hipMemcpyHostToDevice);
+    if (e != hipSuccess) rc = fail(ANR_EHIP, "upload failed: %s", hipGetErrorString(e));
+  }
+  if (rc != ANR_OK) {
+    anr_bm25_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return ANR_OK;
+}
+
+int anr_bm25_destroy(anr_bm25 *h) {
+  if (!h) return ANR_OK;
+  DeviceGuard g(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  b_free(h->indptr);
+  b_free(h->docs);
+  b_free(h->weights);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return ANR_OK;
+}
+
+int anr_bm25_scores(anr_bm25 *h, int64_t nq, const int64_t *q_indptr, const int32_t *q_terms, int32_t normalize,
+                    double *out_host) {
+  ANR_TRY(validate_queries(h, nq, q_indptr, q_terms));
+  if (!out_host) return fail(ANR_EINVAL, "out is null");
+  if (nq == 0 || h->n_docs == 0) return ANR_OK;
+  DeviceGuard g(h->device);
+  std::lock_guard<std::mutex> lk(h->mu);
+  const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(nq, (int64_t)(1ll << 30) / (h->n_docs * 8)));
+  for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
+    const int64_t m = std::min(chunk, nq - q0);
+    double *d = nullptr;
+    int rc = score_chunk(h, m, q_indptr + q0, q_terms, normalize, &d);
+    if (rc == ANR_OK) {
+      hipError_t e = hipMemcpy(out_host + q0 * h->n_docs, d, (size_t)m * h->n_docs * 8, hipMemcpyDeviceToHost);
+      if (e != hipSuccess) rc = fail(ANR_EHIP, "download failed: %s", hipGetErrorString(e));
+    }
+    b_free(d);
+    if (rc != ANR_OK) return rc;
+  }
+  return ANR_OK;
+}
+
+int anr_bm25_nonzero(anr_bm25 *h, int64_t nq, const int64_t *q_indptr, const int32_t *q_terms, int32_t normalize,
+                     int32_t cap, int32_t *out_docs, double *out_scores, int32_t *out_count) {
+  ANR_TRY(validate_queries(h, nq, q_indptr, q_terms));
+  if (cap <= 0 || !out_docs || !out_scores || !out_count) return fail(ANR_EINVAL, "bad output arguments");
+  if (nq == 0) return ANR_OK;
+  DeviceGuard g(h->device);
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (h->n_docs == 0) {
+    for (int64_t i = 0; i < nq; ++i) out_count[i] = 0;
+    return ANR_OK;
+  }
+  const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(nq, (int64_t)(1ll << 31) / (h->n_docs * 8)));
+  for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
+    const int64_t m = std::min(chunk, nq - q0);
+    double *d = nullptr, *dsc = nullptr;
+    int32_t *ddoc = nullptr;
+    int *dcnt = nullptr;
+    int rc = score_chunk(h, m, q_indptr + q0, q_terms, normalize, &d);
+    if (rc == ANR_OK) rc = b_alloc(&ddoc, m * cap);
+    if (rc == ANR_OK) rc = b_alloc(&dsc, m * cap);
+    if (rc == ANR_OK) rc = b_alloc(&dcnt, m);
+    if (rc == ANR_OK) {
+      NzParams np{d, h->n_docs, cap, ddoc, dsc, dcnt};
+      hipLaunchKernelGGL(k_bm25_nonzero, dim3((unsigned)m), dim3(1024), 0, h->stream, np);
+      hipError_t e = hipGetLastError();
+      if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+      if (e == hipSuccess) e = hipMemcpy(out_docs + q0 * cap, ddoc, (size_t)m * cap * 4, hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipMemcpy(out_scores + q0 * cap, dsc, (size_t)m * cap * 8, hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipMemcpy(out_count + q0, dcnt, (size_t)m * 4, hipMemcpyDeviceToHost);
+      if (e != hipSuccess) rc = fail(ANR_EHIP, "bm25 nonzero failed: %s", hipGetErrorString(e));
+    }
+    b_free(d);
+    b_free(ddoc);
+    b_free(dsc);
+    b_free(dcnt);
+    if (rc != ANR_OK) return rc;
+  }
+  return ANR_OK;
+}
+
+}  // extern "C"

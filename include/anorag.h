@@ -164,6 +164,26 @@ int anr_encoder_finalize(anr_encoder *e); /* fails if a tensor is missing */
 int anr_encoder_forward(anr_encoder *e, const int32_t *ids, const int32_t *lengths, const int32_t *type_ids,
                         int32_t B, int32_t L, int32_t normalize, float *out_host);
 
+/* ------------------------------------------------------------------------------------------------
+ * BM25 scoring: SimpleBM25.get_scores / bm25_scores of utils/bm25_search.py:43-63,
+ * :286-340 over a CSR postings image.  Tokenisation, term ids and the float64 posting weights
+ *   w(t,d) = idf_t * (tf*(k1+1) / (tf + k1*(1 - b + b*(dl_d/avgdl))))
+ * are host work (anorag_hip/bm25_search.py); the device adds them per query in the reference's order, so the
+ * float64 scores are bit-identical.  normalize != 0 divides by the maximum when it is > 0 (:329-333).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct anr_bm25 anr_bm25;
+int anr_bm25_create(int32_t device, int64_t n_docs, int64_t n_terms, const int64_t *indptr /*[n_terms+1]*/,
+                    const int32_t *doc_ids, const double *weights, anr_bm25 **out);
+int anr_bm25_destroy(anr_bm25 *h);
+/* query i = term ids q_terms[q_indptr[i] .. q_indptr[i+1]) in query-token order (repeats count twice, unknown
+ * tokens are simply omitted).  out_host: dense [nq][n_docs] float64. */
+int anr_bm25_scores(anr_bm25 *h, int64_t nq, const int64_t *q_indptr, const int32_t *q_terms, int32_t normalize,
+                    double *out_host);
+/* sparse form for the fusion: the documents with a non-zero score, unordered; out_count may exceed cap
+ * (the lists are then truncated) */
+int anr_bm25_nonzero(anr_bm25 *h, int64_t nq, const int64_t *q_indptr, const int32_t *q_terms, int32_t normalize,
+                     int32_t cap, int32_t *out_docs, double *out_scores, int32_t *out_count);
+
 #ifdef __cplusplus
 }
 #endif
