@@ -33,7 +33,8 @@ struct Workspace {
   float *ladder = nullptr;
   unsigned *lcum = nullptr;   // [64][kLadder][kCumStride]
   unsigned *cntb = nullptr;   // [64][n_cu]
-  unsigned *ncand = nullptr;  // [64] candidates, then [64] overflow flags
+  unsigned *ncand = nullptr;  // status block: [64] candidates | [64] overflow | [64] flags | [64] theta (float)
+  int *qslots = nullptr;      // [64] query slots of a second pass
   uint2 *cand = nullptr;      // [n_cu][64][cand_cap]
   int64_t cand_alloc = 0;
   float *sel_rank = nullptr;
@@ -157,14 +158,15 @@ int ensure_workspaces(anr_index *h) {
     ANR_TRY(dev_alloc(&w.ladder, kQB * kLadder, true));
     ANR_TRY(dev_alloc(&w.lcum, (int64_t)kQB * kLadder * kCumStride, true));
     ANR_TRY(dev_alloc(&w.cntb, (int64_t)kQB * h->n_cu, true));
-    ANR_TRY(dev_alloc(&w.ncand, 3 * kQB, true));
+    ANR_TRY(dev_alloc(&w.ncand, 4 * kQB, true));
+    ANR_TRY(dev_alloc(&w.qslots, kQB, true));
     ANR_TRY(dev_alloc(&w.sel_rank, kQB * kMaxSel, true));
     ANR_TRY(dev_alloc(&w.sel_row, kQB * kMaxSel, true));
     ANR_TRY(dev_alloc(&w.sel_m, kQB, true));
     ANR_TRY(dev_alloc(&w.exact, kQB * kMaxSel, true));
     ANR_TRY(dev_alloc(&w.flags, kQB, true));
     ANR_HIP(hipHostMalloc(reinterpret_cast<void **>(&w.flags_host), kQB * sizeof(int), hipHostMallocDefault));
-    ANR_HIP(hipHostMalloc(reinterpret_cast<void **>(&w.cnt_host), 3 * kQB * sizeof(unsigned), hipHostMallocDefault));
+    ANR_HIP(hipHostMalloc(reinterpret_cast<void **>(&w.cnt_host), 4 * kQB * sizeof(unsigned), hipHostMallocDefault));
     ANR_HIP(hipEventCreateWithFlags(&w.ev_in, hipEventDisableTiming));
     ANR_HIP(hipEventCreateWithFlags(&w.ev_pre, hipEventDisableTiming));
     ANR_HIP(hipEventCreateWithFlags(&w.ev_scan, hipEventDisableTiming));
@@ -315,6 +317,83 @@ int run_exact(anr_index *h, Workspace &w, const std::vector<int> &slots) {
   return ANR_OK;
 }
 
+// Second pass for the queries whose certificate failed (sparse path): a scan with the fixed per-query threshold
+// theta = rank(k-th exact) - eps, which every row of the true top-k must pass, then the exact value of EVERY
+// emitted row and a select on those exact values.  Always exact; costs one more scan for the whole batch
+// however many queries failed.  Queries whose lists overflow are left to the dense exact path (returned).
+int run_second_pass(anr_index *h, Workspace &w, const std::vector<int> &slots, std::vector<int> *still_failed) {
+  hipStream_t st = h->stream;
+  const float inf = __builtin_inff();
+  std::vector<float> lad((size_t)kQB * kLadder, inf);
+  std::vector<int> run;
+  const float *theta = reinterpret_cast<const float *>(w.cnt_host + 3 * kQB);
+  for (int q : slots) {
+    if (theta[q] > -inf) {
+      for (int j = 0; j < kLadder; ++j) lad[(size_t)q * kLadder + j] = theta[q];
+      run.push_back(q);
+    } else {
+      still_failed->push_back(q);
+    }
+  }
+  if (run.empty()) return ANR_OK;
+  ANR_TRY(ensure_cand(h, w));
+  ANR_HIP(hipMemcpyAsync(w.ladder, lad.data(), lad.size() * sizeof(float), hipMemcpyHostToDevice, st));
+  ANR_HIP(hipMemcpyAsync(w.qslots, run.data(), run.size() * sizeof(int), hipMemcpyHostToDevice, st));
+  ANR_HIP(hipMemsetAsync(w.lcum, 0, (size_t)kQB * kLadder * kCumStride * sizeof(unsigned), st));
+  ScanParams sc{};
+  sc.x16 = reinterpret_cast<const uint4 *>(h->x16);
+  sc.q16 = reinterpret_cast<const uint4 *>(w.q16);
+  sc.kb = h->kb;
+  sc.n_rows = h->ntotal;
+  sc.rowbias = h->rowbias;
+  sc.tile0 = 0;
+  sc.tile_stride = 1;
+  sc.n_tiles = ceil_div(h->ntotal, kTileRows);
+  sc.ladder = w.ladder;
+  sc.lcum = w.lcum;
+  sc.cntb = w.cntb;
+  sc.cand = w.cand;
+  sc.capb = (unsigned)h->cand_cap;
+  sc.kprime = 0x7fffffffu;  // levels never advance: the threshold stays theta
+  int grid = 0;
+  ANR_TRY(launch_scan<false>(h, sc, st, h->n_cu, &grid));
+  RescoreListsParams rl{h->x32, w.q32, h->dim, h->dimp, h->metric, w.cand, w.cntb, grid, (unsigned)h->cand_cap, w.qslots};
+  hipLaunchKernelGGL(k_rescore_lists, dim3((unsigned)run.size(), 4), dim3(1024), 0, st, rl);
+  SelParams sp{};
+  sp.cand = w.cand;
+  sp.cntb = w.cntb;
+  sp.G = grid;
+  sp.capb = (unsigned)h->cand_cap;
+  sp.M = w.k;
+  sp.negate = h->metric == ANR_METRIC_L2;  // lists hold -distance: flip back on output
+  sp.out_rank = w.sel_rank;
+  sp.out_row = w.sel_row;
+  sp.out_m = w.sel_m;
+  sp.overflow = w.ncand + kQB;
+  sp.qslots = w.qslots;
+  ANR_TRY(launch_select((int)run.size(), sp, st));
+  {
+    EmitParams mp{};
+    mp.rank = w.sel_rank;
+    mp.row = w.sel_row;
+    mp.m = w.sel_m;
+    mp.nf = (int)run.size();
+    mp.qslots = w.qslots;
+    mp.out_off = w.out_off;
+    mp.k = w.k;
+    mp.metric = h->metric;
+    mp.D = w.D;
+    mp.I = w.I;
+    hipLaunchKernelGGL(k_emit, dim3(mp.nf), dim3(256), 0, st, mp);
+  }
+  ANR_HIP(hipGetLastError());
+  ANR_HIP(hipMemcpyAsync(w.cnt_host + kQB, w.ncand + kQB, kQB * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+  ANR_HIP(hipStreamSynchronize(st));
+  for (int q : run)
+    if (w.cnt_host[kQB + q]) still_failed->push_back(q);  // a list overflowed: dense exact path
+  return ANR_OK;
+}
+
 // wait for a workspace's batch, fold its statistics, run the exact path where the certificate failed
 int retire(anr_index *h, Workspace &w) {
   if (!w.in_flight) return ANR_OK;
@@ -341,7 +420,13 @@ int retire(anr_index *h, Workspace &w) {
   }
   if (!fallback.empty()) {
     h->stats.n_fallback += (int64_t)fallback.size();
-    ANR_TRY(run_exact(h, w, fallback));
+    std::vector<int> dense;
+    if (w.sparse && !w.exact_all) ANR_TRY(run_second_pass(h, w, fallback, &dense));
+    else dense = fallback;
+    if (!dense.empty()) {
+      h->stats.n_dense_exact += (int64_t)dense.size();
+      ANR_TRY(run_exact(h, w, dense));
+    }
   }
   return ANR_OK;
 }
@@ -543,10 +628,11 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
   fp.D = D_dev;
   fp.I = I_dev;
   fp.flags = reinterpret_cast<int *>(w.ncand + 2 * kQB);
+  fp.theta = reinterpret_cast<float *>(w.ncand + 3 * kQB);
   fp.id_offset = 0;
   hipLaunchKernelGGL(k_finalize, dim3(nq), dim3(256), 0, s_post, fp);
   ANR_HIP(hipGetLastError());
-  ANR_HIP(hipMemcpyAsync(w.cnt_host, w.ncand, 3 * kQB * sizeof(unsigned), hipMemcpyDeviceToHost, s_post));
+  ANR_HIP(hipMemcpyAsync(w.cnt_host, w.ncand, 4 * kQB * sizeof(unsigned), hipMemcpyDeviceToHost, s_post));
   ANR_HIP(hipEventRecord(w.ev_done, s_post));
   ANR_HIP(hipStreamWaitEvent(user, w.ev_done, 0));
   return ANR_OK;
@@ -665,7 +751,7 @@ int add_impl(anr_index *h, const float *x_dev, int64_t n, hipStream_t st) {
 void free_workspaces(anr_index *h) {
   for (auto &w : h->ws) {
     dev_free(w.q32); dev_free(w.q16); dev_free(w.qstat); dev_free(w.qstage); dev_free(w.dense);
-    dev_free(w.ladder); dev_free(w.lcum); dev_free(w.cntb); dev_free(w.ncand); dev_free(w.cand);
+    dev_free(w.ladder); dev_free(w.lcum); dev_free(w.cntb); dev_free(w.ncand); dev_free(w.cand); dev_free(w.qslots);
     dev_free(w.sel_rank); dev_free(w.sel_row); dev_free(w.sel_m); dev_free(w.exact); dev_free(w.flags);
     if (w.flags_host) (void)hipHostFree(w.flags_host);
     if (w.cnt_host) (void)hipHostFree(w.cnt_host);

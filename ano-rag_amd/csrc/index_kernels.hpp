@@ -469,6 +469,7 @@ struct SelParams {
   const float *ladder_in;
   unsigned kprime;
   int debug_stop;        // developer switch: leave the kernel early (timing experiments only)
+  const int *qslots;     // optional: block b handles query slot qslots[b]
 };
 
 struct SelShared {
@@ -508,7 +509,7 @@ __global__ __launch_bounds__(1024) void k_select(SelParams p) {
   SelShared &sh = *reinterpret_cast<SelShared *>(sel_smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int NT = blockDim.x, NW = NT >> 6;
-  const int q = blockIdx.x;
+  const int q = p.qslots ? p.qslots[blockIdx.x] : blockIdx.x;
   int64_t n;
   if (p.dense) {
     n = p.n;
@@ -845,6 +846,72 @@ __global__ __launch_bounds__(256) void k_score_rows(ScoreRowsParams p) {
   if (lane == 0) p.out[w] = (float)acc;
 }
 
+// second pass: exact rank score of EVERY entry of a query's candidate lists, written over the scan score
+// (IP: the score; L2: minus the squared distance, so that larger is still better); one workgroup per query
+struct RescoreListsParams {
+  const float *x32;
+  const float *q32;
+  int dim, dimp, metric;
+  uint2 *cand;
+  const unsigned *cntb;
+  int G;
+  unsigned capb;
+  const int *qslots;   // [nf] query slots to process
+};
+
+__global__ __launch_bounds__(1024) void k_rescore_lists(RescoreListsParams p) {
+  __shared__ unsigned offs[kSelMaxLists + 1];
+  __shared__ unsigned wsum[16];
+  const int q = p.qslots[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // exclusive prefix of the (clamped) list lengths, then one wave per flattened entry
+  if (tid == 0) offs[0] = 0;
+  for (int base_i = 0; base_i < p.G; base_i += 1024) {
+    const int i = base_i + tid;
+    unsigned v = 0;
+    if (i < p.G) {
+      v = p.cntb[(int64_t)q * p.G + i];
+      v = v < p.capb ? v : p.capb;
+    }
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned t = __shfl_up(v, off);
+      if (lane >= off) v += t;
+    }
+    if (lane == 63) wsum[wave] = v;
+    __syncthreads();
+    unsigned carry = offs[base_i];
+    for (int w = 0; w < wave; ++w) carry += wsum[w];
+    __syncthreads();
+    if (i < p.G) offs[i + 1] = v + carry;
+    __syncthreads();
+  }
+  const unsigned total = offs[p.G];
+  const float *qv = p.q32 + (int64_t)q * p.dimp;
+  for (unsigned e = blockIdx.y * 16 + wave; e < total; e += 16 * gridDim.y) {
+    int lo = 0, hi = p.G;  // offs[lo] <= e < offs[hi]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (offs[mid] <= e) lo = mid;
+      else hi = mid;
+    }
+    uint2 *ent = p.cand + ((int64_t)lo * kQB + q) * p.capb + (e - offs[lo]);
+    const unsigned row = ent->y;
+    const float *x = p.x32 + (int64_t)row * p.dim;
+    double acc = 0.0;
+    if (p.metric == 0) {
+      for (int k = lane; k < p.dim; k += 64) acc += (double)x[k] * (double)qv[k];
+    } else {
+      for (int k = lane; k < p.dim; k += 64) {
+        const double d = (double)qv[k] - (double)x[k];
+        acc += d * d;
+      }
+      acc = -acc;
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (lane == 0) ent->x = __float_as_uint((float)acc);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // finalize: per query sort the re-scored candidates, write the top-k, decide the certificate
 // ------------------------------------------------------------------------------------------------
@@ -865,6 +932,7 @@ struct FinalParams {
   float *D;
   int64_t *I;
   int *flags;                // [64] 0 = certified, 1 = needs the exact path
+  float *theta;              // [64] scan-score threshold of the second pass: rank(k-th exact) - eps
   int64_t id_offset;
 };
 
@@ -903,6 +971,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinalParams p) {
   }
   if (tid == 0) {
     int flag = 0;
+    float theta = -__builtin_inff();
     if (p.overflow && p.overflow[q]) flag = 1;
     if (kk > 0 && (int64_t)m < p.n_rows) {
       // rows outside the candidate set have approx rank <= approx[m-1]; their exact rank is at most
@@ -916,8 +985,11 @@ __global__ __launch_bounds__(256) void k_finalize(FinalParams p) {
       if (p.metric != 0) kth = 0.5 * (kth + (double)p.qstat[q * 4 + 3]);  // -dist -> q.x - 0.5||x||^2
       if (m < p.M || !(bound < kth)) flag = 1;
       if (m >= p.M && kk < p.k) flag = 1;
+      // every row of the true top-k has exact rank >= kth, hence scan score >= kth - eps (rounded down a little)
+      if (kk >= p.k && !(p.overflow && p.overflow[q])) theta = (float)(kth - eps - 1e-6 * (fabs(kth) + 1.0));
     }
     p.flags[q] = flag;
+    if (p.theta) p.theta[q] = theta;
   }
 }
 
@@ -967,8 +1039,11 @@ struct EmitParams {
   const unsigned *row;
   const int *m;
   int nf;
+  const int *qslots;       // device: query slot of each block, or nullptr -> slot[] below
   int slot[4];             // select slot of each query
   int64_t outq[4];         // output row of each query
+  int64_t out_off;         // with qslots: output row = out_off + slot
+  int sel_is_slot;         // with qslots: the select results live at index slot (else at index blockIdx)
   int k, metric;
   float *D;
   int64_t *I;
@@ -978,11 +1053,12 @@ struct EmitParams {
 __global__ __launch_bounds__(256) void k_emit(EmitParams p) {
   const int f = blockIdx.x;
   if (f >= p.nf) return;
-  const int s = p.slot[f];
+  const int s = p.qslots ? p.qslots[f] : p.slot[f];
+  const int64_t oq = p.qslots ? p.out_off + s : p.outq[f];
   const int m = p.m[s];
   for (int i = threadIdx.x; i < p.k; i += 256) {
-    float *D = p.D + p.outq[f] * (int64_t)p.k;
-    int64_t *I = p.I + p.outq[f] * (int64_t)p.k;
+    float *D = p.D + oq * (int64_t)p.k;
+    int64_t *I = p.I + oq * (int64_t)p.k;
     if (i < m) {
       D[i] = p.rank[s * kMaxSel + i];
       I[i] = (int64_t)p.row[s * kMaxSel + i] + p.id_offset;

@@ -240,3 +240,26 @@ def test_score_rows_matches_oracle():
     ref = ((q[:, None, :].astype(np.float64) - x[np.clip(ids, 0, 4999)].astype(np.float64)) ** 2).sum(-1)
     assert np.max(np.abs(got[ok] - ref[ok]) / ref[ok]) <= 1e-6
     l2.close()
+
+
+def test_tight_clusters_second_pass_is_exact():
+    """near-duplicate neighbourhoods: hundreds of rows within the f16 error bound of the k-th score, so the
+    certificate fails and the fixed-threshold second pass must deliver the exact answer (cosine and L2)."""
+    from anorag_hip import FlatIndex, METRIC_IP, METRIC_L2
+    rng = np.random.default_rng(11)
+    n, d, nq, k = 150_000, 256, 64, 50
+    cent = rng.standard_normal((300, d)).astype(np.float32)
+    x = (cent[rng.integers(0, 300, n)] + 0.02 * rng.standard_normal((n, d))).astype(np.float32)
+    q = (cent[rng.integers(0, 300, nq)] + 0.02 * rng.standard_normal((nq, d))).astype(np.float32)
+    idx = FlatIndex(d, METRIC_IP, normalize=True)
+    idx.add(x)
+    D, I, Dr, Ir = _check(idx, x, q, k, "ip", True)
+    st = idx.last_stats()
+    assert st["n_fallback"] > 0, "this data is meant to defeat the certificate"
+    assert st["n_dense_exact"] == 0, st
+    idx.close()
+    l2 = FlatIndex(d, METRIC_L2, normalize=False)
+    l2.add(x)
+    _check(l2, x, q, k, "l2", False)
+    assert l2.last_stats()["n_dense_exact"] == 0
+    l2.close()

@@ -17,6 +17,7 @@ ap.add_argument("--sample", type=int, default=0)
 ap.add_argument("--overfetch", type=int, default=0)
 ap.add_argument("--reserve", type=int, default=-1)
 ap.add_argument("--mode", default="both")
+ap.add_argument("--clustered", action="store_true", help="1024 Gaussian centroids, sigma 0.3 (SURVEY 8d)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 idx = FlatIndex(a.dim, METRIC_IP, normalize=True)
@@ -26,6 +27,10 @@ done = 0
 while done < a.rows:
     m = min(262144, a.rows - done)
     x = torch.randn((m, a.dim), generator=g, device=dev)
+    if a.clustered:
+        if done == 0:
+            cent = torch.randn((1024, a.dim), generator=g, device=dev)
+        x = cent[torch.randint(0, 1024, (m,), generator=g, device=dev)] + float(os.environ.get("SIGMA", "0.3")) * x
     torch.cuda.synchronize()
     idx.add_device(x.data_ptr(), m)
     done += m
@@ -33,6 +38,8 @@ idx.set_option(OPT_TIMING, 1)
 if a.sample: idx.set_option(OPT_SAMPLE_ROWS, a.sample)
 if a.overfetch: idx.set_option(OPT_OVERFETCH, a.overfetch)
 Q = torch.randn((a.steps + 2, a.batch, a.dim), generator=g, device=dev)
+if a.clustered:
+    Q = cent[torch.randint(0, 1024, (a.steps + 2, a.batch), generator=g, device=dev)] + 0.3 * Q
 D = torch.empty((a.batch, a.k), device=dev); I = torch.empty((a.batch, a.k), device=dev, dtype=torch.int64)
 for i in range(2):
     idx.search_device(Q[i].data_ptr(), a.batch, a.k, D.data_ptr(), I.data_ptr())
