@@ -193,7 +193,51 @@ struct GemmParams {
   _Float16 *out;          // EPI_ACT / EPI_GELU: [TB][NB*2][64][8]; EPI_VT: [NB][TB*2][64][8]
 };
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// gelu(x) = 0.5 x (1 + erf(x / sqrt 2)); erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the f16
+// the value is stored in) — the libm erff costs as much as the GEMM's MFMAs at K = 768
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __frcp_rn(1.0f + 0.3275911f * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float erf_abs = 1.0f - poly * __expf(-z * z);
+  return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
+
+// epilogue of one 32 x 32 accumulator tile (token block tb, feature block nb)
+template <int EPI>
+__device__ __forceinline__ void gemm_store_tile(const GemmParams &p, const floatx16 &c, int64_t tb, int nb, int lane) {
+  const int h = lane >> 5;
+  if (EPI == EPI_VT) {
+    const float bb = p.bias[nb * 32 + (lane & 31)];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      half8 hv;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) hv[j] = (_Float16)(c[8 * s + j] + bb);
+      *reinterpret_cast<half8 *>(p.out + (((int64_t)nb * (p.TB * 2) + tb * 2 + s) * 64 + lane) * 8) = hv;
+    }
+  } else {
+    const float *ba = p.bias_acc + ((int64_t)nb * 2 + h) * 16;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int64_t e = ((tb * (p.NB * 2) + nb * 2 + s) * 64 + lane) * 8;
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = c[8 * s + j] + ba[8 * s + j];
+      if (EPI == EPI_RES) {
+        const float4 r0 = *reinterpret_cast<const float4 *>(p.res_in + e);
+        const float4 r1 = *reinterpret_cast<const float4 *>(p.res_in + e + 4);
+        *reinterpret_cast<float4 *>(p.res_out + e) = make_float4(o[0] + r0.x, o[1] + r0.y, o[2] + r0.z, o[3] + r0.w);
+        *reinterpret_cast<float4 *>(p.res_out + e + 4) = make_float4(o[4] + r1.x, o[5] + r1.y, o[6] + r1.z, o[7] + r1.w);
+      } else {
+        half8 hv;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hv[j] = (_Float16)(EPI == EPI_GELU ? gelu_erf(o[j]) : o[j]);
+        *reinterpret_cast<half8 *>(p.out + e) = hv;
+      }
+    }
+  }
+}
 
 // each wave: MT token blocks x NT feature blocks; waves are laid out feature-group fastest so the waves of a
 // workgroup share their activation fragments through L1
@@ -253,49 +297,95 @@ __global__ __launch_bounds__(256) void k_gemm(GemmParams p) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) b[n] = bn[n];
   }
-  const int h = lane >> 5;
 #pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    const int64_t tb = tb0 + m;
-    if (tb >= p.TB) continue;
+  for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      const int nb = nb0 + n;
-      if (nb >= p.NB) continue;
-      floatx16 c = acc[m][n];
-      if (EPI == EPI_VT) {
-        const float bb = p.bias[nb * 32 + (lane & 31)];
+    for (int n = 0; n < NT; ++n)
+      if (tb0 + m < p.TB && nb0 + n < p.NB) gemm_store_tile<EPI>(p, acc[m][n], tb0 + m, nb0 + n, lane);
+}
+
+// LDS-staged GEMM: a workgroup (4 waves, 2 x 2) owns 128 tokens x 256 features; per stage of two k-steps the
+// 24 operand fragments (4 activation + 8 weight blocks per k-step, 1 KiB each, already in operand layout) are
+// copied global -> LDS once by global_load_lds (lane-linear, so the LDS image needs no swizzle and every
+// ds_read_b128 is conflict-free) and read by the waves that need them: each fragment leaves L2 once per
+// workgroup instead of once per wave.  The copies of stages s+1 and s+2 are in flight while stage s is
+// multiplied (three-slot ring, counted vmcnt + one raw s_barrier per stage, never a full drain in the loop).
+template <int EPI>
+__global__ __launch_bounds__(256) void k_gemm_lds(GemmParams p) {
+  constexpr int TM = 4, TN = 8, S = 2, F = TM + TN, LPW = S * F / 4;  // 6 fragment copies per wave per stage
+  extern __shared__ uint4 g_lds[];  // ring [3][S][F][64]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int NG = (p.NB + TN - 1) / TN;
+  const int64_t tb0 = (int64_t)(blockIdx.x / NG) * TM;
+  const int nb0 = (int)(blockIdx.x % NG) * TN;
+  const int wm = wave >> 1, wn = wave & 1;
+  const uint4 *src[LPW];
+  int dst[LPW];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          half8 hv;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) hv[j] = (_Float16)(c[8 * s + j] + bb);
-          *reinterpret_cast<half8 *>(p.out + (((int64_t)nb * (p.TB * 2) + tb * 2 + s) * 64 + lane) * 8) = hv;
-        }
-      } else {
-        const float *ba = p.bias_acc + ((int64_t)nb * 2 + h) * 16;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const int64_t e = ((tb * (p.NB * 2) + nb * 2 + s) * 64 + lane) * 8;
-          float o[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) o[j] = c[8 * s + j] + ba[8 * s + j];
-          if (EPI == EPI_RES) {
-            const float4 r0 = *reinterpret_cast<const float4 *>(p.res_in + e);
-            const float4 r1 = *reinterpret_cast<const float4 *>(p.res_in + e + 4);
-            *reinterpret_cast<float4 *>(p.res_out + e) = make_float4(o[0] + r0.x, o[1] + r0.y, o[2] + r0.z, o[3] + r0.w);
-            *reinterpret_cast<float4 *>(p.res_out + e + 4) =
-                make_float4(o[4] + r1.x, o[5] + r1.y, o[6] + r1.z, o[7] + r1.w);
-          } else {
-            half8 hv;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) hv[j] = (_Float16)(EPI == EPI_GELU ? gelu_erf(o[j]) : o[j]);
-            *reinterpret_cast<half8 *>(p.out + e) = hv;
-          }
-        }
-      }
+  for (int i = 0; i < LPW; ++i) {
+    const int f = wave * LPW + i, ks = f / F, idx = f % F;
+    if (idx < TM) {
+      const int64_t tb = tb0 + idx < p.TB ? tb0 + idx : p.TB - 1;
+      src[i] = p.act + (tb * p.KB + ks) * 64 + lane;
+    } else {
+      const int nb = nb0 + idx - TM < p.NB ? nb0 + idx - TM : p.NB - 1;
+      src[i] = p.w + ((int64_t)nb * p.KB + ks) * 64 + lane;
     }
+    dst[i] = (ks * F + idx) * 64;
   }
+  floatx16 acc[2][4];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+  const int nstages = p.KB / S;
+  constexpr int BUF = S * F * 64;  // uint4 per ring slot
+  // three-slot ring, copies issued two stages ahead: one barrier per stage
+#pragma unroll
+  for (int i = 0; i < LPW; ++i) __builtin_amdgcn_global_load_lds(src[i], g_lds + dst[i], 16, 0, 0);
+  if (nstages > 1) {
+#pragma unroll
+    for (int i = 0; i < LPW; ++i) __builtin_amdgcn_global_load_lds(src[i] + (int64_t)S * 64, g_lds + BUF + dst[i], 16, 0, 0);
+  }
+  for (int s = 0; s < nstages; ++s) {
+    if (s + 1 < nstages) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // stage s landed, s+1 may be in flight
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave's copies of stage s are in LDS; every wave is done with stage s-1
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 2 < nstages) {
+      uint4 *slot = g_lds + ((s + 2) % 3) * BUF;  // last read in stage s-1
+#pragma unroll
+      for (int i = 0; i < LPW; ++i)
+        __builtin_amdgcn_global_load_lds(src[i] + (int64_t)(s + 2) * S * 64, slot + dst[i], 16, 0, 0);
+    }
+    const uint4 *L = g_lds + (s % 3) * BUF + lane;
+#pragma unroll
+    for (int ks = 0; ks < S; ++ks) {
+      half8 a[2], b[4];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) a[m] = __builtin_bit_cast(half8, L[(ks * F + 2 * wm + m) * 64]);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) b[n] = __builtin_bit_cast(half8, L[(ks * F + TM + 4 * wn + n) * 64]);
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          if (EPI == EPI_VT) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m], b[n], acc[m][n], 0, 0, 0);
+          else acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[n], a[m], acc[m][n], 0, 0, 0);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const int64_t tb = tb0 + 2 * wm + m;
+      const int nb = nb0 + 4 * wn + n;
+      if (tb < p.TB && nb < p.NB) gemm_store_tile<EPI>(p, acc[m][n], tb, nb, lane);
+    }
 }
 
 // ---- attention: one wave per (sequence, head, 32-query block), online softmax, all in registers --------
@@ -515,9 +605,15 @@ int plain_copy(const float *host, int64_t n, float **dst) {
 
 template <int EPI>
 void launch_gemm(anr_encoder *e, GemmParams &g) {
-  constexpr int MT = 2, NT = 4;
-  const int64_t waves = ceil_div(g.TB, MT) * ceil_div(g.NB, NT);
-  hipLaunchKernelGGL((k_gemm<MT, NT, EPI>), dim3((unsigned)ceil_div(waves, 4)), dim3(256), 0, e->stream, g);
+  static const bool simple = getenv("ANORAG_GEMM_SIMPLE") != nullptr;  // developer switch: the LDS-free kernel
+  if (simple || g.KB % 2) {
+    constexpr int MT = 2, NT = 4;
+    const int64_t waves = ceil_div(g.TB, MT) * ceil_div(g.NB, NT);
+    hipLaunchKernelGGL((k_gemm<MT, NT, EPI>), dim3((unsigned)ceil_div(waves, 4)), dim3(256), 0, e->stream, g);
+    return;
+  }
+  const int64_t blocks = ceil_div(g.TB, 4) * ceil_div(g.NB, 8);
+  hipLaunchKernelGGL((k_gemm_lds<EPI>), dim3((unsigned)blocks), dim3(256), 3 * 2 * 12 * 1024, e->stream, g);
 }
 
 int ensure_ws(anr_encoder *e, int B, int L, int Lp) {

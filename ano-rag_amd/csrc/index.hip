@@ -229,8 +229,7 @@ int launch_scan(anr_index *h, const ScanParams &p, hipStream_t st, int max_grid,
   int64_t grid = ceil_div(p.n_tiles, nwaves);
   if (grid > max_grid) grid = max_grid;
   if (grid_out) *grid_out = (int)grid;
-  static const bool force_ch4 = getenv("ANORAG_SCAN_CH4") != nullptr;  // developer switch
-  if (p.kb % 16 == 0 && !force_ch4) {
+  if (p.kb % 16 == 0) {
     static bool done = false;
     if (!done) {
       ANR_TRY(set_max_lds(k_scan<DENSE, 8, 1024>));
@@ -591,10 +590,6 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
     sp.lcum_in = w.lcum;
     sp.ladder_in = w.ladder;
     sp.kprime = (unsigned)M;
-    {
-      static const char *dbg = getenv("ANORAG_SEL_STOP");
-      sp.debug_stop = dbg ? atoi(dbg) : 0;
-    }
     ANR_TRY(launch_select(nq, sp, s_post));
   }
 

@@ -468,7 +468,6 @@ struct SelParams {
   const unsigned *lcum_in;
   const float *ladder_in;
   unsigned kprime;
-  int debug_stop;        // developer switch: leave the kernel early (timing experiments only)
   const int *qslots;     // optional: block b handles query slot qslots[b]
 };
 
@@ -548,7 +547,6 @@ __global__ __launch_bounds__(1024) void k_select(SelParams p) {
       if (p.ncand) p.ncand[q] = (unsigned)n;
     }
   }
-  if (p.debug_stop == 1) return;
   int M = (int)((int64_t)p.M < n ? (int64_t)p.M : n);
   if (M == 0) {
     if (tid == 0) p.out_m[q] = 0;
@@ -621,12 +619,10 @@ __global__ __launch_bounds__(1024) void k_select(SelParams p) {
   if (staged && !p.dense) {
     n = sh.cnt;  // candidates that survived the pre-filter (>= K' of them unless a list overflowed)
     M = (int)((int64_t)p.M < n ? (int64_t)p.M : n);
-    if (p.debug_stop == 9 && tid == 0 && p.ncand) p.ncand[q] = (unsigned)n;
   }
   int koff = 0;
   if (tid == 0) p.out_m[q] = M;
   if (M == 0) return;
-  if (p.debug_stop == 2) return;
   kmin = sh.red[0][0];
   kmax = sh.red[0][1];
   for (int w = 1; w < NW; ++w) {
@@ -758,7 +754,6 @@ __global__ __launch_bounds__(1024) void k_select(SelParams p) {
   }
   __syncthreads();
   }
-  if (p.debug_stop == 3) return;
   for (int i = tid; i < M; i += NT) {
     const unsigned long long k = sh.srt[i];
     float v = ord2f((unsigned)(k >> 32));
