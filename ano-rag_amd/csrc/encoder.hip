@@ -312,7 +312,10 @@ __global__ __launch_bounds__(256) void k_gemm(GemmParams p) {
 // multiplied (three-slot ring, counted vmcnt + one raw s_barrier per stage, never a full drain in the loop).
 template <int EPI>
 __global__ __launch_bounds__(256) void k_gemm_lds(GemmParams p) {
-  constexpr int TM = 4, TN = 8, S = 2, F = TM + TN, LPW = S * F / 4;  // 6 fragment copies per wave per stage
+#ifndef ANR_GEMM_S
+#define ANR_GEMM_S 4
+#endif
+  constexpr int TM = 4, TN = 8, S = ANR_GEMM_S, F = TM + TN, LPW = S * F / 4;  // fragment copies per wave per stage
   extern __shared__ uint4 g_lds[];  // ring [3][S][F][64]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int NG = (p.NB + TN - 1) / TN;
@@ -350,7 +353,10 @@ __global__ __launch_bounds__(256) void k_gemm_lds(GemmParams p) {
     for (int i = 0; i < LPW; ++i) __builtin_amdgcn_global_load_lds(src[i] + (int64_t)S * 64, g_lds + BUF + dst[i], 16, 0, 0);
   }
   for (int s = 0; s < nstages; ++s) {
-    if (s + 1 < nstages) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // stage s landed, s+1 may be in flight
+    if (s + 1 < nstages) {  // stage s landed, the LPW copies of stage s+1 may stay in flight
+      if (S == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // every wave's copies of stage s are in LDS; every wave is done with stage s-1
     __builtin_amdgcn_sched_barrier(0);
@@ -606,14 +612,20 @@ int plain_copy(const float *host, int64_t n, float **dst) {
 template <int EPI>
 void launch_gemm(anr_encoder *e, GemmParams &g) {
   static const bool simple = getenv("ANORAG_GEMM_SIMPLE") != nullptr;  // developer switch: the LDS-free kernel
-  if (simple || g.KB % 2) {
+  if (simple || g.KB % ANR_GEMM_S) {
     constexpr int MT = 2, NT = 4;
     const int64_t waves = ceil_div(g.TB, MT) * ceil_div(g.NB, NT);
     hipLaunchKernelGGL((k_gemm<MT, NT, EPI>), dim3((unsigned)ceil_div(waves, 4)), dim3(256), 0, e->stream, g);
     return;
   }
   const int64_t blocks = ceil_div(g.TB, 4) * ceil_div(g.NB, 8);
-  hipLaunchKernelGGL((k_gemm_lds<EPI>), dim3((unsigned)blocks), dim3(256), 3 * 2 * 12 * 1024, e->stream, g);
+  constexpr int lds_bytes = 3 * ANR_GEMM_S * 12 * 1024;
+  static bool attr = false;
+  if (!attr && lds_bytes > 64 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_lds<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    attr = true;
+  }
+  hipLaunchKernelGGL((k_gemm_lds<EPI>), dim3((unsigned)blocks), dim3(256), lds_bytes, e->stream, g);
 }
 
 int ensure_ws(anr_encoder *e, int B, int L, int Lp) {
