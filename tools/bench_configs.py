@@ -12,25 +12,6 @@ from oracle import flat_index as orc
 out = {}
 dev = torch.device("cuda", 0)
 
-# ---- C1: 10k x 384, batch-1 top-10, host buffers (what VectorIndex.search does) -------------------------
-x = np.random.default_rng(1234).standard_normal((10_000, 384), dtype=np.float32)
-q = np.random.default_rng(4321).standard_normal((200, 384), dtype=np.float32)
-idx = FlatIndex(384, METRIC_IP, normalize=True); idx.add(x)
-for i in range(5): idx.search(q[i:i + 1], 10)
-t0 = time.perf_counter()
-for i in range(200): D, I = idx.search(q[i:i + 1], 10)
-gpu_us = (time.perf_counter() - t0) / 200 * 1e6
-xn = orc.preprocess_vectors(x)
-t0 = time.perf_counter()
-for i in range(200):
-    qn = orc.preprocess_vectors(q[i:i + 1]); s = qn @ xn.T
-    part = np.argpartition(-s, 9, axis=1)[:, :10]; o = np.argsort(-np.take_along_axis(s, part, 1), axis=1)
-cpu_us = (time.perf_counter() - t0) / 200 * 1e6
-Dr, Ir = orc.flat_search(orc.preprocess_vectors(q[199:200]), xn, 10, "ip")
-out["C1"] = {"config": "10k x 384, batch-1 top-10 (host in/out, synchronous)", "gpu_us_per_query": gpu_us,
-             "cpu_oracle_us_per_query": cpu_us, "ids_match_oracle": bool(np.array_equal(I, Ir))}
-idx.close()
-
 # ---- C2: 1M x 768, batch-64 top-100 ----------------------------------------------------------------------
 def build(rows, dim):
     ix = FlatIndex(dim, METRIC_IP, normalize=True); ix.reserve(rows)
@@ -41,7 +22,7 @@ def build(rows, dim):
         xb = torch.randn((m, dim), generator=g, device=dev); torch.cuda.synchronize()
         ix.add_device(xb.data_ptr(), m); done += m
     return ix
-idx = build(1_000_000, 768)
+idx = build(1_000_000, 768)  # measured first: BLAS worker threads spinning after numpy work slow the launch loop
 g = torch.Generator(device=dev); g.manual_seed(4321)
 Q = torch.randn((43, 64, 768), generator=g, device=dev)
 NS = 3
@@ -90,6 +71,25 @@ out["C4"] = {"config": "bge-base-en shape (12L, H768, 12 heads, I3072, vocab 305
              "search_ms_256_queries": t_search * 1e3, "end_to_end_qps": 256 / (t_enc + t_search),
              "min_cosine_vs_f32_oracle_16": cos}
 enc.close(); idx.close()
+
+# ---- C1: 10k x 384, batch-1 top-10, host buffers (what VectorIndex.search does) -------------------------
+x = np.random.default_rng(1234).standard_normal((10_000, 384), dtype=np.float32)
+q = np.random.default_rng(4321).standard_normal((200, 384), dtype=np.float32)
+idx1 = FlatIndex(384, METRIC_IP, normalize=True); idx1.add(x)
+for i in range(5): idx1.search(q[i:i + 1], 10)
+t0 = time.perf_counter()
+for i in range(200): D, I = idx1.search(q[i:i + 1], 10)
+gpu_us = (time.perf_counter() - t0) / 200 * 1e6
+xn = orc.preprocess_vectors(x)
+t0 = time.perf_counter()
+for i in range(200):
+    qn = orc.preprocess_vectors(q[i:i + 1]); s = qn @ xn.T
+    part = np.argpartition(-s, 9, axis=1)[:, :10]; o = np.argsort(-np.take_along_axis(s, part, 1), axis=1)
+cpu_us = (time.perf_counter() - t0) / 200 * 1e6
+Dr, Ir = orc.flat_search(orc.preprocess_vectors(q[199:200]), xn, 10, "ip")
+out["C1"] = {"config": "10k x 384, batch-1 top-10 (host in/out, synchronous)", "gpu_us_per_query": gpu_us,
+             "cpu_oracle_us_per_query": cpu_us, "ids_match_oracle": bool(np.array_equal(I, Ir))}
+idx1.close()
 
 # ---- C5: dense + BM25 fusion, 200 queries, pool 80 ---------------------------------------------------------
 from retrieval.hybrid_search import HybridSearcher
