@@ -11,6 +11,7 @@
 // asynchronously).  Queries whose certificate fails are answered by the dense exact path
 // (k_exact_dense + select) when the batch is retired.
 #include <algorithm>
+#include <cmath>
 #include <mutex>
 #include <vector>
 
@@ -31,7 +32,6 @@ struct Workspace {
   float *dense = nullptr;
   int64_t dense_ld = 0;
   float *ladder = nullptr;
-  unsigned *lcum = nullptr;   // [64][kLadder][kCumStride]
   unsigned *cntb = nullptr;   // [64][n_cu]
   unsigned *ncand = nullptr;  // status block: [64] candidates | [64] overflow | [64] flags | [64] theta (float)
   int *qslots = nullptr;      // [64] query slots of a second pass
@@ -156,7 +156,6 @@ int ensure_workspaces(anr_index *h) {
     ANR_TRY(dev_alloc(&w.qstat, kQB * 4, true));
     ANR_TRY(dev_alloc(&w.qstage, (int64_t)kQB * h->dim, true));
     ANR_TRY(dev_alloc(&w.ladder, kQB * kLadder, true));
-    ANR_TRY(dev_alloc(&w.lcum, (int64_t)kQB * kLadder * kCumStride, true));
     ANR_TRY(dev_alloc(&w.cntb, (int64_t)kQB * h->n_cu, true));
     ANR_TRY(dev_alloc(&w.ncand, 4 * kQB, true));
     ANR_TRY(dev_alloc(&w.qslots, kQB, true));
@@ -222,9 +221,12 @@ template <bool DENSE>
 int launch_scan(anr_index *h, const ScanParams &p, hipStream_t st, int max_grid, int *grid_out = nullptr) {
   if (p.n_tiles <= 0) return ANR_OK;
   const size_t lds = (size_t)2 * p.kb * 64 * 16 + kQB * kLadder * 8 + kQB * 8;
-  // 16 waves per block when there is enough work for every CU, else smaller blocks on more CUs
-  int nwaves = 16;
-  while (nwaves > 4 && ceil_div(p.n_tiles, nwaves) < max_grid) nwaves >>= 1;
+  // 12 waves per block (3 per SIMD: 168 VGPRs each, room for two 8-KiB operand buffers without spills;
+  // measured faster than 16 waves at 128 VGPRs) when there is enough work for every CU, else smaller
+  // blocks on more CUs
+  int nwaves = 12;
+  if (ceil_div(p.n_tiles, nwaves) < max_grid) nwaves = 8;
+  if (ceil_div(p.n_tiles, nwaves) < max_grid) nwaves = 4;
   const int nt = nwaves * 64;
   int64_t grid = ceil_div(p.n_tiles, nwaves);
   if (grid > max_grid) grid = max_grid;
@@ -232,17 +234,17 @@ int launch_scan(anr_index *h, const ScanParams &p, hipStream_t st, int max_grid,
   if (p.kb % 16 == 0) {
     static bool done = false;
     if (!done) {
-      ANR_TRY(set_max_lds(k_scan<DENSE, 8, 1024>));
+      ANR_TRY(set_max_lds(k_scan<DENSE, 8, 768>));
       done = true;
     }
-    hipLaunchKernelGGL((k_scan<DENSE, 8, 1024>), dim3((unsigned)grid), dim3(nt), lds, st, p);
+    hipLaunchKernelGGL((k_scan<DENSE, 8, 768>), dim3((unsigned)grid), dim3(nt), lds, st, p);
   } else {
     static bool done = false;
     if (!done) {
-      ANR_TRY(set_max_lds(k_scan<DENSE, 4, 1024>));
+      ANR_TRY(set_max_lds(k_scan<DENSE, 4, 768>));
       done = true;
     }
-    hipLaunchKernelGGL((k_scan<DENSE, 4, 1024>), dim3((unsigned)grid), dim3(nt), lds, st, p);
+    hipLaunchKernelGGL((k_scan<DENSE, 4, 768>), dim3((unsigned)grid), dim3(nt), lds, st, p);
   }
   ANR_HIP(hipGetLastError());
   return ANR_OK;
@@ -338,7 +340,6 @@ int run_second_pass(anr_index *h, Workspace &w, const std::vector<int> &slots, s
   ANR_TRY(ensure_cand(h, w));
   ANR_HIP(hipMemcpyAsync(w.ladder, lad.data(), lad.size() * sizeof(float), hipMemcpyHostToDevice, st));
   ANR_HIP(hipMemcpyAsync(w.qslots, run.data(), run.size() * sizeof(int), hipMemcpyHostToDevice, st));
-  ANR_HIP(hipMemsetAsync(w.lcum, 0, (size_t)kQB * kLadder * kCumStride * sizeof(unsigned), st));
   ScanParams sc{};
   sc.x16 = reinterpret_cast<const uint4 *>(h->x16);
   sc.q16 = reinterpret_cast<const uint4 *>(w.q16);
@@ -349,7 +350,7 @@ int run_second_pass(anr_index *h, Workspace &w, const std::vector<int> &slots, s
   sc.tile_stride = 1;
   sc.n_tiles = ceil_div(h->ntotal, kTileRows);
   sc.ladder = w.ladder;
-  sc.lcum = w.lcum;
+  sc.lvl0 = 0;
   sc.cntb = w.cntb;
   sc.cand = w.cand;
   sc.capb = (unsigned)h->cand_cap;
@@ -487,7 +488,11 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
   const int64_t n_tiles = ceil_div(h->ntotal, kTileRows);
   const int64_t full_tiles = h->ntotal / kTileRows;
   // threshold sample: ~1/64 of the rows, between 4K and 16K (more rows -> tighter first threshold)
-  const int64_t auto_sample = round_up(std::min<int64_t>(16384, std::max<int64_t>(4096, h->ntotal / 64)), 1024);
+  // sample size: the sample pass costs ~S rows of streaming, the candidates it lets through cost
+  // ~64 * 12 * N / S list appends (about as much per append as per streamed row); the sum is least near
+  // S = 27 sqrt(N)
+  const int64_t auto_sample = round_up(
+      std::min<int64_t>(262144, std::max<int64_t>(4096, (int64_t)(27.0 * std::sqrt((double)h->ntotal)))), 1024);
   int64_t sample_tiles = (h->sample_rows > 0 ? h->sample_rows : auto_sample) / kTileRows;
   if (sample_tiles < 2 * M) sample_tiles = 2 * M;  // tile maxima: the M-th largest is backed by M distinct rows
   const bool sparse = full_tiles >= 8 * sample_tiles;
@@ -554,7 +559,6 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
     ss.row0 = 0;
     ss.row_tile_stride = 1;
     ss.ladder = w.ladder;
-    ss.lcum_zero = w.lcum;
     ANR_TRY(launch_select(kQB, ss, s_pre));
     // scan
     if (pipelined) {
@@ -566,7 +570,15 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
     sc.n_tiles = n_tiles;
     sc.dense = nullptr;
     sc.ladder = w.ladder;
-    sc.lcum = w.lcum;
+    {
+      // start level: the highest one whose sample rank still predicts >= 4 K' corpus rows above it
+      const int64_t ratio = full_tiles / sample_tiles;
+      const int64_t need = std::max<int64_t>(12, ceil_div((int64_t)4 * M, ratio));
+      int lvl0 = 0;
+      for (int j = 1; j < kLadder - 1; ++j)
+        if ((M >> j) >= need) lvl0 = j;
+      sc.lvl0 = lvl0;
+    }
     sc.cntb = w.cntb;
     sc.cand = w.cand;
     sc.capb = (unsigned)h->cand_cap;
@@ -587,9 +599,6 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
     sp.capb = (unsigned)h->cand_cap;
     sp.overflow = w.ncand + kQB;
     sp.ncand = w.ncand;
-    sp.lcum_in = w.lcum;
-    sp.ladder_in = w.ladder;
-    sp.kprime = (unsigned)M;
     ANR_TRY(launch_select(nq, sp, s_post));
   }
 
@@ -746,7 +755,7 @@ int add_impl(anr_index *h, const float *x_dev, int64_t n, hipStream_t st) {
 void free_workspaces(anr_index *h) {
   for (auto &w : h->ws) {
     dev_free(w.q32); dev_free(w.q16); dev_free(w.qstat); dev_free(w.qstage); dev_free(w.dense);
-    dev_free(w.ladder); dev_free(w.lcum); dev_free(w.cntb); dev_free(w.ncand); dev_free(w.cand); dev_free(w.qslots);
+    dev_free(w.ladder); dev_free(w.cntb); dev_free(w.ncand); dev_free(w.cand); dev_free(w.qslots);
     dev_free(w.sel_rank); dev_free(w.sel_row); dev_free(w.sel_m); dev_free(w.exact); dev_free(w.flags);
     if (w.flags_host) (void)hipHostFree(w.flags_host);
     if (w.cnt_host) (void)hipHostFree(w.cnt_host);

@@ -218,14 +218,17 @@ __global__ __launch_bounds__(256) void k_prepq(PrepQParams p) {
 // KB x 2 MFMAs (32 rows x 64 queries), then either writes the score tile densely (DENSE) or appends
 // the scores that pass the per-query running threshold to this block's per-query candidate list.
 //
-// Running threshold ("ladder"): the sample phase leaves, per query, kLadder ascending values
-// lad[0..L-1] = the sample's scores of rank K', K'/2, K'/4, ... 1.  lcum[q][j] counts the rows emitted
-// so far (by any block) whose score is >= lad[j].  Every row is scored exactly once, so once
-// lcum[q][j] >= K' there are K' distinct rows at or above lad[j] and lad[j] is a valid threshold:
-// nothing below it can be among the K' best.  Stale or under-counted counters only delay tightening.
+// Threshold ("ladder"): the sample phase leaves, per query, kLadder ascending values
+// lad[0..L-1] = the sample's tile maxima of rank K', K'/2, K'/4, ... 1.  Every block starts at level
+// lvl0, chosen on the host so that the sample predicts >= 4 K' rows at or above it in the whole corpus
+// (and the level is backed by >= 12 sample tiles, so the prediction is not noise).  The threshold is a
+// guess, not a bound: the select kernel counts what was emitted, and a query whose lists hold fewer than
+// K' rows fails its certificate and takes the second pass.  While scanning, a block that has itself seen
+// K' rows at or above a higher level moves up to it (valid: those K' rows exist) — this bounds the list
+// growth on clustered corpora without any global traffic.  (An earlier version kept global per-level
+// counters updated with device-scope atomics; those cost ~60 us per 1.25 M-row scan and the levels lagged
+// a tile round behind, so it emitted 4x more candidates than the static start does.)
 // ------------------------------------------------------------------------------------------------
-constexpr int kCumStride = 64;  // uints: one 256-B line per counter (spreads the hot words over channels)
-
 struct ScanParams {
   const uint4 *x16;
   const uint4 *q16;
@@ -239,7 +242,7 @@ struct ScanParams {
   int groupmax;      // DENSE: write only the maximum of each 32-row tile: dense[q][i]
   // sparse
   const float *ladder;   // [64][kLadder] ascending thresholds from the sample
-  unsigned *lcum;        // [64][kLadder][kCumStride] emitted rows with score >= ladder level
+  int lvl0;              // ladder level every block starts at
   unsigned *cntb;        // [64][gridDim.x] list lengths, written when a block retires
   uint2 *cand;           // [gridDim.x][64][capb] (rank-score bits, row)
   unsigned capb;
@@ -267,46 +270,63 @@ __device__ __forceinline__ void scan_mfma(const uint4 (&a)[CH], const uint4 *lds
   }
 }
 
+// same, and re-fills each operand register from `next` as soon as its two MFMAs have issued
+template <int CH>
+__device__ __forceinline__ void scan_mfma_refill(uint4 (&a)[CH], const uint4 *next, const uint4 *ldsq0,
+                                                 const uint4 *ldsq1, int kbase, floatx16 &acc0, floatx16 &acc1) {
+#pragma unroll
+  for (int j = 0; j < CH; ++j) {
+    const uint4 b0 = ldsq0[(kbase + j) * 64];
+    const uint4 b1 = ldsq1[(kbase + j) * 64];
+    const half8 av = __builtin_bit_cast(half8, a[j]);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(half8, b0), acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(half8, b1), acc1, 0, 0, 0);
+    a[j] = ld16(next + (int64_t)j * 64);
+  }
+}
+
 __device__ __forceinline__ unsigned ld_relaxed(const unsigned *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // append this lane's hits of one 32x32 accumulator block (all for query q) to the block's list and
-// count them against the next three ladder levels in the block's pending counters (LDS)
+// count them against the next three ladder levels in the block's pending counters (LDS).
+// Hits are rare (a handful per tile), so the lane first builds a 16-bit hit mask without branches and
+// then the wave loops max-hits-per-lane times (usually once), each lane peeling its lowest hit.
 __device__ __forceinline__ void scan_emit(const floatx16 &acc, float tau, int lvl, int q, int64_t row_base,
-                                          int64_t n_rows, const float *lad, unsigned *lds_cnt,
+                                          unsigned valid, const float *lad, unsigned *lds_cnt,
                                           unsigned *lds_pend, const ScanParams &p) {
-  unsigned n = 0;
+  unsigned m = 0;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int64_t row = row_base + (r & 3) + 8 * (r >> 2);
-    n += (row < n_rows && acc[r] >= tau) ? 1u : 0u;
-  }
-  if (n) {
-    unsigned k = atomicAdd(lds_cnt + q, n);  // LDS: slot reservation inside the block
-    const int ja = lvl + 1 < kLadder ? lvl + 1 : kLadder - 1;
-    const int jb = lvl + 2 < kLadder ? lvl + 2 : kLadder - 1;
-    const int jc = lvl + 3 < kLadder ? lvl + 3 : kLadder - 1;
-    const float la = lad[q * kLadder + ja], lb = lad[q * kLadder + jb], lc = lad[q * kLadder + jc];
-    unsigned ca = 0, cb = 0, cc = 0;
-    uint2 *list = p.cand + ((int64_t)blockIdx.x * kQB + q) * p.capb;
+  for (int r = 0; r < 16; ++r) m |= (acc[r] >= tau) ? (1u << r) : 0u;
+  m &= valid;
+  if (!__any(m != 0)) return;
+  unsigned k = 0;
+  if (m) k = atomicAdd(lds_cnt + q, (unsigned)__popc(m));  // LDS: slot reservation inside the block
+  const int ja = lvl + 1 < kLadder ? lvl + 1 : kLadder - 1;
+  const int jb = lvl + 2 < kLadder ? lvl + 2 : kLadder - 1;
+  const int jc = lvl + 3 < kLadder ? lvl + 3 : kLadder - 1;
+  const float la = lad[q * kLadder + ja], lb = lad[q * kLadder + jb], lc = lad[q * kLadder + jc];
+  unsigned ca = 0, cb = 0, cc = 0;
+  uint2 *list = p.cand + ((int64_t)blockIdx.x * kQB + q) * p.capb;
+  while (__any(m != 0)) {
+    const int r = __ffs(m) - 1;  // -1 on idle lanes
+    float s = acc[0];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int64_t row = row_base + (r & 3) + 8 * (r >> 2);
-      const float s = acc[r];
-      if (row < n_rows && s >= tau) {
-        if (k < p.capb) list[k] = make_uint2(__float_as_uint(s), (unsigned)row);
-        ++k;
-        ca += (s >= la) ? 1u : 0u;
-        cb += (s >= lb) ? 1u : 0u;
-        cc += (s >= lc) ? 1u : 0u;
-      }
+    for (int t = 1; t < 16; ++t) s = (r == t) ? acc[t] : s;
+    if (m) {
+      if (k < p.capb) list[k] = make_uint2(__float_as_uint(s), (unsigned)(row_base + (r & 3) + 8 * (r >> 2)));
+      ++k;
+      ca += (s >= la) ? 1u : 0u;
+      cb += (s >= lb) ? 1u : 0u;
+      cc += (s >= lc) ? 1u : 0u;
     }
-    // levels further than three above the current one are under-counted (safe, see header comment)
-    if (lvl + 1 < kLadder && ca) atomicAdd(lds_pend + q * kLadder + lvl + 1, ca);
-    if (lvl + 2 < kLadder && cb) atomicAdd(lds_pend + q * kLadder + lvl + 2, cb);
-    if (lvl + 3 < kLadder && cc) atomicAdd(lds_pend + q * kLadder + lvl + 3, cc);
+    m &= m - 1;
   }
+  // levels further than three above the current one are under-counted (safe, see header comment)
+  if (lvl + 1 < kLadder && ca) atomicAdd(lds_pend + q * kLadder + lvl + 1, ca);
+  if (lvl + 2 < kLadder && cb) atomicAdd(lds_pend + q * kLadder + lvl + 2, cb);
+  if (lvl + 3 < kLadder && cc) atomicAdd(lds_pend + q * kLadder + lvl + 3, cc);
 }
 
 template <bool DENSE, int CH, int NT>
@@ -328,7 +348,7 @@ __global__ __launch_bounds__(NT) void k_scan(ScanParams p) {
     }
     if (tid < kQB) {
       lds_cnt[tid] = 0;
-      lds_lvl[tid] = 0;
+      lds_lvl[tid] = p.lvl0;
     }
   }
   __syncthreads();
@@ -339,23 +359,29 @@ __global__ __launch_bounds__(NT) void k_scan(ScanParams p) {
   const int64_t wglobal = (int64_t)blockIdx.x * nwaves + wave;
   const int64_t wtotal = (int64_t)gridDim.x * nwaves;
   const int nch = p.kb / CH;  // even by construction (kb % (2*CH) == 0)
-  const int per_wave = kQB / nwaves;  // queries whose counters this wave publishes
 
+  // the first chunk of a wave's next tile is requested before the current tile's epilogue, so the wave
+  // always has loads in flight (the epilogue would otherwise be a bubble in its share of the stream)
+  uint4 aA[CH], aB[CH];
+  if (wglobal < p.n_tiles) scan_load<CH>(aA, p.x16 + (p.tile0 + wglobal * p.tile_stride) * p.kb * 64 + lane, 0);
   for (int64_t i = wglobal; i < p.n_tiles; i += wtotal) {
     const int64_t tile = p.tile0 + i * p.tile_stride;
     const uint4 *xa = p.x16 + tile * p.kb * 64 + lane;
+    // no next tile: re-request this tile's last chunk instead (an L2 hit), which keeps the loop free of
+    // conditional loads so the compiler can count the outstanding loads exactly
+    const uint4 *xn = (i + wtotal < p.n_tiles) ? xa + wtotal * p.tile_stride * p.kb * 64
+                                               : xa + (int64_t)(p.kb - CH) * 64;
     floatx16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       acc0[r] = 0.0f;
       acc1[r] = 0.0f;
     }
-    uint4 aA[CH], aB[CH];
-    scan_load<CH>(aA, xa, 0);
     for (int c = 0; c < nch; c += 2) {
       scan_load<CH>(aB, xa, (c + 1) * CH);
-      scan_mfma<CH>(aA, ldsq0, ldsq1, c * CH, acc0, acc1);
-      if (c + 2 < nch) scan_load<CH>(aA, xa, (c + 2) * CH);
+      __builtin_amdgcn_sched_barrier(0);
+      scan_mfma_refill<CH>(aA, (c + 2 < nch) ? xa + (int64_t)(c + 2) * CH * 64 : xn, ldsq0, ldsq1, c * CH, acc0, acc1);
+      __builtin_amdgcn_sched_barrier(0);
       scan_mfma<CH>(aB, ldsq0, ldsq1, (c + 1) * CH, acc0, acc1);
     }
 
@@ -407,24 +433,18 @@ __global__ __launch_bounds__(NT) void k_scan(ScanParams p) {
       const int lv0 = __hip_atomic_load(lds_lvl + q0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       const int lv1 = __hip_atomic_load(lds_lvl + q0 + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       const float tau0 = lad[q0 * kLadder + lv0], tau1 = lad[(q0 + 32) * kLadder + lv1];
-      float m0 = acc0[0], m1 = acc1[0];
+      unsigned valid = 0xffffu;
+      if ((tile + 1) * kTileRows > p.n_rows) {  // the ragged last tile
+        valid = 0;
 #pragma unroll
-      for (int r = 1; r < 16; ++r) {
-        m0 = fmaxf(m0, acc0[r]);
-        m1 = fmaxf(m1, acc1[r]);
+        for (int r = 0; r < 16; ++r) valid |= (row_base + (r & 3) + 8 * (r >> 2) < p.n_rows) ? (1u << r) : 0u;
       }
-      if (__any((m0 >= tau0) || (m1 >= tau1))) {
-        scan_emit(acc0, tau0, lv0, q0, row_base, p.n_rows, lad, lds_cnt, lds_pend, p);
-        scan_emit(acc1, tau1, lv1, q0 + 32, row_base, p.n_rows, lad, lds_cnt, lds_pend, p);
-      }
-      // publish this wave's share of the pending level counts and pick up the global totals
-      for (int e = lane; e < per_wave * kLadder; e += 64) {
-        const int q = wave * per_wave + (e >> 3), j = e & (kLadder - 1);
-        if (j == 0 || j <= __hip_atomic_load(lds_lvl + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) continue;
-        const unsigned v = atomicExch(lds_pend + q * kLadder + j, 0u);
-        unsigned *gc = p.lcum + (int64_t)(q * kLadder + j) * kCumStride;
-        const unsigned g = v ? atomicAdd(gc, v) + v : ld_relaxed(gc);
-        if (g >= p.kprime) atomicMax(lds_lvl + q, j);
+      scan_emit(acc0, tau0, lv0, q0, row_base, valid, lad, lds_cnt, lds_pend, p);
+      scan_emit(acc1, tau1, lv1, q0 + 32, row_base, valid, lad, lds_cnt, lds_pend, p);
+      // a level at which this block alone has seen K' rows is a valid threshold: raise to it
+      for (int e = tid; e < kQB * kLadder; e += nthreads) {
+        const int q = e >> 3, j = e & (kLadder - 1);
+        if (lds_pend[q * kLadder + j] >= p.kprime) atomicMax(lds_lvl + q, j);
       }
     }
   }
@@ -462,12 +482,6 @@ struct SelParams {
   float *ladder;         // optional [64][kLadder]
   unsigned *overflow;    // optional [64]: set when a list overflowed
   unsigned *ncand;       // optional [64]: candidates seen
-  unsigned *lcum_zero;   // optional: ladder mode also clears this query's level counters
-  // list input, optional pre-filter: the highest ladder level reached by >= kprime emitted rows bounds the
-  // K'-th best from below, so only candidates at or above it need to be ranked
-  const unsigned *lcum_in;
-  const float *ladder_in;
-  unsigned kprime;
   const int *qslots;     // optional: block b handles query slot qslots[b]
 };
 
@@ -568,19 +582,6 @@ __global__ __launch_bounds__(1024) void k_select(SelParams p) {
         kmax = k > kmax ? k : kmax;
       }
     } else {
-      // pre-filter threshold: highest ladder level reached by >= kprime emitted rows (levels read in parallel)
-      if (tid < kLadder) {
-        bool ok = false;
-        if (p.lcum_in && tid >= 1) ok = p.lcum_in[(int64_t)(q * kLadder + tid) * kCumStride] >= p.kprime;
-        sh.hist[tid] = ok ? 1u : 0u;
-      }
-      __syncthreads();
-      float thr = -__builtin_inff();
-      for (int j = kLadder - 1; j >= 1; --j)
-        if (sh.hist[j]) {
-          thr = p.ladder_in[q * kLadder + j];
-          break;
-        }
       // one thread per candidate over the flattened lists, so every list read is in flight at once
       for (int64_t i = tid; i < n; i += NT) {
         int lo = 0, hi = p.G;  // offs[lo] <= i < offs[hi]
@@ -590,13 +591,10 @@ __global__ __launch_bounds__(1024) void k_select(SelParams p) {
           else hi = mid;
         }
         const uint2 e = p.cand[((int64_t)lo * kQB + q) * p.capb + ((unsigned)i - sh.offs[lo])];
-        const float sc = __uint_as_float(e.x);
-        if (sc >= thr) {
-          const unsigned long long k = make_key(sc, e.y);
-          sh.keys[atomicAdd(&sh.cnt, 1u)] = k;  // order is irrelevant: the keys are ranked afterwards
-          kmin = k < kmin ? k : kmin;
-          kmax = k > kmax ? k : kmax;
-        }
+        const unsigned long long k = make_key(__uint_as_float(e.x), e.y);
+        sh.keys[i] = k;
+        kmin = k < kmin ? k : kmin;
+        kmax = k > kmax ? k : kmax;
       }
     }
   } else {
@@ -616,10 +614,6 @@ __global__ __launch_bounds__(1024) void k_select(SelParams p) {
     sh.red[wave][1] = kmax;
   }
   __syncthreads();
-  if (staged && !p.dense) {
-    n = sh.cnt;  // candidates that survived the pre-filter (>= K' of them unless a list overflowed)
-    M = (int)((int64_t)p.M < n ? (int64_t)p.M : n);
-  }
   int koff = 0;
   if (tid == 0) p.out_m[q] = M;
   if (M == 0) return;
@@ -760,7 +754,6 @@ __global__ __launch_bounds__(1024) void k_select(SelParams p) {
     p.out_rank[q * kMaxSel + i] = p.negate ? -v : v;
     p.out_row[q * kMaxSel + i] = 0xffffffffu - (unsigned)(k & 0xffffffffu);
   }
-  if (p.lcum_zero && tid < kLadder) p.lcum_zero[(int64_t)(q * kLadder + tid) * kCumStride] = 0u;
   if (p.ladder && tid < kLadder) {
     // level j = value of rank max(1, M >> j) (1-based) of the sample: ascending in j
     int rk = M >> tid;
