@@ -23,7 +23,7 @@ OPT_SAMPLE_ROWS = 3
 OPT_CAND_CAP = 4
 OPT_TIMING = 5
 OPT_ADD_RAW = 6
-OPT_RESERVE_CUS = 7
+OPT_STREAMS = 7
 
 
 class AnoragError(RuntimeError):

@@ -2,14 +2,15 @@
 // index_kernels.hpp.  Replaces faiss.IndexFlatIP / IndexFlatL2 at the call sites of the reference's
 // vector_store/vector_index.py (:77-80 create, :196 add, :223 search, :415-426 reset).
 //
-// Search pipeline for one batch of <= 64 queries, three stages on three streams:
+// Search pipeline for one batch of <= 64 queries, all on one stream:
 //   pre  : prepq -> scan<DENSE> on a strided tile sample -> select -> threshold ladder
 //   scan : the f16 MFMA scan (threshold-gated candidate append) — the only HBM-heavy kernel
-//   post : select top-K' -> rescore (f32 rows, f64 accumulate) -> finalize (sort, top-k, certificate)
-// Batches rotate over kWorkspaces workspaces, so the pre/post stages of neighbouring batches run beside
-// the scan of the current one (the scan leaves `reserve_cus` CUs free for them when searches are issued
-// asynchronously).  Queries whose certificate fails are answered by the dense exact path
-// (k_exact_dense + select) when the batch is retired.
+//   post : select top-K' -> rescore (f32 rows, f64 accumulate) -> finalize (sort, top-k, certificate, status)
+// Batches rotate over kWorkspaces workspaces, each with its own stream, and nothing orders one batch
+// against the next: the small kernels of neighbouring batches fill the ramp and the tail of the current
+// scan, and the completion marker of one batch does not sit in front of the next one's first kernel
+// (measured at a 1.25 M-row shard: 0.417 -> 0.376 ms per batch).  Queries whose certificate fails are
+// answered by the second pass / the dense exact path when the batch is retired.
 #include <algorithm>
 #include <cmath>
 #include <mutex>
@@ -43,8 +44,9 @@ struct Workspace {
   float *exact = nullptr;
   int *flags = nullptr;
   int *flags_host = nullptr;       // pinned [64]
-  unsigned *cnt_host = nullptr;    // pinned [128]
-  hipEvent_t ev_in = nullptr, ev_pre = nullptr, ev_scan = nullptr, ev_done = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+  unsigned *cnt_host = nullptr;    // pinned [4][64] batch status, written by k_finalize
+  unsigned *cnt_dev = nullptr;     // the same memory as the device addresses it
+  hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
   // the batch in flight
   bool in_flight = false;
   bool sparse = false, timed = false, exact_all = false;
@@ -65,7 +67,7 @@ struct anr_index {
   float *rowbias = nullptr;
   unsigned *xstat = nullptr;  // [4]
   hipStream_t stream = nullptr;                        // adds, exact path, copies
-  hipStream_t s_pre = nullptr, s_scan = nullptr, s_post = nullptr;
+  hipStream_t bstream[kWorkspaces] = {nullptr, nullptr, nullptr};  // one per in-flight batch
   std::mutex mu;
 
   // options
@@ -75,9 +77,7 @@ struct anr_index {
   int64_t cand_cap = 512;   // entries per (block, query) candidate list
   int timing = 0;
   int add_raw = 0;          // adds store the rows as given (already preprocessed, e.g. a reloaded index)
-  int reserve_cus = 0;      // > 0: asynchronous searches run their pre/post stages on separate streams and the
-                            // scan leaves this many CUs free for them (measured: no gain on MI355X, the scan
-                            // saturates HBM and starves the small kernels — kept as an experiment switch)
+  int n_streams = kWorkspaces;  // streams the batches rotate over (1 = strictly one batch after the other)
 
   Workspace ws[kWorkspaces];
   bool ws_ready = false;
@@ -166,12 +166,12 @@ int ensure_workspaces(anr_index *h) {
     ANR_TRY(dev_alloc(&w.flags, kQB, true));
     ANR_HIP(hipHostMalloc(reinterpret_cast<void **>(&w.flags_host), kQB * sizeof(int), hipHostMallocDefault));
     ANR_HIP(hipHostMalloc(reinterpret_cast<void **>(&w.cnt_host), 4 * kQB * sizeof(unsigned), hipHostMallocDefault));
+    ANR_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&w.cnt_dev), w.cnt_host, 0));
     ANR_HIP(hipEventCreateWithFlags(&w.ev_in, hipEventDisableTiming));
-    ANR_HIP(hipEventCreateWithFlags(&w.ev_pre, hipEventDisableTiming));
-    ANR_HIP(hipEventCreateWithFlags(&w.ev_scan, hipEventDisableTiming));
-    ANR_HIP(hipEventCreateWithFlags(&w.ev_done, hipEventDisableTiming));
-    ANR_HIP(hipEventCreate(&w.ev_t0));
-    ANR_HIP(hipEventCreate(&w.ev_t1));
+    // the batch status lands in pinned memory with its own system-scope fence: no cache write-back needed here
+    ANR_HIP(hipEventCreateWithFlags(&w.ev_done, hipEventDisableTiming | hipEventDisableSystemFence));
+    ANR_HIP(hipEventCreateWithFlags(&w.ev_t0, hipEventDisableSystemFence));  // timing only
+    ANR_HIP(hipEventCreateWithFlags(&w.ev_t1, hipEventDisableSystemFence));
   }
   for (auto &e : h->ev_call) ANR_HIP(hipEventCreate(&e));
   h->ws_ready = true;
@@ -440,8 +440,9 @@ int drain(anr_index *h) {
 
 // enqueue one batch of nq <= 64 device-resident queries; returns without waiting
 int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_off, float *D_dev, int64_t *I_dev,
-                  hipStream_t user, bool pipelined) {  // NOLINT
-  Workspace &w = h->ws[h->next_ws];
+                  hipStream_t user) {
+  const int ws_index = h->next_ws;
+  Workspace &w = h->ws[ws_index];
   h->next_ws = (h->next_ws + 1) % kWorkspaces;
   ANR_TRY(retire(h, w));  // back-pressure: the workspace's previous batch must be complete
   w.in_flight = true;
@@ -456,14 +457,15 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
   w.sample_rows = 0;
   w.exact_all = h->force_exact != 0 || h->f16_unusable;
 
-  // pipelined: three stages on three streams; otherwise everything on the scan stream
-  if (h->reserve_cus <= 0) pipelined = false;  // one stream, full grid: batches still queue without host syncs
-  hipStream_t s_pre = pipelined ? h->s_pre : h->s_scan;
-  hipStream_t s_scan = h->s_scan;
-  hipStream_t s_post = pipelined ? h->s_post : h->s_scan;
+  hipStream_t bs = h->bstream[ws_index % h->n_streams];
   // the queries are ready once everything already enqueued on the caller's stream has run
-  ANR_HIP(hipEventRecord(w.ev_in, user));
-  ANR_HIP(hipStreamWaitEvent(s_pre, w.ev_in, 0));
+  // (an idle caller stream has nothing to wait for: skip the cross-queue dependency, which costs the
+  // command processor several microseconds per batch)
+  if (user != bs && hipStreamQuery(user) != hipSuccess) {
+    ANR_HIP(hipEventRecord(w.ev_in, user));
+    ANR_HIP(hipStreamWaitEvent(bs, w.ev_in, 0));
+  }
+  (void)hipGetLastError();  // hipStreamQuery reports hipErrorNotReady through the sticky error too
 
   PrepQParams qp{};
   qp.qin = q_dev;
@@ -475,10 +477,10 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
   qp.q32 = w.q32;
   qp.q16 = w.q16;
   qp.qstat = w.qstat;
-  hipLaunchKernelGGL(k_prepq, dim3(kQB), dim3(256), 0, s_pre, qp);
+  hipLaunchKernelGGL(k_prepq, dim3(kQB), dim3(256), 0, bs, qp);
 
   if (w.exact_all) {
-    ANR_HIP(hipEventRecord(w.ev_done, s_pre));
+    ANR_HIP(hipEventRecord(w.ev_done, bs));
     ANR_HIP(hipStreamWaitEvent(user, w.ev_done, 0));
     return ANR_OK;
   }
@@ -498,7 +500,7 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
   const bool sparse = full_tiles >= 8 * sample_tiles;
   w.sparse = sparse;
   const int side_grid = h->n_cu;
-  const int scan_grid_max = pipelined ? std::max(h->n_cu / 2, h->n_cu - h->reserve_cus) : h->n_cu;
+  const int scan_grid_max = h->n_cu;
 
   ScanParams sc{};
   sc.x16 = reinterpret_cast<const uint4 *>(h->x16);
@@ -521,24 +523,16 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
     sc.n_tiles = n_tiles;
     sc.dense = w.dense;
     sc.dense_ld = w.dense_ld;
-    if (pipelined) {
-      ANR_HIP(hipEventRecord(w.ev_pre, s_pre));
-      ANR_HIP(hipStreamWaitEvent(s_scan, w.ev_pre, 0));
-    }
-    if (w.timed) ANR_HIP(hipEventRecord(w.ev_t0, s_scan));
-    ANR_TRY(launch_scan<true>(h, sc, s_scan, scan_grid_max));
-    if (w.timed) ANR_HIP(hipEventRecord(w.ev_t1, s_scan));
+    if (w.timed) ANR_HIP(hipEventRecord(w.ev_t0, bs));
+    ANR_TRY(launch_scan<true>(h, sc, bs, scan_grid_max));
+    if (w.timed) ANR_HIP(hipEventRecord(w.ev_t1, bs));
     w.scan_bytes = n_tiles * kTileRows * (int64_t)h->dimp * 2;
-    if (pipelined) {
-      ANR_HIP(hipEventRecord(w.ev_scan, s_scan));
-      ANR_HIP(hipStreamWaitEvent(s_post, w.ev_scan, 0));
-    }
     sp.dense = w.dense;
     sp.dense_ld = w.dense_ld;
     sp.n = h->ntotal;
     sp.row0 = 0;
     sp.row_tile_stride = 1;
-    ANR_TRY(launch_select(nq, sp, s_post));
+    ANR_TRY(launch_select(nq, sp, bs));
   } else {
     ANR_TRY(ensure_dense(w, sample_tiles * kTileRows));
     ANR_TRY(ensure_cand(h, w));
@@ -550,7 +544,7 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
     sc.dense = w.dense;
     sc.dense_ld = w.dense_ld;
     sc.groupmax = 1;  // one value per 32-row tile: the K'-th largest tile maximum is a valid threshold
-    ANR_TRY(launch_scan<true>(h, sc, s_pre, side_grid));
+    ANR_TRY(launch_scan<true>(h, sc, bs, side_grid));
     sc.groupmax = 0;
     SelParams ss = sp;
     ss.dense = w.dense;
@@ -559,12 +553,8 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
     ss.row0 = 0;
     ss.row_tile_stride = 1;
     ss.ladder = w.ladder;
-    ANR_TRY(launch_select(kQB, ss, s_pre));
+    ANR_TRY(launch_select(kQB, ss, bs));
     // scan
-    if (pipelined) {
-      ANR_HIP(hipEventRecord(w.ev_pre, s_pre));
-      ANR_HIP(hipStreamWaitEvent(s_scan, w.ev_pre, 0));
-    }
     sc.tile0 = 0;
     sc.tile_stride = 1;
     sc.n_tiles = n_tiles;
@@ -584,22 +574,18 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
     sc.capb = (unsigned)h->cand_cap;
     sc.kprime = (unsigned)M;
     int scan_grid = 0;
-    if (w.timed) ANR_HIP(hipEventRecord(w.ev_t0, s_scan));
-    ANR_TRY(launch_scan<false>(h, sc, s_scan, scan_grid_max, &scan_grid));
-    if (w.timed) ANR_HIP(hipEventRecord(w.ev_t1, s_scan));
+    if (w.timed) ANR_HIP(hipEventRecord(w.ev_t0, bs));
+    ANR_TRY(launch_scan<false>(h, sc, bs, scan_grid_max, &scan_grid));
+    if (w.timed) ANR_HIP(hipEventRecord(w.ev_t1, bs));
     w.scan_bytes = n_tiles * kTileRows * (int64_t)h->dimp * 2;
     // post
-    if (pipelined) {
-      ANR_HIP(hipEventRecord(w.ev_scan, s_scan));
-      ANR_HIP(hipStreamWaitEvent(s_post, w.ev_scan, 0));
-    }
     sp.cand = w.cand;
     sp.cntb = w.cntb;
     sp.G = scan_grid;
     sp.capb = (unsigned)h->cand_cap;
     sp.overflow = w.ncand + kQB;
     sp.ncand = w.ncand;
-    ANR_TRY(launch_select(nq, sp, s_post));
+    ANR_TRY(launch_select(nq, sp, bs));
   }
 
   RescoreParams rp{};
@@ -612,7 +598,7 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
   rp.sel_m = w.sel_m;
   rp.exact = w.exact;
   rp.M = M;
-  hipLaunchKernelGGL(k_rescore, dim3((unsigned)ceil_div((int64_t)nq * M, 4)), dim3(256), 0, s_post, rp);
+  hipLaunchKernelGGL(k_rescore, dim3((unsigned)ceil_div((int64_t)nq * M, 4)), dim3(256), 0, bs, rp);
 
   FinalParams fp{};
   fp.exact = w.exact;
@@ -634,10 +620,11 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
   fp.flags = reinterpret_cast<int *>(w.ncand + 2 * kQB);
   fp.theta = reinterpret_cast<float *>(w.ncand + 3 * kQB);
   fp.id_offset = 0;
-  hipLaunchKernelGGL(k_finalize, dim3(nq), dim3(256), 0, s_post, fp);
+  fp.ncand = sparse ? w.ncand : nullptr;
+  fp.status_host = w.cnt_dev;
+  hipLaunchKernelGGL(k_finalize, dim3(nq), dim3(256), 0, bs, fp);
   ANR_HIP(hipGetLastError());
-  ANR_HIP(hipMemcpyAsync(w.cnt_host, w.ncand, 4 * kQB * sizeof(unsigned), hipMemcpyDeviceToHost, s_post));
-  ANR_HIP(hipEventRecord(w.ev_done, s_post));
+  ANR_HIP(hipEventRecord(w.ev_done, bs));
   ANR_HIP(hipStreamWaitEvent(user, w.ev_done, 0));
   return ANR_OK;
 }
@@ -702,7 +689,6 @@ int search_impl(anr_index *h, const float *q, bool q_on_host, int64_t nq, int32_
     Id = h->i_out;
   }
   if (h->timing) ANR_HIP(hipEventRecord(h->ev_call[0], st));
-  const bool pipelined = nq > kQB;  // several batches in one call overlap their pre/post stages
   for (int64_t q0 = 0; q0 < nq; q0 += kQB) {
     const int nb = (int)std::min<int64_t>(kQB, nq - q0);
     const float *qd = q + q0 * h->dim;
@@ -712,7 +698,7 @@ int search_impl(anr_index *h, const float *q, bool q_on_host, int64_t nq, int32_
       ANR_HIP(hipMemcpyAsync(w.qstage, qd, (size_t)nb * h->dim * sizeof(float), hipMemcpyHostToDevice, st));
       qd = w.qstage;
     }
-    ANR_TRY(enqueue_batch(h, qd, nb, k, q0, Dd, Id, st, pipelined));
+    ANR_TRY(enqueue_batch(h, qd, nb, k, q0, Dd, Id, st));
   }
   ANR_TRY(drain(h));
   if (h->timing) {
@@ -759,7 +745,7 @@ void free_workspaces(anr_index *h) {
     dev_free(w.sel_rank); dev_free(w.sel_row); dev_free(w.sel_m); dev_free(w.exact); dev_free(w.flags);
     if (w.flags_host) (void)hipHostFree(w.flags_host);
     if (w.cnt_host) (void)hipHostFree(w.cnt_host);
-    for (hipEvent_t *e : {&w.ev_in, &w.ev_pre, &w.ev_scan, &w.ev_done, &w.ev_t0, &w.ev_t1})
+    for (hipEvent_t *e : {&w.ev_in, &w.ev_done, &w.ev_t0, &w.ev_t1})
       if (*e) (void)hipEventDestroy(*e);
   }
 }
@@ -790,7 +776,7 @@ int anr_index_create(int32_t dim, int32_t metric, int32_t normalize, int32_t dev
   h->normalize = normalize ? 1 : 0;
   h->device = device;
   h->n_cu = device_cu_count(device);
-  hipStream_t *streams[4] = {&h->stream, &h->s_pre, &h->s_scan, &h->s_post};
+  hipStream_t *streams[1 + kWorkspaces] = {&h->stream, &h->bstream[0], &h->bstream[1], &h->bstream[2]};
   for (auto s : streams) {
     hipError_t e = hipStreamCreateWithFlags(s, hipStreamNonBlocking);
     if (e != hipSuccess) {
@@ -810,7 +796,7 @@ int anr_index_create(int32_t dim, int32_t metric, int32_t normalize, int32_t dev
 int anr_index_destroy(anr_index *h) {
   if (!h) return ANR_OK;
   DeviceGuard g(h->device);
-  for (hipStream_t s : {h->s_pre, h->s_scan, h->s_post, h->stream})
+  for (hipStream_t s : {h->bstream[0], h->bstream[1], h->bstream[2], h->stream})
     if (s) (void)hipStreamSynchronize(s);
   dev_free(h->x32);
   dev_free(h->x16);
@@ -822,7 +808,7 @@ int anr_index_destroy(anr_index *h) {
   dev_free(h->i_out);
   for (auto &e : h->ev_call)
     if (e) (void)hipEventDestroy(e);
-  for (hipStream_t s : {h->s_pre, h->s_scan, h->s_post, h->stream})
+  for (hipStream_t s : {h->bstream[0], h->bstream[1], h->bstream[2], h->stream})
     if (s) (void)hipStreamDestroy(s);
   delete h;
   return ANR_OK;
@@ -922,7 +908,7 @@ int anr_index_search_dev_async(anr_index *h, const float *q_dev, int64_t nq, int
   ANR_TRY(refresh_xstat(h));
   for (int64_t q0 = 0; q0 < nq; q0 += kQB) {
     const int nb = (int)std::min<int64_t>(kQB, nq - q0);
-    ANR_TRY(enqueue_batch(h, q_dev + q0 * h->dim, nb, k, q0, D_dev, I_dev, st, true));
+    ANR_TRY(enqueue_batch(h, q_dev + q0 * h->dim, nb, k, q0, D_dev, I_dev, st));
   }
   return ANR_OK;
 }
@@ -1017,9 +1003,9 @@ int anr_index_set_option(anr_index *h, int32_t opt, int64_t value) {
       break;
     case ANR_OPT_TIMING: h->timing = value != 0; break;
     case ANR_OPT_ADD_RAW: h->add_raw = value != 0; break;
-    case ANR_OPT_RESERVE_CUS:
-      if (value < 0 || value > h->n_cu / 2) return fail(ANR_EINVAL, "reserved CUs must be in 0..%d", h->n_cu / 2);
-      h->reserve_cus = (int)value;
+    case ANR_OPT_STREAMS:
+      if (value < 1 || value > kWorkspaces) return fail(ANR_EINVAL, "streams must be in 1..%d", kWorkspaces);
+      h->n_streams = (int)value;
       break;
     default: return fail(ANR_EINVAL, "unknown option %d", opt);
   }

@@ -922,6 +922,8 @@ struct FinalParams {
   int *flags;                // [64] 0 = certified, 1 = needs the exact path
   float *theta;              // [64] scan-score threshold of the second pass: rank(k-th exact) - eps
   int64_t id_offset;
+  const unsigned *ncand;     // may be null: [64] candidates seen (statistics)
+  unsigned *status_host;     // pinned host memory [4][64]: candidates | overflow | flag | theta bits
 };
 
 __global__ __launch_bounds__(256) void k_finalize(FinalParams p) {
@@ -978,6 +980,15 @@ __global__ __launch_bounds__(256) void k_finalize(FinalParams p) {
     }
     p.flags[q] = flag;
     if (p.theta) p.theta[q] = theta;
+    if (p.status_host) {
+      // the host reads these after the batch's event; written straight to pinned memory so that no
+      // device-to-host copy (and no cache write-back in front of it) sits between two batches
+      p.status_host[q] = p.ncand ? p.ncand[q] : 0u;
+      p.status_host[kQB + q] = p.overflow ? p.overflow[q] : 0u;
+      p.status_host[2 * kQB + q] = (unsigned)flag;
+      p.status_host[3 * kQB + q] = __float_as_uint(theta);
+      __threadfence_system();
+    }
   }
 }
 

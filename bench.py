@@ -40,8 +40,8 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rows", type=int, default=10_000_000, help="total corpus rows (all ranks)")
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--batch", type=int, default=64)
@@ -196,7 +196,7 @@ def main():
     gq = torch.Generator(device=dev)
     gq.manual_seed(4321)
     Q = torch.randn((nb, args.batch, args.dim), generator=gq, device=dev, dtype=torch.float32)
-    # steps are issued asynchronously and overlap (pre/post stages of neighbouring batches run beside the scan):
+    # steps are issued asynchronously and overlap (the small kernels of neighbouring batches run beside the scan):
     # NSLOT rotating sets of output buffers and streams
     NSLOT = 3
     streams = [torch.cuda.Stream(device=dev) for _ in range(NSLOT)]

@@ -92,7 +92,7 @@ int anr_index_score_rows(anr_index *h, const float *q_host, int64_t nq, const in
 #define ANR_OPT_CAND_CAP 4        /* per-query candidate buffer entries                               */
 #define ANR_OPT_TIMING 5          /* 1: record HIP-event time of the scan kernel in stats             */
 #define ANR_OPT_ADD_RAW 6         /* 1: adds store rows as given (already normalised: reloading a saved index) */
-#define ANR_OPT_RESERVE_CUS 7     /* > 0: async searches use 3 streams and the scan leaves this many CUs free (default 0) */
+#define ANR_OPT_STREAMS 7         /* streams the in-flight batches rotate over, 1..3 (default 3; 1 = one batch strictly after the other) */
 int anr_index_set_option(anr_index *h, int32_t opt, int64_t value);
 
 typedef struct anr_search_stats {

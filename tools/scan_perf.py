@@ -15,7 +15,7 @@ ap.add_argument("--k", type=int, default=100)
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--sample", type=int, default=0)
 ap.add_argument("--overfetch", type=int, default=0)
-ap.add_argument("--reserve", type=int, default=-1)
+ap.add_argument("--streams", type=int, default=0)
 ap.add_argument("--mode", default="both")
 ap.add_argument("--clustered", action="store_true", help="1024 Gaussian centroids, sigma 0.3 (SURVEY 8d)")
 a = ap.parse_args()
@@ -58,8 +58,8 @@ if a.mode in ("both", "sync"):
       f"scan GB/s={byt/1e9/(tot_scan/a.steps/1e3):.0f}  qps={a.batch/dt:.0f}  cand/q={cand/a.steps/a.batch:.0f} fallback={fb} "
       f"sample={st['sample_rows']} overfetch={st['overfetch']}")
 if a.mode in ("both", "async"):
-    from anorag_hip._lib import OPT_RESERVE_CUS
-    if a.reserve >= 0: idx.set_option(OPT_RESERVE_CUS, a.reserve)
+    from anorag_hip._lib import OPT_STREAMS
+    if a.streams: idx.set_option(OPT_STREAMS, a.streams)
     NS = 3
     strs = [torch.cuda.Stream() for _ in range(NS)]
     Ds = [torch.empty_like(D) for _ in range(NS)]; Is = [torch.empty_like(I) for _ in range(NS)]
