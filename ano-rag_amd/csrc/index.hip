@@ -231,21 +231,23 @@ int launch_scan(anr_index *h, const ScanParams &p, hipStream_t st, int max_grid,
   int64_t grid = ceil_div(p.n_tiles, nwaves);
   if (grid > max_grid) grid = max_grid;
   if (grid_out) *grid_out = (int)grid;
-  if (p.kb % 16 == 0) {
-    static bool done = false;
-    if (!done) {
-      ANR_TRY(set_max_lds(k_scan<DENSE, 8, 768>));
-      done = true;
-    }
-    hipLaunchKernelGGL((k_scan<DENSE, 8, 768>), dim3((unsigned)grid), dim3(nt), lds, st, p);
-  } else {
-    static bool done = false;
-    if (!done) {
-      ANR_TRY(set_max_lds(k_scan<DENSE, 4, 768>));
-      done = true;
-    }
-    hipLaunchKernelGGL((k_scan<DENSE, 4, 768>), dim3((unsigned)grid), dim3(nt), lds, st, p);
+  // a pass over more than the Infinity Cache can hold streams with non-temporal loads
+  const bool stream = p.tile_stride == 1 && p.n_tiles * (int64_t)p.kb * 1024 > ((int64_t)192 << 20);
+#define ANR_LAUNCH_SCAN(CHV, STRV)                                                             \
+  {                                                                                            \
+    static bool done = false;                                                                  \
+    if (!done) {                                                                               \
+      ANR_TRY(set_max_lds(k_scan<DENSE, CHV, 768, STRV>));                                     \
+      done = true;                                                                             \
+    }                                                                                          \
+    hipLaunchKernelGGL((k_scan<DENSE, CHV, 768, STRV>), dim3((unsigned)grid), dim3(nt), lds, st, p); \
   }
+  if (p.kb % 16 == 0) {
+    if (stream) ANR_LAUNCH_SCAN(8, true) else ANR_LAUNCH_SCAN(8, false)
+  } else {
+    if (stream) ANR_LAUNCH_SCAN(4, true) else ANR_LAUNCH_SCAN(4, false)
+  }
+#undef ANR_LAUNCH_SCAN
   ANR_HIP(hipGetLastError());
   return ANR_OK;
 }

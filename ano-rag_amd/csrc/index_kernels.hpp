@@ -249,12 +249,23 @@ struct ScanParams {
   unsigned kprime;
 };
 
-__device__ __forceinline__ uint4 ld16(const uint4 *p) { return *p; }
+// STREAM: every byte is read once per batch and the corpus is far larger than the 256-MiB Infinity Cache,
+// so the loads carry the non-temporal hint (measured: 6.3 -> 6.7 TB/s on the 15-GB scan).  Small corpora
+// and the threshold sample keep the default policy and stay cache-resident between batches.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <bool STREAM>
+__device__ __forceinline__ uint4 ld16(const uint4 *p) {
+  if (STREAM) {
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+  }
+  return *p;
+}
 
-template <int CH>
+template <int CH, bool STREAM>
 __device__ __forceinline__ void scan_load(uint4 (&a)[CH], const uint4 *xa, int kbase) {
 #pragma unroll
-  for (int j = 0; j < CH; ++j) a[j] = ld16(xa + (int64_t)(kbase + j) * 64);
+  for (int j = 0; j < CH; ++j) a[j] = ld16<STREAM>(xa + (int64_t)(kbase + j) * 64);
 }
 
 template <int CH>
@@ -271,7 +282,7 @@ __device__ __forceinline__ void scan_mfma(const uint4 (&a)[CH], const uint4 *lds
 }
 
 // same, and re-fills each operand register from `next` as soon as its two MFMAs have issued
-template <int CH>
+template <int CH, bool STREAM>
 __device__ __forceinline__ void scan_mfma_refill(uint4 (&a)[CH], const uint4 *next, const uint4 *ldsq0,
                                                  const uint4 *ldsq1, int kbase, floatx16 &acc0, floatx16 &acc1) {
 #pragma unroll
@@ -281,7 +292,7 @@ __device__ __forceinline__ void scan_mfma_refill(uint4 (&a)[CH], const uint4 *ne
     const half8 av = __builtin_bit_cast(half8, a[j]);
     acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(half8, b0), acc0, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(half8, b1), acc1, 0, 0, 0);
-    a[j] = ld16(next + (int64_t)j * 64);
+    a[j] = ld16<STREAM>(next + (int64_t)j * 64);
   }
 }
 
@@ -329,7 +340,7 @@ __device__ __forceinline__ void scan_emit(const floatx16 &acc, float tau, int lv
   if (lvl + 3 < kLadder && cc) atomicAdd(lds_pend + q * kLadder + lvl + 3, cc);
 }
 
-template <bool DENSE, int CH, int NT>
+template <bool DENSE, int CH, int NT, bool STREAM>
 __global__ __launch_bounds__(NT) void k_scan(ScanParams p) {
   // LDS: Q operand image [2][kb][64] | ladder [64][L] | list lengths [64] | level [64] | pending [64][L]
   extern __shared__ uint4 lds[];
@@ -363,7 +374,7 @@ __global__ __launch_bounds__(NT) void k_scan(ScanParams p) {
   // the first chunk of a wave's next tile is requested before the current tile's epilogue, so the wave
   // always has loads in flight (the epilogue would otherwise be a bubble in its share of the stream)
   uint4 aA[CH], aB[CH];
-  if (wglobal < p.n_tiles) scan_load<CH>(aA, p.x16 + (p.tile0 + wglobal * p.tile_stride) * p.kb * 64 + lane, 0);
+  if (wglobal < p.n_tiles) scan_load<CH, STREAM>(aA, p.x16 + (p.tile0 + wglobal * p.tile_stride) * p.kb * 64 + lane, 0);
   for (int64_t i = wglobal; i < p.n_tiles; i += wtotal) {
     const int64_t tile = p.tile0 + i * p.tile_stride;
     const uint4 *xa = p.x16 + tile * p.kb * 64 + lane;
@@ -378,9 +389,9 @@ __global__ __launch_bounds__(NT) void k_scan(ScanParams p) {
       acc1[r] = 0.0f;
     }
     for (int c = 0; c < nch; c += 2) {
-      scan_load<CH>(aB, xa, (c + 1) * CH);
+      scan_load<CH, STREAM>(aB, xa, (c + 1) * CH);
       __builtin_amdgcn_sched_barrier(0);
-      scan_mfma_refill<CH>(aA, (c + 2 < nch) ? xa + (int64_t)(c + 2) * CH * 64 : xn, ldsq0, ldsq1, c * CH, acc0, acc1);
+      scan_mfma_refill<CH, STREAM>(aA, (c + 2 < nch) ? xa + (int64_t)(c + 2) * CH * 64 : xn, ldsq0, ldsq1, c * CH, acc0, acc1);
       __builtin_amdgcn_sched_barrier(0);
       scan_mfma<CH>(aB, ldsq0, ldsq1, (c + 1) * CH, acc0, acc1);
     }
