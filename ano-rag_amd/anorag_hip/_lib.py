@@ -24,6 +24,7 @@ OPT_CAND_CAP = 4
 OPT_TIMING = 5
 OPT_ADD_RAW = 6
 OPT_STREAMS = 7
+OPT_ID_OFFSET = 8
 
 
 class AnoragError(RuntimeError):
@@ -93,6 +94,11 @@ SIGNATURES = {
         C.c_int,
         [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
          C.c_void_p],
+    ),
+    "anr_merge_topk_strided_dev": (
+        C.c_int,
+        [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
+         C.c_void_p, C.c_void_p, C.c_void_p],
     ),
     "anr_fuse_lists": (
         C.c_int,

@@ -77,6 +77,7 @@ struct anr_index {
   int64_t cand_cap = 512;   // entries per (block, query) candidate list
   int timing = 0;
   int add_raw = 0;          // adds store the rows as given (already preprocessed, e.g. a reloaded index)
+  int64_t id_offset = 0;    // added to every returned id (a shard's first global row)
   int n_streams = kWorkspaces;  // streams the batches rotate over (1 = strictly one batch after the other)
 
   Workspace ws[kWorkspaces];
@@ -312,7 +313,7 @@ int run_exact(anr_index *h, Workspace &w, const std::vector<int> &slots) {
     mp.metric = h->metric;
     mp.D = w.D;
     mp.I = w.I;
-    mp.id_offset = 0;
+    mp.id_offset = h->id_offset;
     hipLaunchKernelGGL(k_emit, dim3(nf), dim3(256), 0, st, mp);
     ANR_HIP(hipGetLastError());
   }
@@ -386,6 +387,7 @@ int run_second_pass(anr_index *h, Workspace &w, const std::vector<int> &slots, s
     mp.metric = h->metric;
     mp.D = w.D;
     mp.I = w.I;
+    mp.id_offset = h->id_offset;
     hipLaunchKernelGGL(k_emit, dim3(mp.nf), dim3(256), 0, st, mp);
   }
   ANR_HIP(hipGetLastError());
@@ -621,7 +623,7 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
   fp.I = I_dev;
   fp.flags = reinterpret_cast<int *>(w.ncand + 2 * kQB);
   fp.theta = reinterpret_cast<float *>(w.ncand + 3 * kQB);
-  fp.id_offset = 0;
+  fp.id_offset = h->id_offset;
   fp.ncand = sparse ? w.ncand : nullptr;
   fp.status_host = w.cnt_dev;
   hipLaunchKernelGGL(k_finalize, dim3(nq), dim3(256), 0, bs, fp);
@@ -1005,6 +1007,10 @@ int anr_index_set_option(anr_index *h, int32_t opt, int64_t value) {
       break;
     case ANR_OPT_TIMING: h->timing = value != 0; break;
     case ANR_OPT_ADD_RAW: h->add_raw = value != 0; break;
+    case ANR_OPT_ID_OFFSET:
+      if (value < 0) return fail(ANR_EINVAL, "id offset must be >= 0");
+      h->id_offset = value;
+      break;
     case ANR_OPT_STREAMS:
       if (value < 1 || value > kWorkspaces) return fail(ANR_EINVAL, "streams must be in 1..%d", kWorkspaces);
       h->n_streams = (int)value;
@@ -1045,16 +1051,24 @@ int anr_normalize_rows(float *x_host, int64_t n, int32_t d, int32_t device) {
   return rc;
 }
 
-int anr_merge_topk_dev(int32_t device, const float *Dp_dev, const int64_t *Ip_dev, int32_t P, int64_t nq, int32_t k,
-                       int32_t larger_is_better, float *D_dev, int64_t *I_dev, void *stream) {
+int anr_merge_topk_strided_dev(int32_t device, const float *Dp_dev, const int64_t *Ip_dev, int64_t d_stride,
+                               int64_t i_stride, int32_t P, int64_t nq, int32_t k, int32_t larger_is_better,
+                               float *D_dev, int64_t *I_dev, void *stream) {
   if (!Dp_dev || !Ip_dev || !D_dev || !I_dev || P <= 0 || nq < 0 || k <= 0) return fail(ANR_EINVAL, "bad argument");
+  if (d_stride < nq * k || i_stride < nq * k) return fail(ANR_EINVAL, "part stride shorter than one part");
   if (nq == 0) return ANR_OK;
   DeviceGuard g(device);
   if (!g.ok) return fail(ANR_EHIP, "hipSetDevice(%d) failed", device);
-  MergeParams mp{Dp_dev, Ip_dev, P, nq, k, larger_is_better, D_dev, I_dev};
+  MergeParams mp{Dp_dev, Ip_dev, d_stride, i_stride, P, nq, k, larger_is_better, D_dev, I_dev};
   hipLaunchKernelGGL(k_merge, dim3((unsigned)nq), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), mp);
   ANR_HIP(hipGetLastError());
   return ANR_OK;
+}
+
+int anr_merge_topk_dev(int32_t device, const float *Dp_dev, const int64_t *Ip_dev, int32_t P, int64_t nq, int32_t k,
+                       int32_t larger_is_better, float *D_dev, int64_t *I_dev, void *stream) {
+  return anr_merge_topk_strided_dev(device, Dp_dev, Ip_dev, nq * k, nq * k, P, nq, k, larger_is_better, D_dev, I_dev,
+                                    stream);
 }
 
 }  // extern "C"

@@ -1085,6 +1085,7 @@ __global__ __launch_bounds__(256) void k_emit(EmitParams p) {
 struct MergeParams {
   const float *Dp;
   const int64_t *Ip;
+  int64_t d_stride, i_stride;  // elements between the lists of consecutive parts
   int P;
   int64_t nq;
   int k;
@@ -1111,14 +1112,14 @@ __global__ __launch_bounds__(256) void k_merge(MergeParams p) {
   __syncthreads();
   for (int e = threadIdx.x; e < total; e += 256) {
     const int pe = e / p.k, je = e % p.k;
-    const float s = p.Dp[((int64_t)pe * p.nq + q) * p.k + je];
-    const int64_t id = p.Ip[((int64_t)pe * p.nq + q) * p.k + je];
+    const float s = p.Dp[pe * p.d_stride + q * p.k + je];
+    const int64_t id = p.Ip[pe * p.i_stride + q * p.k + je];
     if (id < 0) continue;
     int rank = je;  // entries of its own list that precede it
     for (int po = 0; po < p.P; ++po) {
       if (po == pe) continue;
-      const float *Do = p.Dp + ((int64_t)po * p.nq + q) * p.k;
-      const int64_t *Io = p.Ip + ((int64_t)po * p.nq + q) * p.k;
+      const float *Do = p.Dp + po * p.d_stride + q * p.k;
+      const int64_t *Io = p.Ip + po * p.i_stride + q * p.k;
       int lo = 0, hi = p.k;  // count entries of list po ordered before (s, id)
       while (lo < hi) {
         const int mid = (lo + hi) >> 1;

@@ -200,11 +200,16 @@ def main():
     # NSLOT rotating sets of output buffers and streams
     NSLOT = 3
     streams = [torch.cuda.Stream(device=dev) for _ in range(NSLOT)]
-    Dl = [torch.empty((args.batch, args.k), device=dev, dtype=torch.float32) for _ in range(NSLOT)]
-    Il = [torch.empty((args.batch, args.k), device=dev, dtype=torch.int64) for _ in range(NSLOT)]
+    # per slot one packed result buffer [B*k f32 | B*k i64]: the index writes both halves, and for N > 1 the
+    # partial top-k lists of all ranks travel in ONE all-gather
+    nres = args.batch * args.k
+    Pl = [torch.empty(nres * 12, device=dev, dtype=torch.uint8) for _ in range(NSLOT)]
+    Dl = [p[: nres * 4].view(torch.float32).view(args.batch, args.k) for p in Pl]
+    Il = [p[nres * 4:].view(torch.int64).view(args.batch, args.k) for p in Pl]
     if world > 1:
-        Dg = [torch.empty((world, args.batch, args.k), device=dev, dtype=torch.float32) for _ in range(NSLOT)]
-        Ig = [torch.empty((world, args.batch, args.k), device=dev, dtype=torch.int64) for _ in range(NSLOT)]
+        from anorag_hip._lib import OPT_ID_OFFSET
+        idx.set_option(OPT_ID_OFFSET, row0)  # the shard returns global ids (no -1 padding: every shard holds >= k rows)
+        Pg = [torch.empty(world * nres * 12, device=dev, dtype=torch.uint8) for _ in range(NSLOT)]
         Dm = [torch.empty_like(Dl[0]) for _ in range(NSLOT)]
         Im = [torch.empty_like(Il[0]) for _ in range(NSLOT)]
     lib = _lib.load()
@@ -217,22 +222,18 @@ def main():
                                 st.cuda_stream)
         if world > 1:
             with torch.cuda.stream(st):
-                Il[s].add_(row0)  # local -> global ids (no -1 padding: every shard holds >= k rows)
                 if args.backend == "nccl":
-                    dist.all_gather_into_tensor(Dg[s], Dl[s])
-                    dist.all_gather_into_tensor(Ig[s], Il[s])
+                    dist.all_gather_into_tensor(Pg[s], Pl[s])
                 else:  # rehearsal path (gloo has no all_gather_into_tensor for device tensors)
                     st.synchronize()
-                    dh = [torch.empty_like(Dl[s], device="cpu") for _ in range(world)]
-                    ih = [torch.empty_like(Il[s], device="cpu") for _ in range(world)]
-                    dist.all_gather(dh, Dl[s].cpu())
-                    dist.all_gather(ih, Il[s].cpu())
-                    Dg[s].copy_(torch.stack(dh))
-                    Ig[s].copy_(torch.stack(ih))
-                _lib.check(lib.anr_merge_topk_dev(local_rank, C.c_void_p(Dg[s].data_ptr()),
-                                                  C.c_void_p(Ig[s].data_ptr()), world, args.batch, args.k, 1,
-                                                  C.c_void_p(Dm[s].data_ptr()), C.c_void_p(Im[s].data_ptr()),
-                                                  C.c_void_p(st.cuda_stream)), "anr_merge_topk_dev")
+                    ph = [torch.empty(nres * 12, dtype=torch.uint8) for _ in range(world)]
+                    dist.all_gather(ph, Pl[s].cpu())
+                    Pg[s].copy_(torch.cat(ph))
+                _lib.check(lib.anr_merge_topk_strided_dev(
+                    local_rank, C.c_void_p(Pg[s].data_ptr()), C.c_void_p(Pg[s].data_ptr() + nres * 4),
+                    nres * 3, (nres * 3) // 2, world, args.batch, args.k, 1,
+                    C.c_void_p(Dm[s].data_ptr()), C.c_void_p(Im[s].data_ptr()),
+                    C.c_void_p(st.cuda_stream)), "anr_merge_topk_strided_dev")
             return Dm[s], Im[s]
         return Dl[s], Il[s]
 

@@ -93,6 +93,7 @@ int anr_index_score_rows(anr_index *h, const float *q_host, int64_t nq, const in
 #define ANR_OPT_TIMING 5          /* 1: record HIP-event time of the scan kernel in stats             */
 #define ANR_OPT_ADD_RAW 6         /* 1: adds store rows as given (already normalised: reloading a saved index) */
 #define ANR_OPT_STREAMS 7         /* streams the in-flight batches rotate over, 1..3 (default 3; 1 = one batch strictly after the other) */
+#define ANR_OPT_ID_OFFSET 8       /* added to every returned id: the first global row of this shard (default 0) */
 int anr_index_set_option(anr_index *h, int32_t opt, int64_t value);
 
 typedef struct anr_search_stats {
@@ -121,6 +122,11 @@ int anr_normalize_rows(float *x_host, int64_t n, int32_t d, int32_t device);
  * larger_is_better selects the order.  Ties → lower id first. */
 int anr_merge_topk_dev(int32_t device, const float *Dp_dev, const int64_t *Ip_dev, int32_t P, int64_t nq,
                        int32_t k, int32_t larger_is_better, float *D_dev, int64_t *I_dev, void *stream);
+/* Same, with the parts d_stride floats / i_stride int64 apart instead of back to back — e.g. the receive
+ * buffer of ONE all-gather whose per-rank chunk is [nq*k f32 | nq*k i64] (bench.py). */
+int anr_merge_topk_strided_dev(int32_t device, const float *Dp_dev, const int64_t *Ip_dev, int64_t d_stride,
+                               int64_t i_stride, int32_t P, int64_t nq, int32_t k, int32_t larger_is_better,
+                               float *D_dev, int64_t *I_dev, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Score fusion: the arithmetic of HybridSearcher.fuse, retrieval/hybrid_search.py:34-103, for a batch

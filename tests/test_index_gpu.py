@@ -263,3 +263,50 @@ def test_tight_clusters_second_pass_is_exact():
     _check(l2, x, q, k, "l2", False)
     assert l2.last_stats()["n_dense_exact"] == 0
     l2.close()
+
+
+def test_two_shards_id_offset_packed_exchange_and_strided_merge():
+    """The N > 1 data path of bench.py on one device: two row shards with ANR_OPT_ID_OFFSET, results written
+    into packed [B*k f32 | B*k i64] buffers, the two buffers laid out as one all-gather would leave them,
+    anr_merge_topk_strided_dev — equals the single-index oracle; -1 padding is not shifted by the offset."""
+    import ctypes as C
+    import torch
+    from anorag_hip import FlatIndex, METRIC_IP, _lib
+    from anorag_hip._lib import OPT_ID_OFFSET
+    n, d, B, k = 90_000, 128, 64, 20
+    x, q = _data(n, d, B)
+    cut = 50_016
+    dev = torch.device("cuda", 0)
+    qt = torch.from_numpy(q).to(dev)
+    nres = B * k
+    packed = torch.zeros(2 * nres * 12, device=dev, dtype=torch.uint8)
+    shards = []
+    for r, (lo, hi) in enumerate(((0, cut), (cut, n))):
+        idx = FlatIndex(d, METRIC_IP, normalize=True)
+        idx.add(x[lo:hi])
+        idx.set_option(OPT_ID_OFFSET, lo)
+        base = packed.data_ptr() + r * nres * 12
+        idx.search_device(qt.data_ptr(), B, k, base, base + nres * 4)
+        shards.append(idx)
+    torch.cuda.synchronize()
+    Dm = torch.empty((B, k), device=dev)
+    Im = torch.empty((B, k), device=dev, dtype=torch.int64)
+    lib = _lib.load()
+    _lib.check(lib.anr_merge_topk_strided_dev(0, C.c_void_p(packed.data_ptr()), C.c_void_p(packed.data_ptr() + nres * 4),
+                                              nres * 3, nres * 3 // 2, 2, B, k, 1, C.c_void_p(Dm.data_ptr()),
+                                              C.c_void_p(Im.data_ptr()), C.c_void_p(0)), "merge")
+    torch.cuda.synchronize()
+    xm, qm = orc.preprocess_vectors(x), orc.preprocess_vectors(q)
+    Dr, Ir = orc.flat_search(qm, xm, k, "ip")
+    assert orc.near_tie_equal(Im.cpu().numpy(), Ir, orc.exact_scores(qm, xm, "ip"), k, 1e-6)
+    assert np.max(np.abs(Dm.cpu().numpy() - Dr)) <= SCORE_TOL
+    # second shard alone: ids are global; asking for more than it holds pads with -1 (not offset - 1)
+    tiny = FlatIndex(d, METRIC_IP, normalize=True)
+    tiny.add(x[:5])
+    tiny.set_option(OPT_ID_OFFSET, 1000)
+    D, I = tiny.search(q[:3], 8)
+    assert np.array_equal(np.sort(I[:, :5], axis=1), np.tile(np.arange(1000, 1005), (3, 1)))
+    assert np.all(I[:, 5:] == -1)
+    for s in shards:
+        s.close()
+    tiny.close()
