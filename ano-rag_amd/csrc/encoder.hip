@@ -75,8 +75,80 @@ struct EmbedParams {
   _Float16 *act;
 };
 
-// one wave per 32-token block; each lane owns (token, half) and walks the KB feature blocks
+constexpr int kLnMaxKbw = 16;  // feature blocks per wave held in registers by the workgroup LN kernels (H <= 1024)
+
+// one workgroup per 32-token block, each wave gathers a quarter of the feature blocks of word + position +
+// type rows into registers; mean and variance (two exact passes over the registers) meet in LDS
 __global__ __launch_bounds__(256) void k_embed_ln(EmbedParams p) {
+  __shared__ float red[2][4][32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t tb = blockIdx.x;
+  const int64_t t = tb * 32 + (lane & 31);
+  const int h = lane >> 5;
+  const int b = (int)(t / p.Lp), pos = (int)(t % p.Lp);
+  const bool real = pos < p.L;
+  const int id = real ? p.ids[(int64_t)b * p.L + pos] : 0;
+  const int ty = (real && p.types) ? p.types[(int64_t)b * p.L + pos] : 0;
+  const int64_t prow = pos + p.pos_offset < p.max_pos ? pos + p.pos_offset : p.max_pos - 1;  // padding rows only
+  const int kbw = p.KB / 4, kb0 = wave * kbw;
+  float x[kLnMaxKbw][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < kLnMaxKbw; ++i) {
+    if (i < kbw) {
+      const int o = ((kb0 + i) * 2 + h) * 8;
+      const float4 *w = reinterpret_cast<const float4 *>(p.word + (int64_t)id * p.H + o);
+      const float4 *q = reinterpret_cast<const float4 *>(p.pos + prow * p.H + o);
+      const float4 *y = reinterpret_cast<const float4 *>(p.type + (int64_t)ty * p.H + o);
+      const float4 a0 = w[0], a1 = w[1], b0 = q[0], b1 = q[1], c0 = y[0], c1 = y[1];
+      x[i][0] = a0.x + b0.x + c0.x; x[i][1] = a0.y + b0.y + c0.y; x[i][2] = a0.z + b0.z + c0.z; x[i][3] = a0.w + b0.w + c0.w;
+      x[i][4] = a1.x + b1.x + c1.x; x[i][5] = a1.y + b1.y + c1.y; x[i][6] = a1.z + b1.z + c1.z; x[i][7] = a1.w + b1.w + c1.w;
+      s += (x[i][0] + x[i][1]) + (x[i][2] + x[i][3]) + (x[i][4] + x[i][5]) + (x[i][6] + x[i][7]);
+    }
+  }
+  s += __shfl_xor(s, 32);
+  if (lane < 32) red[0][wave][lane] = s;
+  __syncthreads();
+  const float mean = ((red[0][0][lane & 31] + red[0][1][lane & 31]) + (red[0][2][lane & 31] + red[0][3][lane & 31])) / p.H;
+  float v = 0.f;
+#pragma unroll
+  for (int i = 0; i < kLnMaxKbw; ++i) {
+    if (i < kbw) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float d = x[i][j] - mean;
+        v += d * d;
+      }
+    }
+  }
+  v += __shfl_xor(v, 32);
+  if (lane < 32) red[1][wave][lane] = v;
+  __syncthreads();
+  v = (red[1][0][lane & 31] + red[1][1][lane & 31]) + (red[1][2][lane & 31] + red[1][3][lane & 31]);
+  const float rstd = rsqrtf(v / p.H + p.eps);
+#pragma unroll
+  for (int i = 0; i < kLnMaxKbw; ++i) {
+    if (i < kbw) {
+      const int kb = kb0 + i;
+      const int o = (kb * 2 + h) * 8;
+      float out[8];
+      half8 hv;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        out[j] = (x[i][j] - mean) * rstd * p.g[o + j] + p.b[o + j];
+        hv[j] = (_Float16)out[j];
+      }
+      const int64_t e = ((tb * p.KB + kb) * 64 + lane) * 8;
+      *reinterpret_cast<float4 *>(p.res + e) = make_float4(out[0], out[1], out[2], out[3]);
+      *reinterpret_cast<float4 *>(p.res + e + 4) = make_float4(out[4], out[5], out[6], out[7]);
+      *reinterpret_cast<half8 *>(p.act + e) = hv;
+    }
+  }
+}
+
+// fallback (H > 1024 or H % 64 != 0): one wave per 32-token block; each lane owns (token, half) and walks the
+// KB feature blocks
+__global__ __launch_bounds__(256) void k_embed_ln_wave(EmbedParams p) {
   const int lane = threadIdx.x & 63;
   const int64_t tb = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t TB = (int64_t)p.B * p.Lp / 32;
@@ -139,7 +211,74 @@ struct LnParams {
   _Float16 *act;
 };
 
+// one workgroup per 32-token block; each of the 4 waves owns a quarter of the feature blocks, keeps it in
+// registers (<= 16 blocks x 8 values per lane), and the per-token sums meet in LDS: the row is read once and
+// 4x as many waves stream as with one wave per token block
 __global__ __launch_bounds__(256) void k_layernorm(LnParams p) {
+  __shared__ float red[4][32][2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t tb = blockIdx.x;
+  const int h = lane >> 5;
+  const int kbw = p.KB / 4, kb0 = wave * kbw;
+  // shifted single-pass statistics: sums of (x - c) and (x - c)^2 with c = the token's first value, so the
+  // variance does not cancel
+  const float c = __shfl(p.in[(tb * p.KB * 64 + (lane & 31)) * 8], lane & 31);
+  float4 v[kLnMaxKbw][2];
+  float s = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < kLnMaxKbw; ++i) {
+    if (i < kbw) {
+      const float4 *x = reinterpret_cast<const float4 *>(p.in + ((tb * p.KB + kb0 + i) * 64 + lane) * 8);
+      v[i][0] = x[0];
+      v[i][1] = x[1];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < kLnMaxKbw; ++i) {
+    if (i < kbw) {
+      const float4 a = v[i][0], b = v[i][1];
+      const float d0 = a.x - c, d1 = a.y - c, d2 = a.z - c, d3 = a.w - c, d4 = b.x - c, d5 = b.y - c, d6 = b.z - c,
+                  d7 = b.w - c;
+      s += (d0 + d1) + (d2 + d3) + (d4 + d5) + (d6 + d7);
+      s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3) + (d4 * d4 + d5 * d5) + (d6 * d6 + d7 * d7);
+    }
+  }
+  s += __shfl_xor(s, 32);
+  s2 += __shfl_xor(s2, 32);
+  if (lane < 32) {
+    red[wave][lane][0] = s;
+    red[wave][lane][1] = s2;
+  }
+  __syncthreads();
+  s = (red[0][lane & 31][0] + red[1][lane & 31][0]) + (red[2][lane & 31][0] + red[3][lane & 31][0]);
+  s2 = (red[0][lane & 31][1] + red[1][lane & 31][1]) + (red[2][lane & 31][1] + red[3][lane & 31][1]);
+  const float md = s / p.H;                       // mean - c
+  const float var = fmaxf(s2 / p.H - md * md, 0.f);
+  const float mean = c + md;
+  const float rstd = rsqrtf(var + p.eps);
+#pragma unroll
+  for (int i = 0; i < kLnMaxKbw; ++i) {
+    if (i < kbw) {
+      const int kb = kb0 + i;
+      const int64_t e = ((tb * p.KB + kb) * 64 + lane) * 8;
+      const int o = (kb * 2 + h) * 8;
+      const float in[8] = {v[i][0].x, v[i][0].y, v[i][0].z, v[i][0].w, v[i][1].x, v[i][1].y, v[i][1].z, v[i][1].w};
+      float out[8];
+      half8 hv;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        out[j] = (in[j] - mean) * rstd * p.g[o + j] + p.b[o + j];
+        hv[j] = (_Float16)out[j];
+      }
+      *reinterpret_cast<float4 *>(p.res + e) = make_float4(out[0], out[1], out[2], out[3]);
+      *reinterpret_cast<float4 *>(p.res + e + 4) = make_float4(out[4], out[5], out[6], out[7]);
+      *reinterpret_cast<half8 *>(p.act + e) = hv;
+    }
+  }
+}
+
+// fallback for shapes the workgroup kernel does not cover (H > 1024 or H % 64 != 0): one wave per token block
+__global__ __launch_bounds__(256) void k_layernorm_wave(LnParams p) {
   const int lane = threadIdx.x & 63;
   const int64_t tb = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (tb >= p.TB) return;
@@ -176,6 +315,11 @@ __global__ __launch_bounds__(256) void k_layernorm(LnParams p) {
     *reinterpret_cast<float4 *>(p.res + e + 4) = make_float4(out[4], out[5], out[6], out[7]);
     *reinterpret_cast<half8 *>(p.act + e) = hv;
   }
+}
+
+static void launch_layernorm(const LnParams &p, hipStream_t st) {
+  if (p.KB % 4 == 0 && p.KB / 4 <= kLnMaxKbw) hipLaunchKernelGGL(k_layernorm, dim3((unsigned)p.TB), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL(k_layernorm_wave, dim3((unsigned)ceil_div(p.TB, 4)), dim3(256), 0, st, p);
 }
 
 // ---- GEMM: out[t][n] = sum_k act[t][k] * W[n][k] + bias[n] -------------------------------------------
@@ -362,6 +506,87 @@ __global__ __launch_bounds__(256) void k_gemm_lds(GemmParams p) {
     __builtin_amdgcn_sched_barrier(0);
     if (s + 2 < nstages) {
       uint4 *slot = g_lds + ((s + 2) % 3) * BUF;  // last read in stage s-1
+#pragma unroll
+      for (int i = 0; i < LPW; ++i)
+        __builtin_amdgcn_global_load_lds(src[i] + (int64_t)(s + 2) * S * 64, slot + dst[i], 16, 0, 0);
+    }
+    const uint4 *L = g_lds + (s % 3) * BUF + lane;
+#pragma unroll
+    for (int ks = 0; ks < S; ++ks) {
+      half8 a[2], b[4];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) a[m] = __builtin_bit_cast(half8, L[(ks * F + 2 * wm + m) * 64]);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) b[n] = __builtin_bit_cast(half8, L[(ks * F + TM + 4 * wn + n) * 64]);
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          if (EPI == EPI_VT) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m], b[n], acc[m][n], 0, 0, 0);
+          else acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[n], a[m], acc[m][n], 0, 0, 0);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const int64_t tb = tb0 + 2 * wm + m;
+      const int nb = nb0 + 4 * wn + n;
+      if (tb < p.TB && nb < p.NB) gemm_store_tile<EPI>(p, acc[m][n], tb, nb, lane);
+    }
+}
+
+// 8-wave form of the same kernel: a workgroup (4 x 2 waves) owns 256 tokens x 256 features, so each byte that
+// leaves L2 feeds twice the MFMAs of the 4-wave tile (the 128 x 256 tile needs ~29 TB/s from L2 at the MFMA
+// peak, more than the L2 delivers), and two waves share each SIMD so one wave's LDS reads hide behind the
+// other's MFMAs.  Ring of three slots x 3 k-steps x 16 fragments = 144 KiB.
+template <int EPI>
+__global__ __launch_bounds__(512) void k_gemm_lds8(GemmParams p) {
+  constexpr int TM = 8, TN = 8, S = 3, F = TM + TN, LPW = S * F / 8;  // fragment copies per wave per stage
+  extern __shared__ uint4 g_lds[];  // ring [3][S][F][64]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int NG = (p.NB + TN - 1) / TN;
+  const int64_t tb0 = (int64_t)(blockIdx.x / NG) * TM;
+  const int nb0 = (int)(blockIdx.x % NG) * TN;
+  const int wm = wave >> 1, wn = wave & 1;
+  const uint4 *src[LPW];
+  int dst[LPW];
+#pragma unroll
+  for (int i = 0; i < LPW; ++i) {
+    const int f = wave * LPW + i, ks = f / F, idx = f % F;
+    if (idx < TM) {
+      const int64_t tb = tb0 + idx < p.TB ? tb0 + idx : p.TB - 1;
+      src[i] = p.act + (tb * p.KB + ks) * 64 + lane;
+    } else {
+      const int nb = nb0 + idx - TM < p.NB ? nb0 + idx - TM : p.NB - 1;
+      src[i] = p.w + ((int64_t)nb * p.KB + ks) * 64 + lane;
+    }
+    dst[i] = (ks * F + idx) * 64;
+  }
+  floatx16 acc[2][4];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+  const int nstages = p.KB / S;
+  constexpr int BUF = S * F * 64;  // uint4 per ring slot
+#pragma unroll
+  for (int i = 0; i < LPW; ++i) __builtin_amdgcn_global_load_lds(src[i], g_lds + dst[i], 16, 0, 0);
+  if (nstages > 1) {
+#pragma unroll
+    for (int i = 0; i < LPW; ++i) __builtin_amdgcn_global_load_lds(src[i] + (int64_t)S * 64, g_lds + BUF + dst[i], 16, 0, 0);
+  }
+  for (int s = 0; s < nstages; ++s) {
+    if (s + 1 < nstages) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // LPW copies of stage s+1 stay in flight
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 2 < nstages) {
+      uint4 *slot = g_lds + ((s + 2) % 3) * BUF;
 #pragma unroll
       for (int i = 0; i < LPW; ++i)
         __builtin_amdgcn_global_load_lds(src[i] + (int64_t)(s + 2) * S * 64, slot + dst[i], 16, 0, 0);
@@ -618,6 +843,18 @@ void launch_gemm(anr_encoder *e, GemmParams &g) {
     hipLaunchKernelGGL((k_gemm<MT, NT, EPI>), dim3((unsigned)ceil_div(waves, 4)), dim3(256), 0, e->stream, g);
     return;
   }
+  static const bool wide = getenv("ANORAG_GEMM_NARROW") == nullptr;  // developer switch: the 4-wave tile everywhere
+  if (wide && g.KB % 3 == 0 && g.TB >= 8 * 16) {
+    const int64_t blocks8 = ceil_div(g.TB, 8) * ceil_div(g.NB, 8);
+    constexpr int lds8 = 3 * 3 * 16 * 1024;
+    static bool attr8 = false;
+    if (!attr8) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_lds8<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds8);
+      attr8 = true;
+    }
+    hipLaunchKernelGGL((k_gemm_lds8<EPI>), dim3((unsigned)blocks8), dim3(512), lds8, e->stream, g);
+    return;
+  }
   const int64_t blocks = ceil_div(g.TB, 4) * ceil_div(g.NB, 8);
   constexpr int lds_bytes = 3 * ANR_GEMM_S * 12 * 1024;
   static bool attr = false;
@@ -805,7 +1042,8 @@ int anr_encoder_forward(anr_encoder *e, const int32_t *ids, const int32_t *lengt
   ep.B = B; ep.L = L; ep.Lp = Lp; ep.H = H; ep.KB = KB; ep.pos_offset = c.pos_offset; ep.max_pos = c.max_positions;
   ep.word = e->word; ep.pos = e->pos; ep.type = e->type; ep.g = e->eg; ep.b = e->eb; ep.eps = c.ln_eps;
   ep.res = e->res; ep.act = e->act;
-  hipLaunchKernelGGL(k_embed_ln, dim3((unsigned)ceil_div(TB, 4)), dim3(256), 0, st, ep);
+  if (KB % 4 == 0 && KB / 4 <= kLnMaxKbw) hipLaunchKernelGGL(k_embed_ln, dim3((unsigned)TB), dim3(256), 0, st, ep);
+  else hipLaunchKernelGGL(k_embed_ln_wave, dim3((unsigned)ceil_div(TB, 4)), dim3(256), 0, st, ep);
 
   const int dh = H / c.n_heads;
   for (int li = 0; li < c.n_layers; ++li) {
@@ -831,7 +1069,7 @@ int anr_encoder_forward(anr_encoder *e, const int32_t *ids, const int32_t *lengt
     go.TB = TB; go.NB = H / 32; go.KB = KB; go.bias_acc = l.bo; go.res_in = e->res; go.res_out = e->res2;
     launch_gemm<EPI_RES>(e, go);
     LnParams l1{e->res2, TB, H, KB, l.ln1g, l.ln1b, c.ln_eps, e->res, e->act};
-    hipLaunchKernelGGL(k_layernorm, dim3((unsigned)ceil_div(TB, 4)), dim3(256), 0, st, l1);
+    launch_layernorm(l1, st);
     GemmParams g1{};
     g1.act = reinterpret_cast<const uint4 *>(e->act); g1.w = reinterpret_cast<const uint4 *>(l.w1);
     g1.TB = TB; g1.NB = I / 32; g1.KB = KB; g1.bias_acc = l.b1; g1.out = e->ffn;
@@ -841,7 +1079,7 @@ int anr_encoder_forward(anr_encoder *e, const int32_t *ids, const int32_t *lengt
     g2.TB = TB; g2.NB = H / 32; g2.KB = I / 16; g2.bias_acc = l.b2; g2.res_in = e->res; g2.res_out = e->res2;
     launch_gemm<EPI_RES>(e, g2);
     LnParams l2{e->res2, TB, H, KB, l.ln2g, l.ln2b, c.ln_eps, e->res, e->act};
-    hipLaunchKernelGGL(k_layernorm, dim3((unsigned)ceil_div(TB, 4)), dim3(256), 0, st, l2);
+    launch_layernorm(l2, st);
   }
   PoolParams pp{e->res, e->d_lens, B, Lp, H, KB, c.pooling, normalize ? 1 : 0, e->out};
   hipLaunchKernelGGL(k_pool, dim3(B), dim3(256), 0, st, pp);
