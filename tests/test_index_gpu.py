@@ -310,3 +310,43 @@ def test_two_shards_id_offset_packed_exchange_and_strided_merge():
     for s in shards:
         s.close()
     tiny.close()
+
+
+def test_sample_that_overestimates_the_corpus_still_gives_exact_results():
+    """The scan's start threshold is a guess from a strided tile sample.  Here the guess is as wrong as it can
+    be: every row that scores high sits in a SAMPLED tile (tile index a multiple of the sample stride), so the
+    sample predicts thousands of rows above the threshold while the corpus holds only the planted ones — fewer
+    than K' candidates come out of the scan, the certificate must fail and the second pass must restore the
+    exact answer.  Also the opposite order: all high rows packed into one UNSAMPLED stretch (threshold far too
+    low for that region) must stay exact without overflowing into the dense path."""
+    from anorag_hip import FlatIndex, METRIC_IP
+    from anorag_hip._lib import OPT_SAMPLE_ROWS
+    rng = np.random.default_rng(5)
+    n, d, nq, k = 200_000, 64, 8, 10
+    sample_rows = 12288                      # 384 sample tiles -> stride 6250 // 384 = 16 tiles
+    stride = (n // 32) // (sample_rows // 32)
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    for t in range(0, (sample_rows // 32)):  # one near-copy of every query in each sampled tile
+        r0 = t * stride * 32
+        for j in range(nq):
+            x[r0 + j] = q[j] * (1.0 + 0.01 * t) + 0.05 * rng.standard_normal(d).astype(np.float32)
+    idx = FlatIndex(d, METRIC_IP, normalize=True)
+    idx.add(x)
+    idx.set_option(OPT_SAMPLE_ROWS, sample_rows)
+    _check(idx, x, q, k, "ip", True)
+    st = idx.last_stats()
+    assert st["n_fallback"] == nq, st        # every query: fewer than K' candidates above the guessed threshold
+    assert st["n_dense_exact"] == 0, st      # ... and the second pass (not the dense path) answered them
+    idx.close()
+
+    x2 = rng.standard_normal((n, d)).astype(np.float32)
+    lo = 5 * 32                              # tiles 5..14 lie between two sampled tiles (0 and 16)
+    for j in range(300):
+        x2[lo + j] = q[j % nq] + 0.2 * rng.standard_normal(d).astype(np.float32)
+    idx = FlatIndex(d, METRIC_IP, normalize=True)
+    idx.add(x2)
+    idx.set_option(OPT_SAMPLE_ROWS, sample_rows)
+    _check(idx, x2, q, k, "ip", True)
+    assert idx.last_stats()["n_dense_exact"] == 0
+    idx.close()

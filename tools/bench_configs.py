@@ -105,10 +105,12 @@ for method in ("linear", "rrf"):
     hs = HybridSearcher({"retrieval": {"candidate_pool": 80, "hybrid": {"fusion_method": method, "rrf_k": 60,
                                                                         "weights": {"dense": 1.0, "bm25": 0.5, "graph": 0.5, "path": 0.1}}}})
     hs.fuse_batch(queries[:8])
-    t0 = time.perf_counter(); got = hs.fuse_batch(queries); t_gpu = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    exp = [ofu.fuse(*qq, candidate_pool=80, fusion_method=method, weights=hs.weights, rrf_k=60) for qq in queries]
-    t_cpu = time.perf_counter() - t0
+    t_gpu = t_cpu = 1e9
+    for _ in range(3):  # best of three: single shots pick up GC pauses and the host BLAS threads' spinning
+        t0 = time.perf_counter(); got = hs.fuse_batch(queries); t_gpu = min(t_gpu, time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        exp = [ofu.fuse(*qq, candidate_pool=80, fusion_method=method, weights=hs.weights, rrf_k=60) for qq in queries]
+        t_cpu = min(t_cpu, time.perf_counter() - t0)
     same = all([r["final_similarity"] for r in a] == [r["final_similarity"] for r in b] for a, b in zip(got, exp))
     res[method] = {"device_path_ms_200_queries_incl_python_marshalling": t_gpu * 1e3, "python_reference_algorithm_ms": t_cpu * 1e3,
                    "finals_bit_identical": bool(same)}
