@@ -69,6 +69,29 @@ class FlatIndex:
                                                   out.ctypes.data_as(C.c_void_p)), "anr_index_score_rows")
         return out
 
+    def self_join(self, threshold: float, cap_hint: int = 0, sort: bool = True):
+        """all pairs i < j of stored rows with inner product >= threshold: (i, j, score) arrays, sorted by (i, j)
+        unless sort=False (device order)"""
+        cap = int(cap_hint) if cap_hint > 0 else max(4 * self.ntotal, 1 << 16)
+        n = C.c_int64(0)
+        for _ in range(3):
+            I = np.empty((cap,), dtype=np.int64)
+            J = np.empty((cap,), dtype=np.int64)
+            S = np.empty((cap,), dtype=np.float32)
+            _lib.check(self._lib.anr_index_self_join(self._h, C.c_float(float(threshold)), cap,
+                                                     I.ctypes.data_as(C.c_void_p), J.ctypes.data_as(C.c_void_p),
+                                                     S.ctypes.data_as(C.c_void_p), C.byref(n)), "anr_index_self_join")
+            if n.value >= 0:
+                break
+            cap = -n.value  # the lists were too small: the library reports an upper bound
+        else:
+            raise _lib.AnoragError("anr_index_self_join: pair lists kept overflowing")
+        m = n.value
+        if not sort:
+            return I[:m], J[:m], S[:m]
+        order = np.argsort(I[:m] * np.int64(self.ntotal) + J[:m], kind="stable")
+        return I[:m][order], J[:m][order], S[:m][order]
+
     def reset(self) -> None:
         _lib.check(self._lib.anr_index_reset(self._h), "anr_index_reset")
 

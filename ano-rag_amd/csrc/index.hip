@@ -13,6 +13,7 @@
 // answered by the second pass / the dense exact path when the batch is retired.
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <mutex>
 #include <vector>
 
@@ -20,6 +21,7 @@
 #include "index_kernels.hpp"
 
 using namespace anr;
+
 
 namespace {
 constexpr int kWorkspaces = 3;
@@ -251,6 +253,16 @@ int launch_scan(anr_index *h, const ScanParams &p, hipStream_t st, int max_grid,
 #undef ANR_LAUNCH_SCAN
   ANR_HIP(hipGetLastError());
   return ANR_OK;
+}
+
+template <int S>
+hipError_t launch_join(const JoinParams &jp, int64_t n_blocks, hipStream_t st) {
+  constexpr int ring_bytes = 3 * S * 16 * 1024;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join<S>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, ring_bytes);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((k_join<S>), dim3((unsigned)n_blocks), dim3(512), ring_bytes, st, jp);
+  return hipGetLastError();
 }
 
 int auto_overfetch(const anr_index *h, int k) {
@@ -983,6 +995,92 @@ int anr_index_score_rows(anr_index *h, const float *q_host, int64_t nq, const in
   dev_free(dq32);
   cleanup();
   if (e != hipSuccess) return fail(ANR_EHIP, "score_rows failed: %s", hipGetErrorString(e));
+  return ANR_OK;
+}
+
+int anr_index_self_join(anr_index *h, float threshold, int64_t cap, int64_t *I_host, int64_t *J_host, float *S_host,
+                        int64_t *n_pairs) {
+  if (!h || !n_pairs || cap < 0 || (cap > 0 && (!I_host || !J_host || !S_host))) return fail(ANR_EINVAL, "bad argument");
+  if (h->metric != ANR_METRIC_IP) return fail(ANR_EINVAL, "self join is defined for the inner-product metric");
+  if (!(threshold == threshold)) return fail(ANR_EINVAL, "threshold is NaN");
+  DeviceGuard g(h->device);
+  if (!g.ok) return fail(ANR_EHIP, "hipSetDevice(%d) failed", h->device);
+  std::lock_guard<std::mutex> lk(h->mu);
+  ANR_TRY(drain(h));
+  *n_pairs = 0;
+  if (h->ntotal < 2) return ANR_OK;
+  ANR_TRY(refresh_xstat(h));
+  if (h->f16_unusable) return fail(ANR_ESTATE, "stored values exceed the f16 range: the f16 image cannot nominate pairs");
+  unsigned xs[2] = {0, 0};
+  ANR_HIP(hipMemcpy(xs, h->xstat, sizeof xs, hipMemcpyDeviceToHost));
+  float xmax, xerr;
+  memcpy(&xmax, &xs[0], 4);
+  memcpy(&xerr, &xs[1], 4);
+  // |x16_i . x16_j - x_i . x_j| <= |x_i||dx_j| + |dx_i||x16_j| (+ f32 accumulation of the MFMA)
+  const double eps = 2.0 * xmax * xerr + (double)xerr * xerr + 2.0 * h->dimp * 5.9604645e-8 * (double)xmax * xmax;
+  const int64_t n_tiles = ceil_div(h->ntotal, kTileRows);
+  const int nblk = (int)ceil_div(n_tiles, 8);
+  const int64_t n_blocks = (int64_t)nblk * (nblk + 1) / 2;
+  if (n_blocks > 0x7fffffffLL) return fail(ANR_EINVAL, "too many rows for one self-join launch");
+  // candidates = pairs within eps below the threshold as well: a little more room than the caller's cap
+  const int64_t ccap = cap + cap / 4 + 65536;
+  uint2 *cand = nullptr;
+  unsigned long long *counts = nullptr;  // [0] candidates, [1] results
+  int64_t *oi = nullptr, *oj = nullptr;
+  float *os = nullptr;
+  int rc = ANR_OK;
+  auto cleanup = [&]() {
+    dev_free(cand); dev_free(counts); dev_free(oi); dev_free(oj); dev_free(os);
+  };
+  if ((rc = dev_alloc(&cand, ccap, false)) || (rc = dev_alloc(&counts, 2, true)) ||
+      (rc = dev_alloc(&oi, std::max<int64_t>(cap, 1), false)) || (rc = dev_alloc(&oj, std::max<int64_t>(cap, 1), false)) ||
+      (rc = dev_alloc(&os, std::max<int64_t>(cap, 1), false))) {
+    cleanup();
+    return rc;
+  }
+  hipStream_t st = h->stream;
+  JoinParams jp{};
+  jp.x16 = reinterpret_cast<const uint4 *>(h->x16);
+  jp.kb = h->kb;
+  jp.n_rows = h->ntotal;
+  jp.n_tiles = n_tiles;
+  jp.nblk = nblk;
+  jp.thr_lo = (float)((double)threshold - eps - 1e-7 * (std::fabs((double)threshold) + 1.0));
+  jp.cand = cand;
+  jp.cap = (unsigned long long)ccap;
+  jp.count = counts;
+  hipError_t e = hipSuccess;
+  e = h->kb % 3 == 0 ? launch_join<3>(jp, n_blocks, st) : launch_join<2>(jp, n_blocks, st);
+  unsigned long long hc[2] = {0, 0};
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(hc, counts, sizeof(unsigned long long), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e == hipSuccess && hc[0] > (unsigned long long)ccap) {
+    *n_pairs = -(int64_t)hc[0];
+    cleanup();
+    return ANR_OK;
+  }
+  if (e == hipSuccess && hc[0] > 0) {
+    JoinRescoreParams rp{h->x32, h->dim, cand, hc[0], threshold, oi, oj, os, (unsigned long long)cap, counts + 1};
+    const unsigned grid = (unsigned)std::min<int64_t>(ceil_div((int64_t)hc[0], 256), (int64_t)h->n_cu * 16);
+    hipLaunchKernelGGL(k_join_rescore, dim3(grid), dim3(256), 0, st, rp);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(hc + 1, counts + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess && hc[1] > (unsigned long long)cap) {
+      *n_pairs = -(int64_t)hc[1];
+      cleanup();
+      return ANR_OK;
+    }
+    if (e == hipSuccess && hc[1] > 0) {
+      e = hipMemcpy(I_host, oi, hc[1] * sizeof(int64_t), hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipMemcpy(J_host, oj, hc[1] * sizeof(int64_t), hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipMemcpy(S_host, os, hc[1] * sizeof(float), hipMemcpyDeviceToHost);
+    }
+  }
+  cleanup();
+  if (e != hipSuccess) return fail(ANR_EHIP, "self join failed: %s", hipGetErrorString(e));
+  *n_pairs = (int64_t)hc[1];
   return ANR_OK;
 }
 

@@ -1158,4 +1158,212 @@ __global__ __launch_bounds__(256) void k_merge(MergeParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// self join: all pairs (i < j) of stored rows with x_i . x_j >= threshold — the thresholded upper triangle
+// of the reference's N x N similarity matrix (graph/relation_extractor.py:769-782 and :604-608) without
+// ever forming the matrix.  MFMA-bound: a workgroup (8 waves, 4 x 2) multiplies a 256-row block against a
+// 256-row block of the SAME blocked f16 image (an x16 tile is a valid A and a valid B operand), operands
+// staged once per workgroup through a three-slot LDS ring by global_load_lds; hits at or above
+// threshold - eps go to a candidate list and are re-scored exactly (f32 rows, f64 accumulate) afterwards.
+// ------------------------------------------------------------------------------------------------
+// 16 bytes per lane global -> LDS without passing through registers.  A plain function on purpose: called with
+// template-dependent arguments straight from a kernel template, the builtin makes the host-side instantiation of
+// that kernel fail silently (no host stub is emitted and the launch symbol stays undefined).
+__device__ __forceinline__ void glds16(const uint4 *g, uint4 *l) { __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0); }
+
+struct JoinParams {
+  const uint4 *x16;
+  int kb;
+  int64_t n_rows, n_tiles;
+  int nblk;               // 256-row blocks
+  float thr_lo;           // threshold - eps
+  uint2 *cand;            // [cap] (i, j)
+  unsigned long long cap;
+  unsigned long long *count;
+};
+
+template <int S>
+__global__ __launch_bounds__(512) void k_join(JoinParams p) {
+  constexpr int TM = 8, TN = 8, F = TM + TN, LPW = S * F / 8;
+  extern __shared__ uint4 lds[];  // ring [3][S][F][64]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // block pair (bi <= bj) from the linear index over the upper triangle, column by column
+  const long long t = blockIdx.x;
+  long long bj = (long long)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+  while (bj * (bj + 1) / 2 > t) --bj;
+  while ((bj + 1) * (bj + 2) / 2 <= t) ++bj;
+  const long long bi = t - bj * (bj + 1) / 2;
+  const int64_t tb0 = bi * TM, nb0 = bj * TN;
+  const int wm = wave >> 1, wn = wave & 1;
+  const uint4 *src[LPW];
+  int dst[LPW];
+#pragma unroll
+  for (int i = 0; i < LPW; ++i) {
+    const int f = wave * LPW + i, ks = f / F, idx = f % F;
+    int64_t tile = idx < TM ? tb0 + idx : nb0 + idx - TM;
+    if (tile >= p.n_tiles) tile = p.n_tiles - 1;  // clamp: masked at emit
+    src[i] = p.x16 + (tile * p.kb + ks) * 64 + lane;
+    dst[i] = (ks * F + idx) * 64;
+  }
+  floatx16 acc[2][4];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+  const int nstages = p.kb / S;
+  constexpr int BUF = S * F * 64;
+#pragma unroll
+  for (int i = 0; i < LPW; ++i) glds16(src[i], lds + dst[i]);
+  if (nstages > 1) {
+#pragma unroll
+    for (int i = 0; i < LPW; ++i) glds16(src[i] + (int64_t)S * 64, lds + BUF + dst[i]);
+  }
+  for (int s = 0; s < nstages; ++s) {
+    if (s + 1 < nstages) {  // the LPW copies of stage s+1 may stay in flight
+      if (S == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 2 < nstages) {
+      uint4 *slot = lds + ((s + 2) % 3) * BUF;
+#pragma unroll
+      for (int i = 0; i < LPW; ++i)
+        glds16(src[i] + (int64_t)(s + 2) * S * 64, slot + dst[i]);
+    }
+    const uint4 *L = lds + (s % 3) * BUF + lane;
+#pragma unroll
+    for (int ks = 0; ks < S; ++ks) {
+      half8 a[2], b[4];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) a[m] = __builtin_bit_cast(half8, L[(ks * F + 2 * wm + m) * 64]);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) b[n] = __builtin_bit_cast(half8, L[(ks * F + TM + 4 * wn + n) * 64]);
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[n], a[m], acc[m][n], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // C rows = rows of the j tile, C columns = rows of the i tile.  Two passes over the accumulators: count the
+  // hits, reserve the workgroup's slots with ONE atomic (a counter that every hit bumped serialised at
+  // ~12 ns per hit), then write
+  __shared__ unsigned wave_hits[8];
+  __shared__ unsigned long long block_base;
+  unsigned mine = 0;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const int64_t gi = (tb0 + 2 * wm + m) * 32 + (lane & 31);
+      const int64_t gj0 = (nb0 + 4 * wn + n) * 32 + 4 * (lane >> 5);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t gj = gj0 + (r & 3) + 8 * (r >> 2);
+        mine += (gi < gj && gj < p.n_rows && acc[m][n][r] >= p.thr_lo) ? 1u : 0u;
+      }
+    }
+  unsigned incl = mine;  // inclusive prefix over the lanes
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned v = __shfl_up(incl, off);
+    if (lane >= off) incl += v;
+  }
+  if (lane == 63) wave_hits[wave] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned tot = 0;
+    for (int w = 0; w < 8; ++w) tot += wave_hits[w];
+    block_base = tot ? atomicAdd(p.count, (unsigned long long)tot) : 0ull;
+  }
+  __syncthreads();
+  unsigned long long k = block_base + (incl - mine);
+  for (int w = 0; w < wave; ++w) k += wave_hits[w];
+  if (mine) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const int64_t gi = (tb0 + 2 * wm + m) * 32 + (lane & 31);
+        const int64_t gj0 = (nb0 + 4 * wn + n) * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t gj = gj0 + (r & 3) + 8 * (r >> 2);
+          if (gi < gj && gj < p.n_rows && acc[m][n][r] >= p.thr_lo) {
+            if (k < p.cap) p.cand[k] = make_uint2((unsigned)gi, (unsigned)gj);
+            ++k;
+          }
+        }
+      }
+  }
+}
+
+// exact value of every candidate pair; the pairs that reach the threshold are compacted into the output
+struct JoinRescoreParams {
+  const float *x32;
+  int dim;
+  const uint2 *cand;
+  unsigned long long n_cand;
+  float threshold;
+  int64_t *out_i, *out_j;
+  float *out_s;
+  unsigned long long out_cap;
+  unsigned long long *out_count;
+};
+
+__global__ __launch_bounds__(256) void k_join_rescore(JoinRescoreParams p) {
+  const int lane = threadIdx.x & 63;
+  const unsigned long long w0 = (unsigned long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const unsigned long long wt = (unsigned long long)gridDim.x * 4;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  // a wave takes 64 candidates at a time: lane c keeps candidate c's value, so the survivors of the batch are
+  // appended with one atomic
+  for (unsigned long long c0 = w0 * 64; c0 < p.n_cand; c0 += wt * 64) {
+    const unsigned long long nb = p.n_cand - c0 < 64 ? p.n_cand - c0 : 64;
+    const uint2 my = lane < nb ? p.cand[c0 + lane] : make_uint2(0u, 0u);
+    float mine = 0.f;
+    for (unsigned c = 0; c < nb; ++c) {
+      const unsigned ri = __shfl(my.x, c), rj = __shfl(my.y, c);
+      const float *a = p.x32 + (int64_t)ri * p.dim, *b = p.x32 + (int64_t)rj * p.dim;
+      double acc = 0.0;
+      if ((p.dim & 3) == 0) {
+        const f32x4 *a4 = reinterpret_cast<const f32x4 *>(a), *b4 = reinterpret_cast<const f32x4 *>(b);
+        const int n4 = p.dim >> 2;
+#pragma unroll 4
+        for (int k = lane; k < n4; k += 64) {
+          const f32x4 u = a4[k], v = b4[k];
+          acc += (double)u.x * (double)v.x;
+          acc += (double)u.y * (double)v.y;
+          acc += (double)u.z * (double)v.z;
+          acc += (double)u.w * (double)v.w;
+        }
+      } else {
+        for (int k = lane; k < p.dim; k += 64) acc += (double)a[k] * (double)b[k];
+      }
+      for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+      if (lane == (int)c) mine = (float)acc;
+    }
+    const bool keep = lane < nb && mine >= p.threshold;
+    const unsigned long long mask = __ballot(keep);
+    if (mask) {
+      unsigned long long base = 0;
+      if (lane == 0) base = atomicAdd(p.out_count, (unsigned long long)__popcll(mask));
+      base = __shfl(base, 0);
+      if (keep) {
+        const unsigned long long k = base + __popcll(mask & ((1ull << lane) - 1ull));
+        if (k < p.out_cap) {
+          p.out_i[k] = my.x;
+          p.out_j[k] = my.y;
+          p.out_s[k] = mine;
+        }
+      }
+    }
+  }
+}
+
 }  // namespace anr

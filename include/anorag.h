@@ -85,6 +85,16 @@ int anr_index_sync(anr_index *h);
 int anr_index_score_rows(anr_index *h, const float *q_host, int64_t nq, const int64_t *ids_host,
                          int32_t per_query, float *out_host);
 
+/* Self join: every pair i < j of stored rows whose inner product reaches `threshold` — for a cosine
+ * index (normalize = 1) the thresholded upper triangle of the N x N similarity matrix that
+ * graph/relation_extractor.py:769-782 forms in full and :604-608 scans pair by pair, without the matrix.
+ * Inner-product metric only.  Writes up to `cap` pairs (i, j, exact f32 score of the stored rows; order
+ * unspecified) and sets *n_pairs to the number of qualifying pairs.  If the device-side lists were too
+ * small, nothing is written, *n_pairs is set to minus an upper bound on the number of pairs, and the call
+ * returns ANR_OK: call again with cap >= that bound. */
+int anr_index_self_join(anr_index *h, float threshold, int64_t cap, int64_t *I_host, int64_t *J_host,
+                        float *S_host, int64_t *n_pairs);
+
 /* tuning / introspection */
 #define ANR_OPT_FORCE_EXACT 1     /* 1: skip the f16 scan, run the dense exact path for every query  */
 #define ANR_OPT_OVERFETCH 2       /* candidates kept per query before the exact re-score (0 = auto)  */

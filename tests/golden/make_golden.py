@@ -8,6 +8,11 @@ Imports, by file path, the two reference files of the hot path that are importab
 stub, the same sys.modules technique the reference's own tests use for GPUtil).  Writes
   tests/golden/fusion_cases.json   inputs + the reference's HybridSearcher.fuse output
   tests/golden/bm25_cases.json     notes + queries + the reference's bm25_scores output (SimpleBM25 variant)
+  tests/golden/similarity_relation_cases.json   embeddings + the reference's semantic-similarity relations
+      (graph/relation_extractor.py:591-629, 769-791).  That file's module-level imports (`utils`, `config`) pull
+      in packages that are absent here; the three methods used are pure numpy, so the two names are satisfied by
+      empty stand-in modules whose `config.get(key, default)` returns the default — the arithmetic that runs is
+      the reference's own.
 Only data is written; no reference source is copied.  The GPU box never runs this script.
 """
 import importlib.util
@@ -135,6 +140,54 @@ def bm25_cases(bm):
     return cases
 
 
+def stub_utils_and_config():
+    u = types.ModuleType("utils")
+
+    class _Any:
+        def __init__(self, *a, **k):
+            pass
+
+    u.TextUtils = u.GPUUtils = u.BatchProcessor = _Any
+    sys.modules["utils"] = u
+    c = types.ModuleType("config")
+
+    class _Cfg:
+        def get(self, key, default=None):
+            return default
+
+    c.config = _Cfg()
+    sys.modules["config"] = c
+
+
+def similarity_cases(rx):
+    import numpy as np
+    ext = rx.RelationExtractor()
+    cases = []
+
+    def add(name, emb):
+        notes = [{"note_id": f"n{i:04d}"} for i in range(emb.shape[0])]
+        rel = ext.extract_semantic_similarity_relations(notes, emb)
+        cases.append({"name": name, "threshold": ext.similarity_threshold,
+                      "weight": ext.relation_weights["semantic_similarity"],
+                      "embeddings": [[float(v) for v in row] for row in emb],
+                      "expected": [{"source_id": r["source_id"], "target_id": r["target_id"], "weight": float(r["weight"]),
+                                    "cosine_similarity": r["metadata"]["cosine_similarity"],
+                                    "similarity_rank": int(r["metadata"]["similarity_rank"])} for r in rel]})
+
+    rng = np.random.default_rng(20251031)
+    for t, (n, d, k, sigma) in enumerate([(24, 16, 4, 0.35), (60, 32, 6, 0.5), (40, 8, 3, 0.6)]):
+        cent = rng.standard_normal((k, d))
+        emb = (cent[rng.integers(0, k, n)] + sigma * rng.standard_normal((n, d))).astype(np.float32)
+        add(f"clusters_{t}", emb)
+    emb = rng.standard_normal((20, 12)).astype(np.float32)
+    emb[3] = 0.0                       # zero row: norm replaced by 1, similarity 0 (relation_extractor.py:772-773)
+    emb[7] = 2.5 * emb[5]              # scaled copy: cosine 1
+    emb[11] = emb[5] + 0.05 * rng.standard_normal(12).astype(np.float32)
+    add("zero_row_and_copies", emb)
+    add("nothing_above_threshold", np.eye(10, dtype=np.float32))
+    return cases
+
+
 def main():
     stub_loguru()
     hs = load_by_path("ref_hybrid_search", os.path.join(REF, "retrieval", "hybrid_search.py"))
@@ -144,7 +197,12 @@ def main():
     with open(os.path.join(HERE, "bm25_cases.json"), "w") as f:
         json.dump({"source": "reference utils/bm25_search.py build_bm25_corpus + bm25_scores (SimpleBM25)",
                    "cases": bm25_cases(bm)}, f)
-    print("wrote fusion_cases.json, bm25_cases.json")
+    stub_utils_and_config()
+    rx = load_by_path("ref_relation_extractor", os.path.join(REF, "graph", "relation_extractor.py"))
+    with open(os.path.join(HERE, "similarity_relation_cases.json"), "w") as f:
+        json.dump({"source": "reference graph/relation_extractor.py extract_semantic_similarity_relations",
+                   "cases": similarity_cases(rx)}, f)
+    print("wrote fusion_cases.json, bm25_cases.json, similarity_relation_cases.json")
 
 
 if __name__ == "__main__":

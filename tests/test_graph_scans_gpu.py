@@ -1,0 +1,108 @@
+"""GPU parity tests of the graph layer's dense scans (anr_index_self_join through the C ABI) against the golden
+vectors produced by the reference's own graph/relation_extractor.py and against the oracle at larger sizes.
+
+Bar: identical pair lists (order included) modulo pairs whose similarity is within 1e-6 of the threshold (the
+reference decides those on a float32 sgemm value, this build on the float64-accumulated one), similarities within
+1e-6, ranks identical where no two similarities of the row are closer than 1e-6."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import graph_scans as og
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-6
+
+
+def _compare(got, exp_pairs, exp_sim, exp_rank, exp_weight, thr, sim_rows=None):
+    g = {(r["source_id"], r["target_id"]): r for r in got}
+    e = {p: (s, k, w) for p, s, k, w in zip(exp_pairs, exp_sim, exp_rank, exp_weight)}
+    for p in set(g) ^ set(e):  # only pairs sitting on the threshold may differ
+        s = g[p]["metadata"]["cosine_similarity"] if p in g else e[p][0]
+        assert abs(s - thr) <= TOL, (p, s)
+    common = [p for p in e if p in g]
+    assert [p for p in exp_pairs if p in g] == [p for p in ((r["source_id"], r["target_id"]) for r in got) if p in e]
+    for p in common:
+        s, k, w = e[p]
+        assert abs(g[p]["metadata"]["cosine_similarity"] - s) <= TOL
+        assert abs(float(g[p]["weight"]) - w) <= TOL
+        assert g[p]["relation_type"] == "semantic_similarity"
+        if sim_rows is None or sim_rows(p):
+            assert g[p]["metadata"]["similarity_rank"] == k, p
+
+
+def test_semantic_similarity_relations_match_reference_golden():
+    from anorag_hip.graph_scans import semantic_similarity_relations
+    data = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "similarity_relation_cases.json")))
+    for case in data["cases"]:
+        emb = np.asarray(case["embeddings"], dtype=np.float32)
+        notes = [{"note_id": f"n{i:04d}"} for i in range(emb.shape[0])]
+        got = semantic_similarity_relations(notes, emb, case["threshold"], case["weight"])
+        exp = case["expected"]
+        sim = og.similarity_matrix(emb)
+        idx = {f"n{i:04d}": i for i in range(emb.shape[0])}
+
+        def distinct(p, sim=sim, idx=idx):  # the rank is only defined where the row has no near-tie at that value
+            row = sim[idx[p[0]]]
+            return np.sum(np.abs(row - row[idx[p[1]]]) <= 2 * TOL) == 1
+
+        _compare(got, [(r["source_id"], r["target_id"]) for r in exp], [r["cosine_similarity"] for r in exp],
+                 [r["similarity_rank"] for r in exp], [r["weight"] for r in exp], case["threshold"], distinct)
+
+
+@pytest.mark.parametrize("n,d,thr", [(3000, 768, 0.7), (5000, 1024, 0.55), (700, 100, 0.3)])
+def test_self_join_matches_oracle_at_size(n, d, thr):
+    """ragged sizes (n not a multiple of 256 or 32, d not a multiple of 128), both LDS-ring depths (KB % 3)"""
+    from anorag_hip.graph_scans import semantic_similarity_relations
+    rng = np.random.default_rng(n)
+    cent = rng.standard_normal((n // 40, d)).astype(np.float32)
+    emb = (cent[rng.integers(0, len(cent), n)] + 0.55 * rng.standard_normal((n, d))).astype(np.float32)
+    emb[17] = 0.0
+    notes = [{"note_id": i} for i in range(n)]
+    got = semantic_similarity_relations(notes, emb, thr, 0.5)
+    exp = og.semantic_similarity_relations(notes, emb, thr, 0.5)
+    assert len(exp) > 100
+    sim = og.similarity_matrix(emb)
+
+    def distinct(p):
+        row = sim[p[0]]
+        return np.sum(np.abs(row - row[p[1]]) <= 2 * TOL) == 1
+
+    _compare(got, [(r["source_id"], r["target_id"]) for r in exp], [r["metadata"]["cosine_similarity"] for r in exp],
+             [r["metadata"]["similarity_rank"] for r in exp], [float(r["weight"]) for r in exp], thr, distinct)
+
+
+def test_self_join_edge_cases_and_list_growth():
+    from anorag_hip import FlatIndex, METRIC_IP, METRIC_L2, _lib
+    idx = FlatIndex(32, METRIC_IP, normalize=True)
+    I, J, S = idx.self_join(0.5)
+    assert len(I) == 0                                    # empty index
+    idx.add(np.ones((1, 32), dtype=np.float32))
+    assert len(idx.self_join(0.5)[0]) == 0                # one row: no pair
+    x = np.tile(np.arange(1, 33, dtype=np.float32), (599, 1))  # 599 identical rows after the all-ones row 0
+    idx.add(x)
+    I, J, S = idx.self_join(0.99, cap_hint=1000)          # 179 101 pairs: the lists must grow past the hint
+    assert len(I) == 599 * 598 // 2                       # row 0 (cosine 0.87 to the others) pairs with nobody
+    assert np.all(I < J) and np.all(np.abs(S - 1.0) <= 1e-6)
+    assert np.array_equal(I[:3], [1, 1, 1]) and np.array_equal(J[:3], [2, 3, 4])
+    assert len(idx.self_join(0.85)[0]) == 600 * 599 // 2  # a lower threshold takes row 0 in
+    idx.close()
+    l2 = FlatIndex(32, METRIC_L2, normalize=False)
+    l2.add(x[:4])
+    with pytest.raises(_lib.AnoragError):
+        l2.self_join(0.5)
+    l2.close()
+
+
+def test_find_embedding_candidates_matches_oracle():
+    from anorag_hip.graph_scans import find_embedding_candidates
+    rng = np.random.default_rng(3)
+    emb = (rng.standard_normal((20_000, 384)) * rng.uniform(0.5, 2.0, (20_000, 1))).astype(np.float32)  # un-normalised
+    q = rng.standard_normal(384).astype(np.float32)
+    got = find_embedding_candidates(emb, q, 15)
+    exp = og.find_embedding_candidates(emb, q, 15)
+    assert np.array_equal(got, exp)
+    assert len(find_embedding_candidates(emb[:7], q, 15)) == 7      # fewer rows than top_k

@@ -102,3 +102,23 @@ def test_flat_oracle_basics():
     assert isinstance(r[0], dict) and len(r) == 3 and set(r[0]) == {"index", "score", "rank", "similarity"}
     r = orc.shape_results(Dl, Il, "l2")
     assert len(r) == 3 and abs(r[0][0]["similarity"] - 1.0 / (1.0 + r[0][0]["score"])) < 1e-12
+
+
+def test_similarity_relations_oracle_matches_reference_golden():
+    """oracle/graph_scans.py vs the relations the reference's own relation_extractor.py produced
+    (tests/golden/similarity_relation_cases.json): same pairs in the same order, same similarity, weight, rank."""
+    import json, os
+    import numpy as np
+    from oracle import graph_scans as og
+    data = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "similarity_relation_cases.json")))
+    assert len(data["cases"]) >= 5
+    for case in data["cases"]:
+        emb = np.asarray(case["embeddings"], dtype=np.float32)
+        notes = [{"note_id": f"n{i:04d}"} for i in range(emb.shape[0])]
+        got = og.semantic_similarity_relations(notes, emb, case["threshold"], case["weight"])
+        exp = case["expected"]
+        assert [(r["source_id"], r["target_id"]) for r in got] == [(r["source_id"], r["target_id"]) for r in exp], case["name"]
+        for g, e in zip(got, exp):
+            assert g["metadata"]["cosine_similarity"] == e["cosine_similarity"], case["name"]
+            assert float(g["weight"]) == e["weight"], case["name"]
+            assert g["metadata"]["similarity_rank"] == e["similarity_rank"], case["name"]
