@@ -958,6 +958,7 @@ struct FinalParams {
   int64_t id_offset;
   const unsigned *ncand;     // may be null: [64] candidates seen (statistics)
   unsigned *status_host;     // pinned host memory [4][64]: candidates | overflow | flag | theta bits
+  int host_out;              // D / I are pinned host memory: fence the writes at system scope
 };
 
 __global__ __launch_bounds__(256) void k_finalize(FinalParams p) {
@@ -993,6 +994,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinalParams p) {
       I[i] = -1;
     }
   }
+  if (p.host_out) __threadfence_system();
   if (tid == 0) {
     int flag = 0;
     float theta = -__builtin_inff();
@@ -1100,6 +1102,7 @@ __global__ __launch_bounds__(256) void k_emit(EmitParams p) {
       I[i] = -1;
     }
   }
+  __threadfence_system();  // D / I may be pinned host memory (rare path: always fenced)
 }
 
 // ------------------------------------------------------------------------------------------------

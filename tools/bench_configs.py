@@ -12,6 +12,32 @@ from oracle import flat_index as orc
 out = {}
 dev = torch.device("cuda", 0)
 
+# ---- C1 (device side): 10k x 384, batch-1 top-10, host buffers (what VectorIndex.search does) -----------
+# measured first, in a quiet process: host threads left spinning by BLAS / torch / tokenizers work stretch this
+# latency-bound loop several-fold
+x_c1 = np.random.default_rng(1234).standard_normal((10_000, 384), dtype=np.float32)
+q_c1 = np.random.default_rng(4321).standard_normal((200, 384), dtype=np.float32)
+idx1 = FlatIndex(384, METRIC_IP, normalize=True); idx1.add(x_c1)
+for i in range(5): idx1.search(q_c1[i:i + 1], 10)
+t0 = time.perf_counter()
+for i in range(200): D, I = idx1.search(q_c1[i:i + 1], 10)
+gpu_us = (time.perf_counter() - t0) / 200 * 1e6
+I_c1 = I.copy()
+
+# ---- C1 (CPU oracle side) ------------------------------------------------------------------------------
+xn = orc.preprocess_vectors(x_c1)
+t0 = time.perf_counter()
+for i in range(200):
+    qn = orc.preprocess_vectors(q_c1[i:i + 1]); s = qn @ xn.T
+    part = np.argpartition(-s, 9, axis=1)[:, :10]; o = np.argsort(-np.take_along_axis(s, part, 1), axis=1)
+cpu_us = (time.perf_counter() - t0) / 200 * 1e6
+Dr, Ir = orc.flat_search(orc.preprocess_vectors(q_c1[199:200]), xn, 10, "ip")
+out["C1"] = {"config": "10k x 384, batch-1 top-10 (host in/out, synchronous)", "gpu_us_per_query": gpu_us,
+             "cpu_oracle_us_per_query": cpu_us, "ids_match_oracle": bool(np.array_equal(I_c1, Ir))}
+idx1.close()
+
+
+
 # ---- C2: 1M x 768, batch-64 top-100 ----------------------------------------------------------------------
 def build(rows, dim):
     ix = FlatIndex(dim, METRIC_IP, normalize=True); ix.reserve(rows)
@@ -71,25 +97,6 @@ out["C4"] = {"config": "bge-base-en shape (12L, H768, 12 heads, I3072, vocab 305
              "search_ms_256_queries": t_search * 1e3, "end_to_end_qps": 256 / (t_enc + t_search),
              "min_cosine_vs_f32_oracle_16": cos}
 enc.close(); idx.close()
-
-# ---- C1: 10k x 384, batch-1 top-10, host buffers (what VectorIndex.search does) -------------------------
-x = np.random.default_rng(1234).standard_normal((10_000, 384), dtype=np.float32)
-q = np.random.default_rng(4321).standard_normal((200, 384), dtype=np.float32)
-idx1 = FlatIndex(384, METRIC_IP, normalize=True); idx1.add(x)
-for i in range(5): idx1.search(q[i:i + 1], 10)
-t0 = time.perf_counter()
-for i in range(200): D, I = idx1.search(q[i:i + 1], 10)
-gpu_us = (time.perf_counter() - t0) / 200 * 1e6
-xn = orc.preprocess_vectors(x)
-t0 = time.perf_counter()
-for i in range(200):
-    qn = orc.preprocess_vectors(q[i:i + 1]); s = qn @ xn.T
-    part = np.argpartition(-s, 9, axis=1)[:, :10]; o = np.argsort(-np.take_along_axis(s, part, 1), axis=1)
-cpu_us = (time.perf_counter() - t0) / 200 * 1e6
-Dr, Ir = orc.flat_search(orc.preprocess_vectors(q[199:200]), xn, 10, "ip")
-out["C1"] = {"config": "10k x 384, batch-1 top-10 (host in/out, synchronous)", "gpu_us_per_query": gpu_us,
-             "cpu_oracle_us_per_query": cpu_us, "ids_match_oracle": bool(np.array_equal(I, Ir))}
-idx1.close()
 
 # ---- C5: dense + BM25 fusion, 200 queries, pool 80 ---------------------------------------------------------
 from retrieval.hybrid_search import HybridSearcher
