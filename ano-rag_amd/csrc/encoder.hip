@@ -538,13 +538,21 @@ __global__ __launch_bounds__(256) void k_gemm_lds(GemmParams p) {
     }
 }
 
-// 8-wave form of the same kernel: a workgroup (4 x 2 waves) owns 256 tokens x 256 features, so each byte that
-// leaves L2 feeds twice the MFMAs of the 4-wave tile (the 128 x 256 tile needs ~29 TB/s from L2 at the MFMA
-// peak, more than the L2 delivers), and two waves share each SIMD so one wave's LDS reads hide behind the
-// other's MFMAs.  Ring of three slots x 3 k-steps x 16 fragments = 144 KiB.
-template <int EPI>
+// 8-wave form of the same kernel: a workgroup (4 x 2 waves) owns 256 tokens x (32 TN) features, TN = 8 or 6, so
+// each byte that leaves L2 feeds twice the MFMAs of the 4-wave tile (the 128 x 256 tile needs ~29 TB/s from L2
+// at the MFMA peak, more than the L2 delivers), and two waves share each SIMD so one wave's LDS reads hide
+// behind the other's MFMAs.  Ring of three slots x 3 k-steps x (8 + TN) fragments (<= 144 KiB).  TN = 6 exists
+// for the grid shape: at 16 K tokens a 768-wide output is 192 workgroups of 256 x 256 (a 256-CU chip 3/4 busy)
+// but exactly 256 of 256 x 192; the launcher picks the tile with the fewest workgroup rounds x tile width.
+// When 3 x (8 + TN) fragments do not divide over the 8 waves, the surplus copies repeat the first fragments
+// (same bytes to the same LDS address).
+__device__ __forceinline__ void gemm_glds16(const uint4 *g, uint4 *l) { __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0); }
+
+template <int EPI, int TN>
 __global__ __launch_bounds__(512) void k_gemm_lds8(GemmParams p) {
-  constexpr int TM = 8, TN = 8, S = 3, F = TM + TN, LPW = S * F / 8;  // fragment copies per wave per stage
+  constexpr int TM = 8, S = 3, F = TM + TN, NW = TN / 2;  // NW: feature tiles per wave
+  constexpr int LPW = (S * F + 7) / 8;                      // fragment copies per wave per stage
+  static_assert(LPW == 6, "the counted vmcnt below assumes six copies per wave per stage");
   extern __shared__ uint4 g_lds[];  // ring [3][S][F][64]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int NG = (p.NB + TN - 1) / TN;
@@ -555,7 +563,7 @@ __global__ __launch_bounds__(512) void k_gemm_lds8(GemmParams p) {
   int dst[LPW];
 #pragma unroll
   for (int i = 0; i < LPW; ++i) {
-    const int f = wave * LPW + i, ks = f / F, idx = f % F;
+    const int f = (wave * LPW + i) % (S * F), ks = f / F, idx = f % F;
     if (idx < TM) {
       const int64_t tb = tb0 + idx < p.TB ? tb0 + idx : p.TB - 1;
       src[i] = p.act + (tb * p.KB + ks) * 64 + lane;
@@ -565,20 +573,20 @@ __global__ __launch_bounds__(512) void k_gemm_lds8(GemmParams p) {
     }
     dst[i] = (ks * F + idx) * 64;
   }
-  floatx16 acc[2][4];
+  floatx16 acc[2][NW];
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
-    for (int n = 0; n < 4; ++n)
+    for (int n = 0; n < NW; ++n)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
   const int nstages = p.KB / S;
   constexpr int BUF = S * F * 64;  // uint4 per ring slot
 #pragma unroll
-  for (int i = 0; i < LPW; ++i) __builtin_amdgcn_global_load_lds(src[i], g_lds + dst[i], 16, 0, 0);
+  for (int i = 0; i < LPW; ++i) gemm_glds16(src[i], g_lds + dst[i]);
   if (nstages > 1) {
 #pragma unroll
-    for (int i = 0; i < LPW; ++i) __builtin_amdgcn_global_load_lds(src[i] + (int64_t)S * 64, g_lds + BUF + dst[i], 16, 0, 0);
+    for (int i = 0; i < LPW; ++i) gemm_glds16(src[i] + (int64_t)S * 64, g_lds + BUF + dst[i]);
   }
   for (int s = 0; s < nstages; ++s) {
     if (s + 1 < nstages) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // LPW copies of stage s+1 stay in flight
@@ -588,21 +596,20 @@ __global__ __launch_bounds__(512) void k_gemm_lds8(GemmParams p) {
     if (s + 2 < nstages) {
       uint4 *slot = g_lds + ((s + 2) % 3) * BUF;
 #pragma unroll
-      for (int i = 0; i < LPW; ++i)
-        __builtin_amdgcn_global_load_lds(src[i] + (int64_t)(s + 2) * S * 64, slot + dst[i], 16, 0, 0);
+      for (int i = 0; i < LPW; ++i) gemm_glds16(src[i] + (int64_t)(s + 2) * S * 64, slot + dst[i]);
     }
     const uint4 *L = g_lds + (s % 3) * BUF + lane;
 #pragma unroll
     for (int ks = 0; ks < S; ++ks) {
-      half8 a[2], b[4];
+      half8 a[2], b[NW];
 #pragma unroll
       for (int m = 0; m < 2; ++m) a[m] = __builtin_bit_cast(half8, L[(ks * F + 2 * wm + m) * 64]);
 #pragma unroll
-      for (int n = 0; n < 4; ++n) b[n] = __builtin_bit_cast(half8, L[(ks * F + TM + 4 * wn + n) * 64]);
+      for (int n = 0; n < NW; ++n) b[n] = __builtin_bit_cast(half8, L[(ks * F + TM + NW * wn + n) * 64]);
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
+        for (int n = 0; n < NW; ++n) {
           if (EPI == EPI_VT) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m], b[n], acc[m][n], 0, 0, 0);
           else acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[n], a[m], acc[m][n], 0, 0, 0);
         }
@@ -612,9 +619,9 @@ __global__ __launch_bounds__(512) void k_gemm_lds8(GemmParams p) {
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
+    for (int n = 0; n < NW; ++n) {
       const int64_t tb = tb0 + 2 * wm + m;
-      const int nb = nb0 + 4 * wn + n;
+      const int nb = nb0 + NW * wn + n;
       if (tb < p.TB && nb < p.NB) gemm_store_tile<EPI>(p, acc[m][n], tb, nb, lane);
     }
 }
@@ -760,6 +767,7 @@ struct LayerW {
 struct anr_encoder {
   anr_encoder_config cfg{};
   int device = 0;
+  int n_cu = 256;
   hipStream_t stream = nullptr;
   std::mutex mu;
   float *word = nullptr, *pos = nullptr, *type = nullptr, *eg = nullptr, *eb = nullptr;
@@ -834,6 +842,17 @@ int plain_copy(const float *host, int64_t n, float **dst) {
   return ANR_OK;
 }
 
+template <int EPI, int TN>
+void launch_gemm8(anr_encoder *e, GemmParams &g, int64_t blocks) {
+  constexpr int lds8 = 3 * 3 * (8 + TN) * 1024;
+  static bool attr8 = false;
+  if (!attr8) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_lds8<EPI, TN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds8);
+    attr8 = true;
+  }
+  hipLaunchKernelGGL((k_gemm_lds8<EPI, TN>), dim3((unsigned)blocks), dim3(512), lds8, e->stream, g);
+}
+
 template <int EPI>
 void launch_gemm(anr_encoder *e, GemmParams &g) {
   static const bool simple = getenv("ANORAG_GEMM_SIMPLE") != nullptr;  // developer switch: the LDS-free kernel
@@ -845,14 +864,11 @@ void launch_gemm(anr_encoder *e, GemmParams &g) {
   }
   static const bool wide = getenv("ANORAG_GEMM_NARROW") == nullptr;  // developer switch: the 4-wave tile everywhere
   if (wide && g.KB % 3 == 0 && g.TB >= 8 * 16) {
-    const int64_t blocks8 = ceil_div(g.TB, 8) * ceil_div(g.NB, 8);
-    constexpr int lds8 = 3 * 3 * 16 * 1024;
-    static bool attr8 = false;
-    if (!attr8) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_lds8<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds8);
-      attr8 = true;
-    }
-    hipLaunchKernelGGL((k_gemm_lds8<EPI>), dim3((unsigned)blocks8), dim3(512), lds8, e->stream, g);
+    // tile width by grid shape: fewest rounds of workgroups over the CUs, weighted by the work per workgroup
+    const int64_t b8 = ceil_div(g.TB, 8) * ceil_div(g.NB, 8), b6 = ceil_div(g.TB, 8) * ceil_div(g.NB, 6);
+    const int64_t cost8 = ceil_div(b8, e->n_cu) * 8, cost6 = ceil_div(b6, e->n_cu) * 6;
+    if (cost6 < cost8) launch_gemm8<EPI, 6>(e, g, b6);
+    else launch_gemm8<EPI, 8>(e, g, b8);
     return;
   }
   const int64_t blocks = ceil_div(g.TB, 4) * ceil_div(g.NB, 8);
@@ -926,6 +942,7 @@ int anr_encoder_create(const anr_encoder_config *cfg, int32_t device, anr_encode
   anr_encoder *e = new anr_encoder();
   e->cfg = c;
   e->device = device;
+  e->n_cu = device_cu_count(device);
   e->layers.resize(c.n_layers);
   if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
     delete e;
