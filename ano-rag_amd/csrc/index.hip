@@ -260,13 +260,13 @@ int launch_scan(anr_index *h, const ScanParams &p, hipStream_t st, int max_grid,
   return ANR_OK;
 }
 
-template <int S>
-hipError_t launch_join(const JoinParams &jp, int64_t n_blocks, hipStream_t st) {
-  constexpr int ring_bytes = 3 * S * 16 * 1024;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join<S>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, ring_bytes);
+hipError_t launch_join(const JoinParams &jp, int64_t n_slots, hipStream_t st, int n_cu) {
+  constexpr int slots_bytes = 2 * 4 * 16 * 1024;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_r), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     slots_bytes);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((k_join<S>), dim3((unsigned)n_blocks), dim3(512), ring_bytes, st, jp);
+  const int64_t persistent = std::min<int64_t>(n_slots, std::max(8, n_cu / 8 * 8));  // a multiple of 8: slot % 8 = XCD
+  hipLaunchKernelGGL(k_join_r, dim3((unsigned)persistent), dim3(512), slots_bytes, st, jp);
   return hipGetLastError();
 }
 
@@ -1055,7 +1055,8 @@ int anr_index_self_join(anr_index *h, float threshold, int64_t cap, int64_t *I_h
   const double eps = 2.0 * xmax * xerr + (double)xerr * xerr + 2.0 * h->dimp * 5.9604645e-8 * (double)xmax * xmax;
   const int64_t n_tiles = ceil_div(h->ntotal, kTileRows);
   const int nblk = (int)ceil_div(n_tiles, 8);
-  const int64_t n_blocks = (int64_t)nblk * (nblk + 1) / 2;
+  const PatchGrid pg = make_patch_grid(nblk, nblk);
+  const int64_t n_blocks = pg.grid();
   if (n_blocks > 0x7fffffffLL) return fail(ANR_EINVAL, "too many rows for one self-join launch");
   // candidates = pairs within eps below the threshold as well: a little more room than the caller's cap
   const int64_t ccap = cap + cap / 4 + 65536;
@@ -1080,12 +1081,14 @@ int anr_index_self_join(anr_index *h, float threshold, int64_t cap, int64_t *I_h
   jp.n_rows = h->ntotal;
   jp.n_tiles = n_tiles;
   jp.nblk = nblk;
+  jp.pg = pg;
+  jp.n_slots = n_blocks;
   jp.thr_lo = (float)((double)threshold - eps - 1e-7 * (std::fabs((double)threshold) + 1.0));
   jp.cand = cand;
   jp.cap = (unsigned long long)ccap;
   jp.count = counts;
   hipError_t e = hipSuccess;
-  e = h->kb % 3 == 0 ? launch_join<3>(jp, n_blocks, st) : launch_join<2>(jp, n_blocks, st);
+  e = launch_join(jp, n_blocks, st, h->n_cu);
   unsigned long long hc[2] = {0, 0};
   if (e == hipSuccess) e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(hc, counts, sizeof(unsigned long long), hipMemcpyDeviceToHost, st);

@@ -1166,48 +1166,55 @@ __global__ __launch_bounds__(256) void k_merge(MergeParams p) {
 // of the reference's N x N similarity matrix (graph/relation_extractor.py:769-782 and :604-608) without
 // ever forming the matrix.  MFMA-bound: a workgroup (8 waves, 4 x 2) multiplies a 256-row block against a
 // 256-row block of the SAME blocked f16 image (an x16 tile is a valid A and a valid B operand), operands
-// staged once per workgroup through a three-slot LDS ring by global_load_lds; hits at or above
-// threshold - eps go to a candidate list and are re-scored exactly (f32 rows, f64 accumulate) afterwards.
+// staged once per workgroup in LDS; hits at or above threshold - eps go to a candidate list and are
+// re-scored exactly (f32 rows, f64 accumulate) afterwards.
 // ------------------------------------------------------------------------------------------------
-// 16 bytes per lane global -> LDS without passing through registers.  A plain function on purpose: called with
-// template-dependent arguments straight from a kernel template, the builtin makes the host-side instantiation of
-// that kernel fail silently (no host stub is emitted and the launch symbol stays undefined).
-__device__ __forceinline__ void glds16(const uint4 *g, uint4 *l) { __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0); }
-
 struct JoinParams {
   const uint4 *x16;
   int kb;
   int64_t n_rows, n_tiles;
   int nblk;               // 256-row blocks
+  PatchGrid pg;           // XCD-aware placement of the nblk x nblk block pairs (the lower triangle exits)
+  int64_t n_slots;        // patch slots to walk (k_join_r: persistent workgroups)
   float thr_lo;           // threshold - eps
   uint2 *cand;            // [cap] (i, j)
   unsigned long long cap;
   unsigned long long *count;
 };
 
-template <int S>
-__global__ __launch_bounds__(512) void k_join(JoinParams p) {
-  constexpr int TM = 8, TN = 8, F = TM + TN, LPW = S * F / 8;
-  extern __shared__ uint4 lds[];  // ring [3][S][F][64]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // block pair (bi <= bj) from the linear index over the upper triangle, column by column
-  const long long t = blockIdx.x;
-  long long bj = (long long)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-  while (bj * (bj + 1) / 2 > t) --bj;
-  while ((bj + 1) * (bj + 2) / 2 <= t) ++bj;
-  const long long bi = t - bj * (bj + 1) / 2;
-  const int64_t tb0 = bi * TM, nb0 = bj * TN;
+// The operand fragments travel global -> VGPR -> LDS (ds_write_b128): two LDS slots of four k-steps; the
+// fragments of stage s + 1 wait in registers while stage s is multiplied and are written into the other slot in
+// the middle of it.  Variants measured on this kernel and dropped, all within 5 % of each other (820-880
+// TFLOP/s at K = 768, ~42 % MFMA utilisation at the 1.9 GHz the chip holds under this load): operands through
+// global_load_lds and a three-slot ring; 4 waves x (128 x 128) with double-buffered fragment reads (half the
+// LDS reads per MFMA); non-persistent workgroups; linear instead of XCD-patched tile order (L2 hit rate 76 % with
+// the patches).  What is left is the fill and drain of the 12-stage K loop per tile and the epilogue (~25 % of
+// a tile's time at K = 768; 934 TFLOP/s at 300 k rows, 891 at K = 1024).
+__global__ __launch_bounds__(512) void k_join_r(JoinParams p) {
+  constexpr int TM = 8, TN = 8, S = 4, F = TM + TN, LPW = S * F / 8;
+  extern __shared__ uint4 lds[];  // [2][S][F][64]
+  // the wave index as a scalar: everything derived from it (fragment offsets, LDS slots) then lives in SGPRs
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // persistent: one workgroup per CU walks its share of the patch slots (slot = blockIdx + i * gridDim keeps the
+  // slot -> XCD relation of patch_tile); re-dispatching a 512-thread, 128-KiB-LDS workgroup per tile left each CU
+  // idle for ~8 us between 22-us tiles
+  for (int64_t slot = blockIdx.x; slot < p.n_slots; slot += gridDim.x) {
+  int bi, bj;
+  if (!patch_tile(p.pg, slot, bi, bj) || bi > bj) continue;
+  const int64_t tb0 = (int64_t)bi * TM, nb0 = (int64_t)bj * TN;
   const int wm = wave >> 1, wn = wave & 1;
-  const uint4 *src[LPW];
+  const u32x4 *xl = reinterpret_cast<const u32x4 *>(p.x16) + lane;  // native vectors: HIP's uint4 struct kept the staging array in scratch
+  int64_t src[LPW];  // uniform offsets (uint4 units) of this wave's fragments at k-step 0
   int dst[LPW];
 #pragma unroll
   for (int i = 0; i < LPW; ++i) {
     const int f = wave * LPW + i, ks = f / F, idx = f % F;
     int64_t tile = idx < TM ? tb0 + idx : nb0 + idx - TM;
     if (tile >= p.n_tiles) tile = p.n_tiles - 1;  // clamp: masked at emit
-    src[i] = p.x16 + (tile * p.kb + ks) * 64 + lane;
+    src[i] = (tile * p.kb + ks) * 64;
     dst[i] = (ks * F + idx) * 64;
   }
+  u32x4 *ldsl = reinterpret_cast<u32x4 *>(lds) + lane;
   floatx16 acc[2][4];
 #pragma unroll
   for (int m = 0; m < 2; ++m)
@@ -1216,29 +1223,19 @@ __global__ __launch_bounds__(512) void k_join(JoinParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
   const int nstages = p.kb / S;
-  constexpr int BUF = S * F * 64;
+  constexpr int BUF = S * F * 64;  // uint4 per slot
+  u32x4 stg[LPW];
 #pragma unroll
-  for (int i = 0; i < LPW; ++i) glds16(src[i], lds + dst[i]);
+  for (int i = 0; i < LPW; ++i) stg[i] = xl[src[i]];
+#pragma unroll
+  for (int i = 0; i < LPW; ++i) ldsl[dst[i]] = stg[i];
   if (nstages > 1) {
 #pragma unroll
-    for (int i = 0; i < LPW; ++i) glds16(src[i] + (int64_t)S * 64, lds + BUF + dst[i]);
+    for (int i = 0; i < LPW; ++i) stg[i] = xl[src[i] + (int64_t)S * 64];
   }
+  __syncthreads();
   for (int s = 0; s < nstages; ++s) {
-    if (s + 1 < nstages) {  // the LPW copies of stage s+1 may stay in flight
-      if (S == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    if (s + 2 < nstages) {
-      uint4 *slot = lds + ((s + 2) % 3) * BUF;
-#pragma unroll
-      for (int i = 0; i < LPW; ++i)
-        glds16(src[i] + (int64_t)(s + 2) * S * 64, slot + dst[i]);
-    }
-    const uint4 *L = lds + (s % 3) * BUF + lane;
+    const uint4 *L = lds + (s & 1) * BUF + lane;
 #pragma unroll
     for (int ks = 0; ks < S; ++ks) {
       half8 a[2], b[4];
@@ -1250,26 +1247,49 @@ __global__ __launch_bounds__(512) void k_join(JoinParams p) {
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[n], a[m], acc[m][n], 0, 0, 0);
+      if (ks == 1 && s + 1 < nstages) {
+        // stage s + 1 has had a k-step and a half to arrive: park it in the other slot (free since the barrier
+        // that ended stage s - 1) and request stage s + 2
+        __builtin_amdgcn_sched_barrier(0);
+        u32x4 *W = ldsl + ((s + 1) & 1) * BUF;
+#pragma unroll
+        for (int i = 0; i < LPW; ++i) W[dst[i]] = stg[i];
+        if (s + 2 < nstages) {
+#pragma unroll
+          for (int i = 0; i < LPW; ++i) stg[i] = xl[src[i] + (int64_t)(s + 2) * S * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
+    // LDS writes of this wave done, then the workgroup barrier — NOT __syncthreads(), whose vmcnt(0) would also
+    // wait for the stage s + 2 loads just requested
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   }
-  // C rows = rows of the j tile, C columns = rows of the i tile.  Two passes over the accumulators: count the
-  // hits, reserve the workgroup's slots with ONE atomic (a counter that every hit bumped serialised at
-  // ~12 ns per hit), then write
+  // C rows = rows of the j tile, C columns = rows of the i tile.  Per accumulator tile a 16-bit hit mask
+  // (value test from the registers, i < j < n test as integer masks), then: count, reserve the workgroup's slots
+  // with ONE atomic (a counter that every hit bumped serialised at ~12 ns per hit), write (i, j) from the masks
   __shared__ unsigned wave_hits[8];
   __shared__ unsigned long long block_base;
+  unsigned hm[2][4];
   unsigned mine = 0;
+  const int n_rows = (int)p.n_rows;
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
-      const int64_t gi = (tb0 + 2 * wm + m) * 32 + (lane & 31);
-      const int64_t gj0 = (nb0 + 4 * wn + n) * 32 + 4 * (lane >> 5);
+      const int gi = (int)(tb0 + 2 * wm + m) * 32 + (lane & 31);
+      const int gj0 = (int)(nb0 + 4 * wn + n) * 32 + 4 * (lane >> 5);
+      unsigned valid = 0, hit = 0;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int64_t gj = gj0 + (r & 3) + 8 * (r >> 2);
-        mine += (gi < gj && gj < p.n_rows && acc[m][n][r] >= p.thr_lo) ? 1u : 0u;
+        const int gj = gj0 + (r & 3) + 8 * (r >> 2);
+        valid |= (gi < gj && gj < n_rows) ? (1u << r) : 0u;
+        hit |= (acc[m][n][r] >= p.thr_lo) ? (1u << r) : 0u;
       }
+      hm[m][n] = hit & valid;
+      mine += (unsigned)__popc(hm[m][n]);
     }
   unsigned incl = mine;  // inclusive prefix over the lanes
 #pragma unroll
@@ -1292,17 +1312,17 @@ __global__ __launch_bounds__(512) void k_join(JoinParams p) {
     for (int m = 0; m < 2; ++m)
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
-        const int64_t gi = (tb0 + 2 * wm + m) * 32 + (lane & 31);
-        const int64_t gj0 = (nb0 + 4 * wn + n) * 32 + 4 * (lane >> 5);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t gj = gj0 + (r & 3) + 8 * (r >> 2);
-          if (gi < gj && gj < p.n_rows && acc[m][n][r] >= p.thr_lo) {
-            if (k < p.cap) p.cand[k] = make_uint2((unsigned)gi, (unsigned)gj);
-            ++k;
-          }
+        const unsigned gi = (unsigned)((tb0 + 2 * wm + m) * 32 + (lane & 31));
+        const unsigned gj0 = (unsigned)((nb0 + 4 * wn + n) * 32 + 4 * (lane >> 5));
+        unsigned h = hm[m][n];
+        while (h) {
+          const int r = __ffs(h) - 1;
+          h &= h - 1;
+          if (k < p.cap) p.cand[k] = make_uint2(gi, gj0 + (r & 3) + 8 * (r >> 2));
+          ++k;
         }
       }
+  }
   }
 }
 
