@@ -168,6 +168,13 @@ def test_async_pipelined_search_equals_sync():
         assert np.array_equal(I.cpu().numpy(), I_all[b * 64:(b + 1) * 64])
         assert np.array_equal(D.cpu().numpy(), D_all[b * 64:(b + 1) * 64])
     assert idx.last_stats()["n_queries"] == 320
+    # ANR_OPT_STREAMS = 1: batches strictly one after the other on a single stream — same answers
+    from anorag_hip._lib import OPT_STREAMS, AnoragError
+    idx.set_option(OPT_STREAMS, 1)
+    D1, I1 = idx.search(q, 30)
+    assert np.array_equal(I1, I_all) and np.array_equal(D1, D_all)
+    with pytest.raises(AnoragError):
+        idx.set_option(OPT_STREAMS, 4)
     idx.close()
 
 
