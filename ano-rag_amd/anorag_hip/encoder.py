@@ -24,7 +24,7 @@ import numpy as np
 from . import _lib
 from ._lib import EncoderConfig
 
-_PREFIXES = ("bert.", "roberta.", "xlm_roberta.", "model.", "0.auto_model.", "auto_model.")
+_PREFIXES = ("bert.", "roberta.", "xlm_roberta.", "mpnet.", "model.", "0.auto_model.", "auto_model.")
 
 
 def _strip(name: str) -> str:
@@ -50,6 +50,8 @@ def map_hf_name(name: str) -> Optional[str]:
     }
     if n in table:
         return table[n]
+    if n == "encoder.relative_attention_bias.weight":
+        return "rel.weight"  # MPNet: [buckets, heads]; load_weights turns it into the per-offset table "rel.bias"
     if not n.startswith("encoder.layer."):
         return None
     rest = n[len("encoder.layer."):]
@@ -57,13 +59,15 @@ def map_hf_name(name: str) -> Optional[str]:
     sub = {
         "attention.self.query": "q", "attention.self.key": "k", "attention.self.value": "v",
         "attention.output.dense": "o", "intermediate.dense": "ffn1", "output.dense": "ffn2",
+        # MPNet names
+        "attention.attn.q": "q", "attention.attn.k": "k", "attention.attn.v": "v", "attention.attn.o": "o",
     }
     for k, v in sub.items():
         if tail == k + ".weight":
             return f"L{li}.{v}.w"
         if tail == k + ".bias":
             return f"L{li}.{v}.b"
-    ln = {"attention.output.LayerNorm": "ln1", "output.LayerNorm": "ln2"}
+    ln = {"attention.output.LayerNorm": "ln1", "output.LayerNorm": "ln2", "attention.LayerNorm": "ln1"}
     for k, v in ln.items():
         if tail == k + ".weight":
             return f"L{li}.{v}.g"
@@ -77,8 +81,8 @@ def read_model_dir(path: str) -> Dict:
     with open(os.path.join(path, "config.json")) as f:
         hf = json.load(f)
     mtype = hf.get("model_type", "bert")
-    if mtype not in ("bert", "roberta", "xlm-roberta"):
-        raise ValueError(f"model_type {mtype!r} is not supported by the HIP encoder (bert / roberta / xlm-roberta)")
+    if mtype not in ("bert", "roberta", "xlm-roberta", "mpnet"):
+        raise ValueError(f"model_type {mtype!r} is not supported by the HIP encoder (bert / roberta / xlm-roberta / mpnet)")
     if hf.get("position_embedding_type", "absolute") != "absolute":
         raise ValueError("only absolute position embeddings are supported")
     act = hf.get("hidden_act", "gelu")
@@ -117,6 +121,25 @@ def read_model_dir(path: str) -> Dict:
     }
 
 
+def relative_bias_table(weight: np.ndarray, span: int, max_distance: int = 128) -> np.ndarray:
+    """MPNet's relative position bias as a per-offset table: out[h][(key - query) + span - 1] (float32
+    [heads][2 span - 1]) from relative_attention_bias.weight [buckets][heads], with the bucket function of
+    transformers' MPNetEncoder.relative_position_bucket (bidirectional T5 buckets)."""
+    import math
+    import torch  # same float32 log as transformers uses: bucket edges must not move by an ulp
+    buckets, heads = weight.shape
+    rel = torch.arange(-(span - 1), span, dtype=torch.long)  # key - query
+    n = -rel
+    half = buckets // 2
+    ret = (n < 0).to(torch.long) * half
+    n = torch.abs(n)
+    max_exact = half // 2
+    large = max_exact + (torch.log(n.float() / max_exact) / math.log(max_distance / max_exact) * (half - max_exact)).to(torch.long)
+    large = torch.min(large, torch.full_like(large, half - 1))
+    ret = ret + torch.where(n < max_exact, n, large)
+    return np.ascontiguousarray(weight[ret.numpy()].T, dtype=np.float32)  # [heads][2 span - 1]
+
+
 def load_weights(path: str) -> Dict[str, np.ndarray]:
     st = os.path.join(path, "model.safetensors")
     if os.path.exists(st):
@@ -131,6 +154,13 @@ def load_weights(path: str) -> Dict[str, np.ndarray]:
         name = map_hf_name(k)
         if name is not None:
             out[name] = np.ascontiguousarray(v, dtype=np.float32)
+    if "rel.weight" in out:  # MPNet
+        with open(os.path.join(path, "config.json")) as f:
+            hf = json.load(f)
+        span = int(hf["max_position_embeddings"]) - (int(hf.get("pad_token_id", 1)) + 1)
+        out["rel.bias"] = relative_bias_table(out.pop("rel.weight"), span)
+        if "emb.type" not in out:  # no token-type embeddings in MPNet: a zero row keeps the embedding kernel uniform
+            out["emb.type"] = np.zeros((1, out["emb.word"].shape[1]), dtype=np.float32)
     return out
 
 

@@ -634,6 +634,8 @@ struct AttnParams {
   int B, Lp, H, heads, dh;
   float scale;
   _Float16 *ctx;      // act layout [TB][H/16][64][8]
+  const float *relbias;  // optional (MPNet): [heads][2 rel_span - 1], added to the scaled score at index key - query + rel_span - 1
+  int rel_span;
 };
 
 template <int DH>
@@ -674,7 +676,9 @@ __global__ __launch_bounds__(256) void k_attention(AttnParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = kbk * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      S[r] = key < len ? S[r] * p.scale : -__builtin_inff();
+      float sc = S[r] * p.scale;
+      if (p.relbias) sc += p.relbias[(int64_t)hd * (2 * p.rel_span - 1) + (key < len ? key : 0) - (qb * 32 + (lane & 31)) + p.rel_span - 1];
+      S[r] = key < len ? sc : -__builtin_inff();
       mx = fmaxf(mx, S[r]);
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32));
@@ -771,6 +775,8 @@ struct anr_encoder {
   hipStream_t stream = nullptr;
   std::mutex mu;
   float *word = nullptr, *pos = nullptr, *type = nullptr, *eg = nullptr, *eb = nullptr;
+  float *relbias = nullptr;  // optional relative position bias table (MPNet)
+  int rel_span = 0;
   bool have_emb[5] = {false, false, false, false, false};
   std::vector<LayerW> layers;
   bool finalized = false;
@@ -956,7 +962,7 @@ int anr_encoder_destroy(anr_encoder *e) {
   if (!e) return ANR_OK;
   DeviceGuard g(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
-  enc_free(e->word); enc_free(e->pos); enc_free(e->type); enc_free(e->eg); enc_free(e->eb);
+  enc_free(e->word); enc_free(e->pos); enc_free(e->type); enc_free(e->eg); enc_free(e->eb); enc_free(e->relbias);
   for (auto &l : e->layers) {
     enc_free(l.wqk); enc_free(l.wv); enc_free(l.wo); enc_free(l.w1); enc_free(l.w2);
     enc_free(l.bqk); enc_free(l.bv); enc_free(l.bo); enc_free(l.b1); enc_free(l.b2);
@@ -989,6 +995,13 @@ int anr_encoder_set_tensor(anr_encoder *e, const char *name, const float *data, 
   if (s == "emb.type") { ANR_TRY(need((int64_t)c.type_vocab_size * H)); e->have_emb[2] = true; return pack_rows(e, data, c.type_vocab_size, H, &e->type); }
   if (s == "emb.ln.g") { ANR_TRY(need(H)); e->have_emb[3] = true; return pack_rows(e, data, 1, H, &e->eg); }
   if (s == "emb.ln.b") { ANR_TRY(need(H)); e->have_emb[4] = true; return pack_rows(e, data, 1, H, &e->eb); }
+  if (s == "rel.bias") {
+    // optional: additive attention bias by relative position, [heads][2 span - 1] with span = usable positions
+    const int span = c.max_positions - c.pos_offset;
+    ANR_TRY(need((int64_t)c.n_heads * (2 * span - 1)));
+    e->rel_span = span;
+    return plain_copy(data, n, &e->relbias);
+  }
   if (s.size() < 4 || s[0] != 'L') return fail(ANR_EINVAL, "unknown tensor name %s", name);
   const size_t dot = s.find('.');
   if (dot == std::string::npos) return fail(ANR_EINVAL, "unknown tensor name %s", name);
@@ -1077,6 +1090,7 @@ int anr_encoder_forward(anr_encoder *e, const int32_t *ids, const int32_t *lengt
     ap.qk = reinterpret_cast<const uint4 *>(e->qk); ap.vt = reinterpret_cast<const uint4 *>(e->vt);
     ap.lens = e->d_lens; ap.B = B; ap.Lp = Lp; ap.H = H; ap.heads = c.n_heads; ap.dh = dh;
     ap.scale = 1.0f / sqrtf((float)dh); ap.ctx = e->ctx;
+    ap.relbias = e->relbias; ap.rel_span = e->rel_span;
     const int64_t aw = (int64_t)B * c.n_heads * (Lp / 32);
     if (dh == 32) hipLaunchKernelGGL(k_attention<32>, dim3((unsigned)ceil_div(aw, 4)), dim3(256), 0, st, ap);
     else if (dh == 64) hipLaunchKernelGGL(k_attention<64>, dim3((unsigned)ceil_div(aw, 4)), dim3(256), 0, st, ap);

@@ -157,7 +157,7 @@ int anr_fuse_lists(int32_t device, int32_t method, int64_t nq, const int64_t *id
 /* ------------------------------------------------------------------------------------------------
  * Sentence encoder: replaces SentenceTransformer.encode as called at
  * vector_store/embedding_manager.py:392-399 (and :357) — transformer forward + pooling + optional L2
- * normalisation for BERT-family models (bert / roberta / xlm-roberta).  Tokenisation is host work.
+ * normalisation for BERT-family models (bert / roberta / xlm-roberta / mpnet).  Tokenisation is host work.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct anr_encoder anr_encoder;
 typedef struct anr_encoder_config {
@@ -173,7 +173,10 @@ int anr_encoder_create(const anr_encoder_config *cfg, int32_t device, anr_encode
 int anr_encoder_destroy(anr_encoder *e);
 /* Upload one float32 tensor by name (row-major, nn.Linear weights as [out][in]):
  *   emb.word emb.pos emb.type emb.ln.g emb.ln.b
- *   L<i>.{q,k,v,o,ffn1,ffn2}.{w,b}   L<i>.ln1.{g,b} (after attention)   L<i>.ln2.{g,b} (after the FFN) */
+ *   L<i>.{q,k,v,o,ffn1,ffn2}.{w,b}   L<i>.ln1.{g,b} (after attention)   L<i>.ln2.{g,b} (after the FFN)
+ *   rel.bias (optional, MPNet): [n_heads][2 P - 1], P = max_positions - pos_offset — added to the scaled
+ *   attention score of (query i, key j) at index j - i + P - 1 (all-mpnet-base-v2, the reference's second
+ *   fallback model, embedding_manager.py:218-219) */
 int anr_encoder_set_tensor(anr_encoder *e, const char *name, const float *data, int64_t n_elements);
 int anr_encoder_finalize(anr_encoder *e); /* fails if a tensor is missing */
 /* ids [B][L] (right-padded), lengths [B] = number of real tokens per row (the attention mask), type_ids

@@ -5,7 +5,7 @@ CPU restatement of what the reference gets from ``self.model.encode(...)`` (vect
 here: sentence-transformers (>= 2.2.0, requirements.txt:15) on top of transformers / torch.  Restated from
 its published pipeline: texts sorted by length (longest first) -> batches -> HF
 tokenizer (padding to the longest, truncation to max_seq_length) -> ``AutoModel`` forward (here
-``transformers.BertModel`` / ``XLMRobertaModel`` in float32 on the CPU, which IS the code sentence-transformers
+``transformers.BertModel`` / ``XLMRobertaModel`` / ``MPNetModel`` in float32 on the CPU, which IS the code sentence-transformers
 calls) -> Pooling (masked mean: ``sum(h * mask) / clamp(sum(mask), 1e-9)``, or CLS) -> ``F.normalize(p=2, dim=1)``.
 
 PARITY UNPINNED for real checkpoints: no model weights / vocab exist in the container and the reference has no
@@ -25,7 +25,7 @@ def make_synthetic_model(path: str, *, layers=6, hidden=384, heads=12, intermedi
                          pooling="mean", seed=0, weight_std=0.05, model_type="bert") -> str:
     """Write an HF/sentence-transformers style model directory with seeded random weights."""
     import torch
-    from transformers import BertConfig, BertModel, XLMRobertaConfig, XLMRobertaModel
+    from transformers import BertConfig, BertModel, MPNetConfig, MPNetModel, XLMRobertaConfig, XLMRobertaModel
 
     os.makedirs(path, exist_ok=True)
     torch.manual_seed(seed)
@@ -47,6 +47,12 @@ def make_synthetic_model(path: str, *, layers=6, hidden=384, heads=12, intermedi
                          intermediate_size=intermediate, max_position_embeddings=max_pos, type_vocab_size=2,
                          initializer_range=weight_std, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
         model = BertModel(cfg, add_pooling_layer=False)
+    elif model_type == "mpnet":  # all-mpnet-base-v2 family: relative position bias shared by all layers
+        cfg = MPNetConfig(vocab_size=vocab, hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=heads,
+                          intermediate_size=intermediate, max_position_embeddings=max_pos + 2, pad_token_id=1,
+                          relative_attention_num_buckets=32, initializer_range=weight_std, hidden_dropout_prob=0.0,
+                          attention_probs_dropout_prob=0.0)
+        model = MPNetModel(cfg, add_pooling_layer=False)
     else:
         cfg = XLMRobertaConfig(vocab_size=vocab, hidden_size=hidden, num_hidden_layers=layers,
                                num_attention_heads=heads, intermediate_size=intermediate,

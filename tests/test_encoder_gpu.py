@@ -62,3 +62,21 @@ def test_xlm_roberta_position_offset(tmp_path):
     """bge-m3 family (XLM-R): position ids start at padding_idx + 1, one token type."""
     _check(tmp_path, n=16, layers=2, hidden=256, heads=4, intermediate=1024, pooling="cls", model_type="xlm-roberta",
            max_pos=128)
+
+
+def test_mpnet_relative_position_bias(tmp_path):
+    """all-mpnet-base-v2 family (the reference's second fallback model, embedding_manager.py:218-219): bucketed
+    relative position bias added to the attention scores in every layer, no token types, positions from
+    padding_idx + 1; mean pooling.  Sequences longer than one 32-key block exercise far buckets."""
+    d = oenc.make_synthetic_model(str(tmp_path / "mp"), layers=3, hidden=256, heads=8, intermediate=1024, pooling="mean",
+                                  model_type="mpnet", max_pos=256)
+    sents = (oenc.synthetic_sentences(d, 12, seed=5, min_words=2, max_words=12)
+             + oenc.synthetic_sentences(d, 6, seed=6, min_words=60, max_words=140))
+    from anorag_hip.encoder import SentenceEncoder
+    ref = oenc.encode(d, sents, batch_size=6, normalize=True)
+    enc = SentenceEncoder(d)
+    got = enc.encode(sents, batch_size=6, normalize_embeddings=True)
+    cos = np.sum(got * ref, axis=1)
+    assert cos.min() >= 0.9995, cos.min()
+    assert np.max(np.abs(got - ref)) <= 5e-3
+    enc.close()
