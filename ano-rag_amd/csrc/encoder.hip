@@ -448,6 +448,64 @@ __global__ __launch_bounds__(256) void k_gemm(GemmParams p) {
       if (tb0 + m < p.TB && nb0 + n < p.NB) gemm_store_tile<EPI>(p, acc[m][n], tb0 + m, nb0 + n, lane);
 }
 
+// Skinny GEMM for short and medium inputs (a single query up to ~5000 tokens).  The tiled kernels below would put a
+// 32-token batch on 3-24 workgroups and walk K serially (33 us for the 3072-deep FFN-down GEMM, 1.7 ms per
+// forward at batch 1 — and the reference encodes queries one at a time).  Here a workgroup owns
+// ONE 32-feature block for <= 2 token blocks, its 4 waves split K four ways, each streaming its quarter of the
+// weight block straight from global memory (deep unroll, no LDS on the operand path), and the four partial
+// accumulators meet in LDS: N/32 x ceil(TB/2) workgroups, K/64 MFMA steps each.
+template <int EPI>
+__global__ __launch_bounds__(256) void k_gemm_skinny(GemmParams p) {
+  __shared__ float red[4][2][64][17];  // [wave][token block][lane][16 (+1: bank spread)]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nb = blockIdx.x % p.NB;
+  const int64_t tb0 = (int64_t)(blockIdx.x / p.NB) * 2;
+  const bool two = tb0 + 1 < p.TB;
+  const int kq = p.KB / 4, k0 = wave * kq;
+  const uint4 *wp = p.w + ((int64_t)nb * p.KB + k0) * 64 + lane;
+  const uint4 *a0 = p.act + (tb0 * p.KB + k0) * 64 + lane;
+  const uint4 *a1 = p.act + ((two ? tb0 + 1 : tb0) * p.KB + k0) * 64 + lane;
+  floatx16 c0, c1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    c0[r] = 0.f;
+    c1[r] = 0.f;
+  }
+  for (int k = 0; k < kq; k += 2) {  // kq is even (KB is a multiple of 8): two k-steps' operands in flight
+    half8 wv[2], x0[2], x1[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      wv[u] = __builtin_bit_cast(half8, wp[(int64_t)(k + u) * 64]);
+      x0[u] = __builtin_bit_cast(half8, a0[(int64_t)(k + u) * 64]);
+      x1[u] = __builtin_bit_cast(half8, a1[(int64_t)(k + u) * 64]);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (EPI == EPI_VT) {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x0[u], wv[u], c0, 0, 0, 0);  // rows = tokens
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x1[u], wv[u], c1, 0, 0, 0);
+      } else {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[u], x0[u], c0, 0, 0, 0);  // rows = features
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[u], x1[u], c1, 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    red[wave][0][lane][r] = c0[r];
+    red[wave][1][lane][r] = c1[r];
+  }
+  __syncthreads();
+  // waves 0 and 1 each finish one token block
+  if (wave < 2 && (wave == 0 || two)) {
+    floatx16 c;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      c[r] = (red[0][wave][lane][r] + red[1][wave][lane][r]) + (red[2][wave][lane][r] + red[3][wave][lane][r]);
+    gemm_store_tile<EPI>(p, c, tb0 + wave, nb, lane);
+  }
+}
+
 // LDS-staged GEMM: a workgroup (4 waves, 2 x 2) owns 128 tokens x 256 features; per stage of two k-steps the
 // 24 operand fragments (4 activation + 8 weight blocks per k-step, 1 KiB each, already in operand layout) are
 // copied global -> LDS once by global_load_lds (lane-linear, so the LDS image needs no swizzle and every
@@ -866,6 +924,14 @@ void launch_gemm(anr_encoder *e, GemmParams &g) {
     constexpr int MT = 2, NT = 4;
     const int64_t waves = ceil_div(g.TB, MT) * ceil_div(g.NB, NT);
     hipLaunchKernelGGL((k_gemm<MT, NT, EPI>), dim3((unsigned)ceil_div(waves, 4)), dim3(256), 0, e->stream, g);
+    return;
+  }
+  static const bool no_skinny = getenv("ANORAG_GEMM_NOSKINNY") != nullptr;  // developer switch
+  // measured crossover with the 256 x 256 tile at the bge-base shape: ~6000 tokens (tools/enc_perf.py)
+  static const int skinny_max = getenv("ANORAG_SKINNY_MAX") ? atoi(getenv("ANORAG_SKINNY_MAX")) : 160;
+  if (!no_skinny && g.TB <= skinny_max && g.KB % 4 == 0) {
+    const int64_t blocks = (int64_t)g.NB * ceil_div(g.TB, 2);
+    hipLaunchKernelGGL((k_gemm_skinny<EPI>), dim3((unsigned)blocks), dim3(256), 0, e->stream, g);
     return;
   }
   static const bool wide = getenv("ANORAG_GEMM_NARROW") == nullptr;  // developer switch: the 4-wave tile everywhere
