@@ -108,3 +108,32 @@ def test_model_dir_reader_and_name_map(tmp_path):
     assert map_hf_name("encoder.layer.0.output.LayerNorm.bias") == "L0.ln2.b"
     assert map_hf_name("roberta.embeddings.word_embeddings.weight") == "emb.word"
     assert map_hf_name("pooler.dense.weight") is None
+
+
+def test_mpnet_relative_bias_table_matches_transformers():
+    """host logic: the per-offset bias table handed to the encoder (rel.bias) equals what transformers' MPNetEncoder
+    computes with its bucket function, for every (query, key) pair of a 512-position model"""
+    import numpy as np
+    import torch
+    from transformers.models.mpnet.modeling_mpnet import MPNetEncoder
+    from anorag_hip.encoder import relative_bias_table
+    w = np.random.default_rng(0).standard_normal((32, 12)).astype(np.float32)
+    span = 512
+    tab = relative_bias_table(w, span)
+    assert tab.shape == (12, 2 * span - 1) and tab.dtype == np.float32
+    q = torch.arange(span)[:, None]
+    k = torch.arange(span)[None, :]
+    ref = w[MPNetEncoder.relative_position_bucket(k - q, num_buckets=32).numpy()]      # [q, k, heads]
+    qi, ki = np.meshgrid(np.arange(span), np.arange(span), indexing="ij")
+    assert np.array_equal(tab[:, (ki - qi) + span - 1].transpose(1, 2, 0), ref)
+
+
+def test_mpnet_parameter_names_map_to_encoder_tensors():
+    from anorag_hip.encoder import map_hf_name
+    assert map_hf_name("mpnet.encoder.layer.3.attention.attn.q.weight") == "L3.q.w"
+    assert map_hf_name("encoder.layer.0.attention.attn.o.bias") == "L0.o.b"
+    assert map_hf_name("encoder.layer.11.attention.LayerNorm.weight") == "L11.ln1.g"
+    assert map_hf_name("encoder.layer.11.output.LayerNorm.bias") == "L11.ln2.b"
+    assert map_hf_name("encoder.relative_attention_bias.weight") == "rel.weight"
+    assert map_hf_name("embeddings.word_embeddings.weight") == "emb.word"
+    assert map_hf_name("pooler.dense.weight") is None
