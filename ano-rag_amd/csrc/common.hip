@@ -1,6 +1,10 @@
 // Error plumbing + trivial introspection entry points of the C ABI (include/anorag.h).
 #include "common.hpp"
 
+#include <mutex>
+#include <set>
+#include <utility>
+
 namespace anr {
 
 std::string &last_error_ref() {
@@ -23,6 +27,18 @@ int device_cu_count(int device) {
   if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || n <= 0)
     n = 256;  // MI355X
   return n;
+}
+
+int ensure_dynamic_lds(const void *kernel, int bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<const void *, int>> done;  // (kernel, device)
+  int dev = 0;
+  ANR_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(mu);
+  if (done.count({kernel, dev})) return ANR_OK;
+  ANR_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  done.insert({kernel, dev});
+  return ANR_OK;
 }
 
 }  // namespace anr

@@ -48,6 +48,10 @@ struct DeviceGuard {
 
 int device_cu_count(int device);
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, current device): the attribute belongs to the
+// device's copy of the kernel, so a process that drives several GPUs needs it on each; thread-safe
+int ensure_dynamic_lds(const void *kernel, int bytes);
+
 // XCD-aware workgroup -> tile mapping for GEMM-shaped grids (MB x NB tiles).  Workgroups are dealt round-robin
 // over the 8 XCDs (b and b + 8 share one; observed, speed only), each XCD has its own L2, and the 32 workgroups
 // an XCD runs at a time walk K in step — so the 32 are given a P x Q patch of tiles (P * Q = 32): the P + Q

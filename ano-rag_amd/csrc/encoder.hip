@@ -909,11 +909,7 @@ int plain_copy(const float *host, int64_t n, float **dst) {
 template <int EPI, int TN>
 void launch_gemm8(anr_encoder *e, GemmParams &g, int64_t blocks) {
   constexpr int lds8 = 3 * 3 * (8 + TN) * 1024;
-  static bool attr8 = false;
-  if (!attr8) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_lds8<EPI, TN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds8);
-    attr8 = true;
-  }
+  (void)ensure_dynamic_lds(reinterpret_cast<const void *>(&k_gemm_lds8<EPI, TN>), lds8);
   hipLaunchKernelGGL((k_gemm_lds8<EPI, TN>), dim3((unsigned)blocks), dim3(512), lds8, e->stream, g);
 }
 
@@ -945,11 +941,7 @@ void launch_gemm(anr_encoder *e, GemmParams &g) {
   }
   const int64_t blocks = ceil_div(g.TB, 4) * ceil_div(g.NB, 8);
   constexpr int lds_bytes = 3 * ANR_GEMM_S * 12 * 1024;
-  static bool attr = false;
-  if (!attr && lds_bytes > 64 * 1024) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_lds<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    attr = true;
-  }
+  if (lds_bytes > 64 * 1024) (void)ensure_dynamic_lds(reinterpret_cast<const void *>(&k_gemm_lds<EPI>), lds_bytes);
   hipLaunchKernelGGL((k_gemm_lds<EPI>), dim3((unsigned)blocks), dim3(256), lds_bytes, e->stream, g);
 }
 

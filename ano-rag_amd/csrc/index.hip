@@ -202,12 +202,7 @@ int ensure_dense(Workspace &w, int64_t ld) {
 }
 
 int launch_select(int nblocks, const SelParams &sp, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    ANR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_select), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)sizeof(SelShared)));
-    attr_set = true;
-  }
+  ANR_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_select), (int)sizeof(SelShared)));
   if (sp.G > kSelMaxLists) return fail(ANR_EINTERNAL, "select: too many candidate lists (%d)", sp.G);
   // small inputs (threshold sample, candidate lists) use a 256-thread block: barriers are 4x cheaper
   const int64_t n_hint = sp.dense ? sp.n : (int64_t)sp.G * 16;
@@ -215,13 +210,6 @@ int launch_select(int nblocks, const SelParams &sp, hipStream_t st) {
   (void)n_hint;
   hipLaunchKernelGGL(k_select, dim3(nblocks), dim3(nt), sizeof(SelShared), st, sp);
   ANR_HIP(hipGetLastError());
-  return ANR_OK;
-}
-
-template <typename K>
-int set_max_lds(K kern) {
-  ANR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024));
   return ANR_OK;
 }
 
@@ -243,11 +231,7 @@ int launch_scan(anr_index *h, const ScanParams &p, hipStream_t st, int max_grid,
   const bool stream = p.tile_stride == 1 && p.n_tiles * (int64_t)p.kb * 1024 > ((int64_t)192 << 20);
 #define ANR_LAUNCH_SCAN(CHV, STRV)                                                             \
   {                                                                                            \
-    static bool done = false;                                                                  \
-    if (!done) {                                                                               \
-      ANR_TRY(set_max_lds(k_scan<DENSE, CHV, 768, STRV>));                                     \
-      done = true;                                                                             \
-    }                                                                                          \
+    ANR_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_scan<DENSE, CHV, 768, STRV>), 160 * 1024)); \
     hipLaunchKernelGGL((k_scan<DENSE, CHV, 768, STRV>), dim3((unsigned)grid), dim3(nt), lds, st, p); \
   }
   if (p.kb % 16 == 0) {
@@ -262,9 +246,7 @@ int launch_scan(anr_index *h, const ScanParams &p, hipStream_t st, int max_grid,
 
 hipError_t launch_join(const JoinParams &jp, int64_t n_slots, hipStream_t st, int n_cu) {
   constexpr int slots_bytes = 2 * 4 * 16 * 1024;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_r), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     slots_bytes);
-  if (e != hipSuccess) return e;
+  if (ensure_dynamic_lds(reinterpret_cast<const void *>(&k_join_r), slots_bytes) != ANR_OK) return hipErrorInvalidValue;
   const int64_t persistent = std::min<int64_t>(n_slots, std::max(8, n_cu / 8 * 8));  // a multiple of 8: slot % 8 = XCD
   hipLaunchKernelGGL(k_join_r, dim3((unsigned)persistent), dim3(512), slots_bytes, st, jp);
   return hipGetLastError();
