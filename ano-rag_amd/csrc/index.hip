@@ -46,8 +46,6 @@ struct Workspace {
   unsigned *sel_row = nullptr;
   int *sel_m = nullptr;
   float *exact = nullptr;
-  int *flags = nullptr;
-  int *flags_host = nullptr;       // pinned [64]
   unsigned *cnt_host = nullptr;    // pinned [4][64] batch status, written by k_finalize
   unsigned *cnt_dev = nullptr;     // the same memory as the device addresses it
   hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
@@ -131,19 +129,25 @@ int grow_storage(anr_index *h, int64_t need_rows) {
   float *nx32 = nullptr;
   _Float16 *nx16 = nullptr;
   float *nbias = nullptr;
-  ANR_TRY(dev_alloc(&nx32, ncap * h->dim, false));
-  ANR_TRY(dev_alloc(&nx16, ncap * h->dimp, true));
-  if (h->metric == ANR_METRIC_L2) ANR_TRY(dev_alloc(&nbias, ncap, true));
-  if (h->ntotal > 0) {
+  int rc = dev_alloc(&nx32, ncap * h->dim, false);
+  if (rc == ANR_OK) rc = dev_alloc(&nx16, ncap * h->dimp, true);
+  if (rc == ANR_OK && h->metric == ANR_METRIC_L2) rc = dev_alloc(&nbias, ncap, true);
+  if (rc == ANR_OK && h->ntotal > 0) {
     const int64_t used = round_up(h->ntotal, kTileRows);
-    ANR_HIP(hipMemcpyAsync(nx32, h->x32, (size_t)h->ntotal * h->dim * sizeof(float), hipMemcpyDeviceToDevice,
-                           h->stream));
-    ANR_HIP(hipMemcpyAsync(nx16, h->x16, (size_t)used * h->dimp * sizeof(_Float16), hipMemcpyDeviceToDevice,
-                           h->stream));
-    if (nbias)
-      ANR_HIP(hipMemcpyAsync(nbias, h->rowbias, (size_t)h->ntotal * sizeof(float), hipMemcpyDeviceToDevice,
-                             h->stream));
-    ANR_HIP(hipStreamSynchronize(h->stream));
+    hipError_t e = hipMemcpyAsync(nx32, h->x32, (size_t)h->ntotal * h->dim * sizeof(float), hipMemcpyDeviceToDevice,
+                                  h->stream);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(nx16, h->x16, (size_t)used * h->dimp * sizeof(_Float16), hipMemcpyDeviceToDevice, h->stream);
+    if (e == hipSuccess && nbias)
+      e = hipMemcpyAsync(nbias, h->rowbias, (size_t)h->ntotal * sizeof(float), hipMemcpyDeviceToDevice, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) rc = fail(ANR_EHIP, "growing the index storage failed: %s", hipGetErrorString(e));
+  }
+  if (rc != ANR_OK) {  // the index keeps its old storage
+    dev_free(nx32);
+    dev_free(nx16);
+    dev_free(nbias);
+    return rc;
   }
   dev_free(h->x32);
   dev_free(h->x16);
@@ -155,8 +159,9 @@ int grow_storage(anr_index *h, int64_t need_rows) {
   return ANR_OK;
 }
 
-int ensure_workspaces(anr_index *h) {
-  if (h->ws_ready) return ANR_OK;
+void free_workspaces(anr_index *h);
+
+int alloc_workspaces(anr_index *h) {
   for (auto &w : h->ws) {
     ANR_TRY(dev_alloc(&w.q32, (int64_t)kQB * h->dimp, true));
     ANR_TRY(dev_alloc(&w.q16, (int64_t)kQB * h->dimp, true));
@@ -171,8 +176,6 @@ int ensure_workspaces(anr_index *h) {
     ANR_TRY(dev_alloc(&w.sel_row, kQB * kMaxSel, true));
     ANR_TRY(dev_alloc(&w.sel_m, kQB, true));
     ANR_TRY(dev_alloc(&w.exact, kQB * kMaxSel, true));
-    ANR_TRY(dev_alloc(&w.flags, kQB, true));
-    ANR_HIP(hipHostMalloc(reinterpret_cast<void **>(&w.flags_host), kQB * sizeof(int), hipHostMallocDefault));
     ANR_HIP(hipHostMalloc(reinterpret_cast<void **>(&w.cnt_host), 4 * kQB * sizeof(unsigned), hipHostMallocDefault));
     ANR_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&w.cnt_dev), w.cnt_host, 0));
     ANR_HIP(hipEventCreateWithFlags(&w.ev_in, hipEventDisableTiming));
@@ -182,6 +185,16 @@ int ensure_workspaces(anr_index *h) {
     ANR_HIP(hipEventCreateWithFlags(&w.ev_t1, hipEventDisableSystemFence));
   }
   for (auto &e : h->ev_call) ANR_HIP(hipEventCreate(&e));
+  return ANR_OK;
+}
+
+int ensure_workspaces(anr_index *h) {
+  if (h->ws_ready) return ANR_OK;
+  const int rc = alloc_workspaces(h);
+  if (rc != ANR_OK) {
+    free_workspaces(h);  // a half-built set would leak on the next attempt
+    return rc;
+  }
   h->ws_ready = true;
   return ANR_OK;
 }
@@ -772,14 +785,23 @@ void free_workspaces(anr_index *h) {
   for (auto &w : h->ws) {
     dev_free(w.q32); dev_free(w.q16); dev_free(w.qstat); dev_free(w.qstage); dev_free(w.dense);
     dev_free(w.ladder); dev_free(w.cntb); dev_free(w.ncand); dev_free(w.cand); dev_free(w.qslots);
-    dev_free(w.sel_rank); dev_free(w.sel_row); dev_free(w.sel_m); dev_free(w.exact); dev_free(w.flags);
-    if (w.flags_host) (void)hipHostFree(w.flags_host);
+    dev_free(w.sel_rank); dev_free(w.sel_row); dev_free(w.sel_m); dev_free(w.exact);
     if (w.cnt_host) (void)hipHostFree(w.cnt_host);
     if (w.qpin) (void)hipHostFree(w.qpin);
+    w.cnt_host = w.cnt_dev = nullptr;
     w.qpin = nullptr;
-    for (hipEvent_t *e : {&w.ev_in, &w.ev_done, &w.ev_t0, &w.ev_t1})
+    w.cand_alloc = 0;
+    w.dense_ld = 0;
+    for (hipEvent_t *e : {&w.ev_in, &w.ev_done, &w.ev_t0, &w.ev_t1}) {
       if (*e) (void)hipEventDestroy(*e);
+      *e = nullptr;
+    }
   }
+  for (auto &e : h->ev_call) {
+    if (e) (void)hipEventDestroy(e);
+    e = nullptr;
+  }
+  h->ws_ready = false;
 }
 
 }  // namespace
