@@ -16,6 +16,7 @@ ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--sample", type=int, default=0)
 ap.add_argument("--overfetch", type=int, default=0)
 ap.add_argument("--streams", type=int, default=0)
+ap.add_argument("--no-timing", action="store_true", help="do not record the per-scan HIP events (ANR_OPT_TIMING)")
 ap.add_argument("--mode", default="both")
 ap.add_argument("--clustered", action="store_true", help="1024 Gaussian centroids, sigma 0.3 (SURVEY 8d)")
 a = ap.parse_args()
@@ -34,7 +35,7 @@ while done < a.rows:
     torch.cuda.synchronize()
     idx.add_device(x.data_ptr(), m)
     done += m
-idx.set_option(OPT_TIMING, 1)
+idx.set_option(OPT_TIMING, 0 if a.no_timing else 1)
 if a.sample: idx.set_option(OPT_SAMPLE_ROWS, a.sample)
 if a.overfetch: idx.set_option(OPT_OVERFETCH, a.overfetch)
 Q = torch.randn((a.steps + 2, a.batch, a.dim), generator=g, device=dev)
@@ -73,7 +74,7 @@ if a.mode in ("both", "async"):
         dt = (time.perf_counter() - t0) / a.steps
     st = idx.last_stats()
     print(f"[async] rows={a.rows} wall/step={dt*1e3:.3f} ms  scan={st['scan_ms']/a.steps:.3f} ms  "
-          f"scan GB/s={st['scan_bytes']/1e9/(st['scan_ms']/1e3):.0f}  qps={a.batch/dt:.0f}  cand/q={st['n_candidates']/a.steps/a.batch:.0f} "
+          f"scan GB/s={(st['scan_bytes']/1e9/(st['scan_ms']/1e3)) if st['scan_ms'] > 0 else 0:.0f}  qps={a.batch/dt:.0f}  cand/q={st['n_candidates']/a.steps/a.batch:.0f} "
           f"fallback={st['n_fallback']}")
     # same answers as the synchronous path
     idx.search_device(Q[a.steps + 1].data_ptr(), a.batch, a.k, D.data_ptr(), I.data_ptr())
