@@ -1347,10 +1347,10 @@ __global__ __launch_bounds__(256) void k_join_rescore(JoinRescoreParams p) {
   // a wave takes 64 candidates at a time: lane c keeps candidate c's value, so the survivors of the batch are
   // appended with one atomic
   for (unsigned long long c0 = w0 * 64; c0 < p.n_cand; c0 += wt * 64) {
-    const unsigned long long nb = p.n_cand - c0 < 64 ? p.n_cand - c0 : 64;
+    const int nb = p.n_cand - c0 < 64 ? (int)(p.n_cand - c0) : 64;
     const uint2 my = lane < nb ? p.cand[c0 + lane] : make_uint2(0u, 0u);
     float mine = 0.f;
-    for (unsigned c = 0; c < nb; ++c) {
+    for (int c = 0; c < nb; ++c) {
       const unsigned ri = __shfl(my.x, c), rj = __shfl(my.y, c);
       const float *a = p.x32 + (int64_t)ri * p.dim, *b = p.x32 + (int64_t)rj * p.dim;
       double acc = 0.0;
@@ -1369,7 +1369,7 @@ __global__ __launch_bounds__(256) void k_join_rescore(JoinRescoreParams p) {
         for (int k = lane; k < p.dim; k += 64) acc += (double)a[k] * (double)b[k];
       }
       for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-      if (lane == (int)c) mine = (float)acc;
+      if (lane == c) mine = (float)acc;
     }
     const bool keep = lane < nb && mine >= p.threshold;
     const unsigned long long mask = __ballot(keep);
