@@ -80,6 +80,8 @@ struct anr_index {
   int timing = 0;
   int add_raw = 0;          // adds store the rows as given (already preprocessed, e.g. a reloaded index)
   int64_t id_offset = 0;    // added to every returned id (a shard's first global row)
+  int overfetch_boost = 1;  // adaptive multiplier of the automatic K' (adapt_overfetch)
+  int clean_batches = 0;
   int n_streams = kWorkspaces;  // streams the batches rotate over (1 = strictly one batch after the other)
 
   Workspace ws[kWorkspaces];
@@ -271,8 +273,28 @@ int auto_overfetch(const anr_index *h, int k) {
     return m > kMaxSel ? kMaxSel : m;
   }
   int extra = k / 2 > 32 ? k / 2 : 32;
-  int m = (int)round_up(k + extra, 64);
+  int m = (int)round_up(k + extra, 64) * h->overfetch_boost;
   return m > kMaxSel ? kMaxSel : m;
+}
+
+// Adaptive overfetch: on corpora with dense neighbourhoods (hundreds of rows within the f16 error bound of the
+// k-th score) K' = 192 candidates cannot certify the top-100 and every batch pays a second scan.  When more than
+// a quarter of a batch's queries fail their certificate the automatic K' doubles (up to 4x, capped at 1024) —
+// an exact re-score of 1024 rows per query costs ~40 us per batch, the second scan ~300 us at a 1.25 M-row
+// shard — and it halves again after 16 consecutive batches without a failure.
+void adapt_overfetch(anr_index *h, int n_queries, int n_failed) {
+  if (h->overfetch > 0 || n_queries <= 0) return;  // the caller fixed K'
+  if (4 * n_failed > n_queries) {
+    if (h->overfetch_boost < 4) h->overfetch_boost *= 2;
+    h->clean_batches = 0;
+  } else if (n_failed == 0) {
+    if (h->overfetch_boost > 1 && ++h->clean_batches >= 16) {
+      h->overfetch_boost /= 2;
+      h->clean_batches = 0;
+    }
+  } else {
+    h->clean_batches = 0;
+  }
 }
 
 // dense exact path for the listed batch-local query slots of workspace w (runs on h->stream, synchronous)
@@ -434,6 +456,7 @@ int retire(anr_index *h, Workspace &w) {
       if (w.cnt_host[2 * kQB + q]) fallback.push_back(q);
     }
   }
+  if (!w.exact_all) adapt_overfetch(h, w.nq, (int)fallback.size());
   if (!fallback.empty()) {
     h->stats.n_fallback += (int64_t)fallback.size();
     std::vector<int> dense;

@@ -264,6 +264,14 @@ def test_tight_clusters_second_pass_is_exact():
     st = idx.last_stats()
     assert st["n_fallback"] > 0, "this data is meant to defeat the certificate"
     assert st["n_dense_exact"] == 0, st
+    # adaptive overfetch: after batches in which most certificates failed, the automatic K' grows (here to its
+    # 4x cap, 512) so that later batches certify without the second scan — and the answers stay exact
+    assert st["overfetch"] == 128
+    for _ in range(3):
+        _check(idx, x, q, k, "ip", True)
+    st = idx.last_stats()
+    assert st["overfetch"] == 512, st
+    assert st["n_fallback"] < nq // 2, st    # far fewer certificates fail with 512 candidates than with 128
     idx.close()
     l2 = FlatIndex(d, METRIC_L2, normalize=False)
     l2.add(x)
