@@ -35,6 +35,7 @@ class SearchStats(C.Structure):
     _fields_ = [
         ("n_queries", C.c_int64),
         ("n_fallback", C.c_int64),
+        ("n_from_lists", C.c_int64),
         ("n_dense_exact", C.c_int64),
         ("n_candidates", C.c_int64),
         ("n_overflow", C.c_int64),

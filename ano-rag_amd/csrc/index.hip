@@ -40,6 +40,8 @@ struct Workspace {
   unsigned *cntb = nullptr;   // [64][n_cu]
   unsigned *ncand = nullptr;  // status block: [64] candidates | [64] overflow | [64] flags | [64] theta (float)
   int *qslots = nullptr;      // [64] query slots of a second pass
+  int *lvlmax = nullptr;      // [64] highest ladder level any scan workgroup ended at
+  int scan_grid = 0;          // workgroups (= candidate lists per query) of the batch's main scan
   uint2 *cand = nullptr;      // [n_cu][64][cand_cap]
   int64_t cand_alloc = 0;
   float *sel_rank = nullptr;
@@ -174,6 +176,7 @@ int alloc_workspaces(anr_index *h) {
     ANR_TRY(dev_alloc(&w.cntb, (int64_t)kQB * h->n_cu, true));
     ANR_TRY(dev_alloc(&w.ncand, 4 * kQB, true));
     ANR_TRY(dev_alloc(&w.qslots, kQB, true));
+    ANR_TRY(dev_alloc(&w.lvlmax, kQB, true));
     ANR_TRY(dev_alloc(&w.sel_rank, kQB * kMaxSel, true));
     ANR_TRY(dev_alloc(&w.sel_row, kQB * kMaxSel, true));
     ANR_TRY(dev_alloc(&w.sel_m, kQB, true));
@@ -362,21 +365,75 @@ int run_exact(anr_index *h, Workspace &w, const std::vector<int> &slots) {
 int run_second_pass(anr_index *h, Workspace &w, const std::vector<int> &slots, std::vector<int> *still_failed) {
   hipStream_t st = h->stream;
   const float inf = __builtin_inff();
-  std::vector<float> lad((size_t)kQB * kLadder, inf);
-  std::vector<int> run;
   const float *theta = reinterpret_cast<const float *>(w.cnt_host + 3 * kQB);
+  // The first scan emitted EVERY row whose scan score reached the threshold of the highest level any workgroup
+  // ended at.  Where theta (below which no row of the true top-k can score) is at or above that threshold, the
+  // lists already hold every row that matters: re-score those entries exactly and select — no second scan.
+  std::vector<float> lad0((size_t)kQB * kLadder);
+  std::vector<int> lvlmax(kQB);
+  ANR_HIP(hipMemcpyAsync(lad0.data(), w.ladder, lad0.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+  ANR_HIP(hipMemcpyAsync(lvlmax.data(), w.lvlmax, kQB * sizeof(int), hipMemcpyDeviceToHost, st));
+  ANR_HIP(hipStreamSynchronize(st));
+  std::vector<int> from_lists, rescan;
   for (int q : slots) {
-    if (theta[q] > -inf) {
-      for (int j = 0; j < kLadder; ++j) lad[(size_t)q * kLadder + j] = theta[q];
-      run.push_back(q);
-    } else {
+    if (!(theta[q] > -inf)) {
       still_failed->push_back(q);
+    } else if (!w.cnt_host[kQB + q] && lvlmax[q] >= 0 && lvlmax[q] < kLadder &&
+               theta[q] >= lad0[(size_t)q * kLadder + lvlmax[q]]) {
+      from_lists.push_back(q);
+    } else {
+      rescan.push_back(q);
     }
   }
-  if (run.empty()) return ANR_OK;
+  auto finish_from_lists = [&](const std::vector<int> &run, int grid, bool filter) -> int {
+    ANR_HIP(hipMemcpyAsync(w.qslots, run.data(), run.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    RescoreListsParams rl{h->x32, w.q32, h->dim, h->dimp, h->metric, w.cand, w.cntb, grid, (unsigned)h->cand_cap, w.qslots,
+                          filter ? reinterpret_cast<const float *>(w.ncand + 3 * kQB) : nullptr};
+    hipLaunchKernelGGL(k_rescore_lists, dim3((unsigned)run.size(), 4), dim3(1024), 0, st, rl);
+    SelParams sp{};
+    sp.cand = w.cand;
+    sp.cntb = w.cntb;
+    sp.G = grid;
+    sp.capb = (unsigned)h->cand_cap;
+    sp.M = w.k;
+    sp.negate = h->metric == ANR_METRIC_L2;  // lists hold -distance: flip back on output
+    sp.out_rank = w.sel_rank;
+    sp.out_row = w.sel_row;
+    sp.out_m = w.sel_m;
+    sp.overflow = w.ncand + kQB;
+    sp.qslots = w.qslots;
+    ANR_TRY(launch_select((int)run.size(), sp, st));
+    EmitParams mp{};
+    mp.rank = w.sel_rank;
+    mp.row = w.sel_row;
+    mp.m = w.sel_m;
+    mp.nf = (int)run.size();
+    mp.qslots = w.qslots;
+    mp.out_off = w.out_off;
+    mp.k = w.k;
+    mp.metric = h->metric;
+    mp.D = w.D;
+    mp.I = w.I;
+    mp.id_offset = h->id_offset;
+    hipLaunchKernelGGL(k_emit, dim3(mp.nf), dim3(256), 0, st, mp);
+    ANR_HIP(hipGetLastError());
+    ANR_HIP(hipMemcpyAsync(w.cnt_host + kQB, w.ncand + kQB, kQB * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    ANR_HIP(hipStreamSynchronize(st));
+    for (int q : run)
+      if (w.cnt_host[kQB + q]) still_failed->push_back(q);  // a list overflowed: dense exact path
+    return ANR_OK;
+  };
+  if (!from_lists.empty()) {
+    h->stats.n_from_lists += (int64_t)from_lists.size();
+    ANR_TRY(finish_from_lists(from_lists, w.scan_grid, true));
+  }
+  if (rescan.empty()) return ANR_OK;
+  // the remaining queries: a scan with the fixed per-query threshold theta
+  std::vector<float> lad((size_t)kQB * kLadder, inf);
+  for (int q : rescan)
+    for (int j = 0; j < kLadder; ++j) lad[(size_t)q * kLadder + j] = theta[q];
   ANR_TRY(ensure_cand(h, w));
   ANR_HIP(hipMemcpyAsync(w.ladder, lad.data(), lad.size() * sizeof(float), hipMemcpyHostToDevice, st));
-  ANR_HIP(hipMemcpyAsync(w.qslots, run.data(), run.size() * sizeof(int), hipMemcpyHostToDevice, st));
   ScanParams sc{};
   sc.x16 = reinterpret_cast<const uint4 *>(h->x16);
   sc.q16 = reinterpret_cast<const uint4 *>(w.q16);
@@ -394,42 +451,7 @@ int run_second_pass(anr_index *h, Workspace &w, const std::vector<int> &slots, s
   sc.kprime = 0x7fffffffu;  // levels never advance: the threshold stays theta
   int grid = 0;
   ANR_TRY(launch_scan<false>(h, sc, st, h->n_cu, &grid));
-  RescoreListsParams rl{h->x32, w.q32, h->dim, h->dimp, h->metric, w.cand, w.cntb, grid, (unsigned)h->cand_cap, w.qslots};
-  hipLaunchKernelGGL(k_rescore_lists, dim3((unsigned)run.size(), 4), dim3(1024), 0, st, rl);
-  SelParams sp{};
-  sp.cand = w.cand;
-  sp.cntb = w.cntb;
-  sp.G = grid;
-  sp.capb = (unsigned)h->cand_cap;
-  sp.M = w.k;
-  sp.negate = h->metric == ANR_METRIC_L2;  // lists hold -distance: flip back on output
-  sp.out_rank = w.sel_rank;
-  sp.out_row = w.sel_row;
-  sp.out_m = w.sel_m;
-  sp.overflow = w.ncand + kQB;
-  sp.qslots = w.qslots;
-  ANR_TRY(launch_select((int)run.size(), sp, st));
-  {
-    EmitParams mp{};
-    mp.rank = w.sel_rank;
-    mp.row = w.sel_row;
-    mp.m = w.sel_m;
-    mp.nf = (int)run.size();
-    mp.qslots = w.qslots;
-    mp.out_off = w.out_off;
-    mp.k = w.k;
-    mp.metric = h->metric;
-    mp.D = w.D;
-    mp.I = w.I;
-    mp.id_offset = h->id_offset;
-    hipLaunchKernelGGL(k_emit, dim3(mp.nf), dim3(256), 0, st, mp);
-  }
-  ANR_HIP(hipGetLastError());
-  ANR_HIP(hipMemcpyAsync(w.cnt_host + kQB, w.ncand + kQB, kQB * sizeof(unsigned), hipMemcpyDeviceToHost, st));
-  ANR_HIP(hipStreamSynchronize(st));
-  for (int q : run)
-    if (w.cnt_host[kQB + q]) still_failed->push_back(q);  // a list overflowed: dense exact path
-  return ANR_OK;
+  return finish_from_lists(rescan, grid, false);
 }
 
 // wait for a workspace's batch, fold its statistics, run the exact path where the certificate failed
@@ -588,6 +610,14 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
     sc.groupmax = 1;  // one value per 32-row tile: the K'-th largest tile maximum is a valid threshold
     ANR_TRY(launch_scan<true>(h, sc, bs, side_grid));
     sc.groupmax = 0;
+    // start level of the scan: the highest one whose sample rank still predicts >= 4 K' corpus rows above it
+    int lvl0 = 0;
+    {
+      const int64_t ratio = full_tiles / sample_tiles;
+      const int64_t need = std::max<int64_t>(12, ceil_div((int64_t)4 * M, ratio));
+      for (int j = 1; j < kLadder - 1; ++j)
+        if ((M >> j) >= need) lvl0 = j;
+    }
     SelParams ss = sp;
     ss.dense = w.dense;
     ss.dense_ld = w.dense_ld;
@@ -595,6 +625,8 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
     ss.row0 = 0;
     ss.row_tile_stride = 1;
     ss.ladder = w.ladder;
+    ss.lvl_init = w.lvlmax;
+    ss.lvl_init_value = lvl0;
     ANR_TRY(launch_select(kQB, ss, bs));
     // scan
     sc.tile0 = 0;
@@ -602,15 +634,8 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
     sc.n_tiles = n_tiles;
     sc.dense = nullptr;
     sc.ladder = w.ladder;
-    {
-      // start level: the highest one whose sample rank still predicts >= 4 K' corpus rows above it
-      const int64_t ratio = full_tiles / sample_tiles;
-      const int64_t need = std::max<int64_t>(12, ceil_div((int64_t)4 * M, ratio));
-      int lvl0 = 0;
-      for (int j = 1; j < kLadder - 1; ++j)
-        if ((M >> j) >= need) lvl0 = j;
-      sc.lvl0 = lvl0;
-    }
+    sc.lvl0 = lvl0;
+    sc.lvlmax = w.lvlmax;
     sc.cntb = w.cntb;
     sc.cand = w.cand;
     sc.capb = (unsigned)h->cand_cap;
@@ -618,6 +643,7 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
     int scan_grid = 0;
     if (w.timed) ANR_HIP(hipEventRecord(w.ev_t0, bs));
     ANR_TRY(launch_scan<false>(h, sc, bs, scan_grid_max, &scan_grid));
+    w.scan_grid = scan_grid;
     if (w.timed) ANR_HIP(hipEventRecord(w.ev_t1, bs));
     w.scan_bytes = n_tiles * kTileRows * (int64_t)h->dimp * 2;
     // post
@@ -807,7 +833,7 @@ int add_impl(anr_index *h, const float *x_dev, int64_t n, hipStream_t st) {
 void free_workspaces(anr_index *h) {
   for (auto &w : h->ws) {
     dev_free(w.q32); dev_free(w.q16); dev_free(w.qstat); dev_free(w.qstage); dev_free(w.dense);
-    dev_free(w.ladder); dev_free(w.cntb); dev_free(w.ncand); dev_free(w.cand); dev_free(w.qslots);
+    dev_free(w.ladder); dev_free(w.cntb); dev_free(w.ncand); dev_free(w.cand); dev_free(w.qslots); dev_free(w.lvlmax);
     dev_free(w.sel_rank); dev_free(w.sel_row); dev_free(w.sel_m); dev_free(w.exact);
     if (w.cnt_host) (void)hipHostFree(w.cnt_host);
     if (w.qpin) (void)hipHostFree(w.qpin);

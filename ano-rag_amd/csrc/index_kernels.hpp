@@ -243,6 +243,8 @@ struct ScanParams {
   // sparse
   const float *ladder;   // [64][kLadder] ascending thresholds from the sample
   int lvl0;              // ladder level every block starts at
+  int *lvlmax;           // optional [64]: highest level any workgroup ended at (every row at or above that level's
+                         // threshold was emitted by every workgroup — what a list-only recovery needs to know)
   unsigned *cntb;        // [64][gridDim.x] list lengths, written when a block retires
   uint2 *cand;           // [gridDim.x][64][capb] (rank-score bits, row)
   unsigned capb;
@@ -462,6 +464,7 @@ __global__ __launch_bounds__(NT) void k_scan(ScanParams p) {
   if (!DENSE) {
     __syncthreads();
     if (tid < kQB) p.cntb[(int64_t)tid * gridDim.x + blockIdx.x] = lds_cnt[tid];
+    if (tid < kQB && p.lvlmax && lds_lvl[tid] > p.lvl0) atomicMax(p.lvlmax + tid, lds_lvl[tid]);
   }
 }
 
@@ -494,6 +497,8 @@ struct SelParams {
   unsigned *overflow;    // optional [64]: set when a list overflowed
   unsigned *ncand;       // optional [64]: candidates seen
   const int *qslots;     // optional: block b handles query slot qslots[b]
+  int *lvl_init;         // optional (ladder mode): lvl_init[q] = lvl_init_value, the scan's start level
+  int lvl_init_value;
 };
 
 struct SelShared {
@@ -576,6 +581,7 @@ __global__ __launch_bounds__(1024) void k_select(SelParams p) {
   if (M == 0) {
     if (tid == 0) p.out_m[q] = 0;
     if (p.ladder && tid < kLadder) p.ladder[q * kLadder + tid] = -__builtin_inff();
+    if (p.lvl_init && tid == 0) p.lvl_init[q] = p.lvl_init_value;
     return;
   }
   const bool staged = n <= kSelLds;
@@ -765,6 +771,7 @@ __global__ __launch_bounds__(1024) void k_select(SelParams p) {
     p.out_rank[q * kMaxSel + i] = p.negate ? -v : v;
     p.out_row[q * kMaxSel + i] = 0xffffffffu - (unsigned)(k & 0xffffffffu);
   }
+  if (p.lvl_init && tid == 0) p.lvl_init[q] = p.lvl_init_value;
   if (p.ladder && tid < kLadder) {
     // level j = value of rank max(1, M >> j) (1-based) of the sample: ascending in j
     int rk = M >> tid;
@@ -879,6 +886,7 @@ struct RescoreListsParams {
   int G;
   unsigned capb;
   const int *qslots;   // [nf] query slots to process
+  const float *theta;  // optional [64]: entries whose scan score is below theta[q] are not re-scored (set to -inf)
 };
 
 __global__ __launch_bounds__(1024) void k_rescore_lists(RescoreListsParams p) {
@@ -917,6 +925,10 @@ __global__ __launch_bounds__(1024) void k_rescore_lists(RescoreListsParams p) {
       else hi = mid;
     }
     uint2 *ent = p.cand + ((int64_t)lo * kQB + q) * p.capb + (e - offs[lo]);
+    if (p.theta && __uint_as_float(ent->x) < p.theta[q]) {
+      if (lane == 0) ent->x = __float_as_uint(-__builtin_inff());
+      continue;
+    }
     const unsigned row = ent->y;
     const float *x = p.x32 + (int64_t)row * p.dim;
     double acc = 0.0;

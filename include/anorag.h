@@ -108,7 +108,8 @@ int anr_index_set_option(anr_index *h, int32_t opt, int64_t value);
 
 typedef struct anr_search_stats {
   int64_t n_queries;        /* queries of the last search call                                        */
-  int64_t n_fallback;       /* of those, whose certificate failed (answered by the second pass)        */
+  int64_t n_fallback;       /* of those, whose certificate failed (answered from the lists / by a second scan) */
+  int64_t n_from_lists;     /* of those, recovered from the first scan's candidate lists (no second scan)  */
   int64_t n_dense_exact;    /* of those, answered by the dense exact path (forced, overflow, tiny index) */
   int64_t n_candidates;     /* candidates emitted by the scan, summed over queries                    */
   int64_t n_overflow;       /* queries whose candidate buffer overflowed                               */

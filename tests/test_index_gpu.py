@@ -264,6 +264,7 @@ def test_tight_clusters_second_pass_is_exact():
     st = idx.last_stats()
     assert st["n_fallback"] > 0, "this data is meant to defeat the certificate"
     assert st["n_dense_exact"] == 0, st
+    assert st["n_from_lists"] > 0, st        # theta above the scan's own threshold: recovered without a second scan
     # adaptive overfetch: after batches in which most certificates failed, the automatic K' grows (here to its
     # 4x cap, 512) so that later batches certify without the second scan — and the answers stay exact
     assert st["overfetch"] == 128
@@ -345,14 +346,35 @@ def test_sample_that_overestimates_the_corpus_still_gives_exact_results():
     for t in range(0, (sample_rows // 32)):  # one near-copy of every query in each sampled tile
         r0 = t * stride * 32
         for j in range(nq):
-            x[r0 + j] = q[j] * (1.0 + 0.01 * t) + 0.05 * rng.standard_normal(d).astype(np.float32)
+            x[r0 + j] = q[j] + 0.02 * (t + 1) * rng.standard_normal(d).astype(np.float32)  # cosine falls with t
     idx = FlatIndex(d, METRIC_IP, normalize=True)
     idx.add(x)
     idx.set_option(OPT_SAMPLE_ROWS, sample_rows)
     _check(idx, x, q, k, "ip", True)
     st = idx.last_stats()
     assert st["n_fallback"] == nq, st        # every query: fewer than K' candidates above the guessed threshold
-    assert st["n_dense_exact"] == 0, st      # ... and the second pass (not the dense path) answered them
+    assert st["n_dense_exact"] == 0, st      # ... and the recovery (not the dense path) answered them
+    assert st["n_from_lists"] == nq, st      # theta (10th best - eps) is above the scan threshold (16th best)
+    idx.close()
+
+    # same construction with near-identical planted rows: the 10th best is within eps of the scan's threshold, so
+    # theta falls BELOW it and the lists cannot be trusted to hold every row above theta -> the theta re-scan runs
+    x3 = rng.standard_normal((n, d)).astype(np.float32)
+    for t in range(0, (sample_rows // 32)):
+        r0 = t * stride * 32
+        for j in range(nq):
+            x3[r0 + j] = q[j] + 1e-4 * rng.standard_normal(d).astype(np.float32)
+    idx = FlatIndex(d, METRIC_IP, normalize=True)
+    idx.add(x3)
+    idx.set_option(OPT_SAMPLE_ROWS, sample_rows)
+    D, I = idx.search(q, k)
+    st = idx.last_stats()
+    assert st["n_fallback"] == nq and st["n_from_lists"] < nq, st
+    s64 = orc.exact_scores(orc.preprocess_vectors(q), orc.preprocess_vectors(x3), "ip")
+    kth = np.sort(s64, axis=1)[:, -k]
+    got = np.take_along_axis(s64, I, axis=1)
+    assert np.all(got >= kth[:, None] - 1e-6)          # every returned row is a true top-k row up to near-ties
+    assert np.max(np.abs(D - np.sort(s64, axis=1)[:, ::-1][:, :k])) <= SCORE_TOL
     idx.close()
 
     x2 = rng.standard_normal((n, d)).astype(np.float32)
