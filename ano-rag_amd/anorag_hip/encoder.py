@@ -17,7 +17,7 @@ from __future__ import annotations
 import ctypes as C
 import json
 import os
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, Optional, Sequence
 
 import numpy as np
 

@@ -10,7 +10,7 @@ the device kernel ``anr_merge_topk_dev`` used when the partials already sit on t
 from __future__ import annotations
 
 import ctypes as C
-from typing import Callable, Optional, Tuple
+from typing import Callable, Tuple
 
 import numpy as np
 

@@ -12,7 +12,6 @@ There is no CPU fallback: without the HIP library ``fuse`` raises.
 from __future__ import annotations
 
 import ctypes as C
-import math
 from typing import Any, Dict, List, Sequence, Tuple
 
 import numpy as np

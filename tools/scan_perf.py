@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "ano-rag_amd"))
 import torch
 from anorag_hip import FlatIndex, METRIC_IP
-from anorag_hip._lib import OPT_TIMING, OPT_SAMPLE_ROWS, OPT_OVERFETCH, OPT_CAND_CAP
+from anorag_hip._lib import OPT_TIMING, OPT_SAMPLE_ROWS, OPT_OVERFETCH
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--rows", type=int, default=1_000_000)
