@@ -875,8 +875,9 @@ int pack_weight(anr_encoder *e, const float *host, int N, int K, _Float16 **dst,
   const int64_t total = (int64_t)(N / 32) * (K / 16) * 64;
   hipLaunchKernelGGL(k_pack_weight, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, e->stream, tmp, N, K,
                      *dst + (int64_t)row_off * K);
-  ANR_HIP(hipStreamSynchronize(e->stream));
+  const hipError_t err = hipStreamSynchronize(e->stream);
   (void)hipFree(tmp);
+  if (err != hipSuccess) return fail(ANR_EHIP, "packing a tensor failed: %s", hipGetErrorString(err));
   return ANR_OK;
 }
 
@@ -885,8 +886,9 @@ int pack_bias_acc(anr_encoder *e, const float *host, int N, float **dst, int off
   float *tmp = nullptr;
   ANR_TRY(upload(host, N, &tmp));
   hipLaunchKernelGGL(k_pack_bias_acc, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, e->stream, tmp, N, *dst + off);
-  ANR_HIP(hipStreamSynchronize(e->stream));
+  const hipError_t err = hipStreamSynchronize(e->stream);
   (void)hipFree(tmp);
+  if (err != hipSuccess) return fail(ANR_EHIP, "packing a tensor failed: %s", hipGetErrorString(err));
   return ANR_OK;
 }
 
@@ -895,8 +897,9 @@ int pack_rows(anr_encoder *e, const float *host, int64_t R, int H, float **dst) 
   float *tmp = nullptr;
   ANR_TRY(upload(host, R * H, &tmp));
   hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)ceil_div(R * H, 256)), dim3(256), 0, e->stream, tmp, R, H, *dst);
-  ANR_HIP(hipStreamSynchronize(e->stream));
+  const hipError_t err = hipStreamSynchronize(e->stream);
   (void)hipFree(tmp);
+  if (err != hipSuccess) return fail(ANR_EHIP, "packing a tensor failed: %s", hipGetErrorString(err));
   return ANR_OK;
 }
 
