@@ -45,6 +45,20 @@ class FlatIndex:
         x = _f32_matrix(x, self.d, "add")
         _lib.check(self._lib.anr_index_add(self._h, x.ctypes.data_as(C.c_void_p), x.shape[0]), "anr_index_add")
 
+    def add_npy(self, path: str, chunk_rows: int = 1 << 18) -> int:
+        """Stream an [N, d] ``.npy`` file (the reference's ``embeddings.npy``, doc/document_processor.py:164-172, or an
+        array saved from ``note_embeddings.npz``) into the index without loading it whole: the file is memory-mapped
+        and added chunk by chunk (any float dtype; rows are converted to float32 per chunk).  Returns the row count."""
+        arr = np.load(path, mmap_mode="r")
+        if arr.ndim != 2 or arr.shape[1] != self.d:
+            raise ValueError(f"{path}: expected an [N, {self.d}] array, found shape {arr.shape}")
+        if arr.dtype.kind != "f":
+            raise ValueError(f"{path}: expected a floating-point array, found {arr.dtype}")
+        self.reserve(self.ntotal + arr.shape[0])
+        for i in range(0, arr.shape[0], int(chunk_rows)):
+            self.add(np.ascontiguousarray(arr[i:i + int(chunk_rows)], dtype=np.float32))
+        return int(arr.shape[0])
+
     def search(self, q, k: int):
         q = _f32_matrix(q, self.d, "search")
         nq = q.shape[0]

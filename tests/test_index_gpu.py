@@ -387,3 +387,30 @@ def test_sample_that_overestimates_the_corpus_still_gives_exact_results():
     _check(idx, x2, q, k, "ip", True)
     assert idx.last_stats()["n_dense_exact"] == 0
     idx.close()
+
+
+def test_add_npy_streams_a_memory_mapped_file(tmp_path):
+    """embeddings.npy -> index without loading the file whole: float32 and float16 files, chunk boundaries that are
+    not multiples of the 32-row tile, equal to adding the array directly"""
+    from anorag_hip import FlatIndex, METRIC_IP
+    x, q = _data(10_007, 96, 5)
+    p32 = str(tmp_path / "embeddings.npy")
+    np.save(p32, x)
+    a = FlatIndex(96, METRIC_IP, normalize=True)
+    assert a.add_npy(p32, chunk_rows=3001) == 10_007 and a.ntotal == 10_007
+    b = FlatIndex(96, METRIC_IP, normalize=True)
+    b.add(x)
+    Da, Ia = a.search(q, 10)
+    Db, Ib = b.search(q, 10)
+    assert np.array_equal(Ia, Ib) and np.array_equal(Da, Db)
+    p16 = str(tmp_path / "embeddings16.npy")
+    np.save(p16, x.astype(np.float16))
+    c = FlatIndex(96, METRIC_IP, normalize=True)
+    c.add_npy(p16)
+    _check(c, x.astype(np.float16).astype(np.float32), q, 10, "ip", True)
+    wrong = FlatIndex(64, METRIC_IP)
+    with pytest.raises(ValueError):
+        wrong.add_npy(p32)                     # dimension mismatch
+    wrong.close()
+    for i in (a, b, c):
+        i.close()
