@@ -414,3 +414,28 @@ def test_add_npy_streams_a_memory_mapped_file(tmp_path):
     wrong.close()
     for i in (a, b, c):
         i.close()
+
+
+def test_randomised_shapes_against_the_oracle():
+    """a seeded sweep over corpus size, dimension, batch size, k and metric (both the dense and the sparse pipeline,
+    ragged tiles, k > n padding, dimensions that are not multiples of 16) — every case against the oracle"""
+    from anorag_hip import FlatIndex, METRIC_IP, METRIC_L2
+    rng = np.random.default_rng(2024)
+    sizes = [1, 31, 33, 1000, 4097, 50_000, 120_001]
+    for case in range(14):
+        n = int(sizes[case % len(sizes)])
+        d = int(rng.choice([8, 17, 64, 100, 200, 384]))
+        nq = int(rng.choice([1, 3, 64, 65, 130]))
+        k = int(rng.choice([1, 7, 50, 200]))
+        metric = "l2" if case % 3 == 2 else "ip"
+        normalize = metric == "ip" and bool(case % 2)
+        x = rng.standard_normal((n, d)).astype(np.float32)
+        q = rng.standard_normal((nq, d)).astype(np.float32)
+        idx = FlatIndex(d, METRIC_L2 if metric == "l2" else METRIC_IP, normalize=normalize)
+        idx.add(x[: n // 2])
+        idx.add(x[n // 2:])
+        try:
+            _check(idx, x, q, k, metric, normalize)
+        except AssertionError as e:  # say which case
+            raise AssertionError(f"case {case}: n={n} d={d} nq={nq} k={k} metric={metric} normalize={normalize}: {e}")
+        idx.close()
