@@ -439,3 +439,19 @@ def test_randomised_shapes_against_the_oracle():
         except AssertionError as e:  # say which case
             raise AssertionError(f"case {case}: n={n} d={d} nq={nq} k={k} metric={metric} normalize={normalize}: {e}")
         idx.close()
+
+
+def test_concurrent_searches_from_worker_threads():
+    """the reference searches from ThreadPoolExecutor workers (query_processor.py:2761-2766): handles serialise
+    their own calls, ctypes releases the GIL, every thread gets the single-threaded answer"""
+    from concurrent.futures import ThreadPoolExecutor
+    from anorag_hip import FlatIndex, METRIC_IP
+    x, q = _data(60_000, 128, 64)
+    idx = FlatIndex(128, METRIC_IP, normalize=True)
+    idx.add(x)
+    ref = [idx.search(q[i:i + 4], 10) for i in range(0, 64, 4)]
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        got = list(ex.map(lambda i: idx.search(q[i:i + 4], 10), range(0, 64, 4)))
+    for (Dr, Ir), (Dg, Ig) in zip(ref, got):
+        assert np.array_equal(Ir, Ig) and np.array_equal(Dr, Dg)
+    idx.close()
