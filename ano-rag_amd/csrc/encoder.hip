@@ -606,11 +606,11 @@ __global__ __launch_bounds__(256) void k_gemm_lds(GemmParams p) {
 // (same bytes to the same LDS address).
 __device__ __forceinline__ void gemm_glds16(const uint4 *g, uint4 *l) { __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0); }
 
-template <int EPI, int TN>
+template <int EPI, int TN, int S>
 __global__ __launch_bounds__(512) void k_gemm_lds8(GemmParams p) {
-  constexpr int TM = 8, S = 3, F = TM + TN, NW = TN / 2;  // NW: feature tiles per wave
-  constexpr int LPW = (S * F + 7) / 8;                      // fragment copies per wave per stage
-  static_assert(LPW == 6, "the counted vmcnt below assumes six copies per wave per stage");
+  constexpr int TM = 8, F = TM + TN, NW = TN / 2;  // NW: feature tiles per wave; S k-steps per ring slot (3, or 2 when KB % 3 != 0)
+  constexpr int LPW = (S * F + 7) / 8;               // fragment copies per wave per stage
+  static_assert(LPW == 6 || LPW == 4, "the counted vmcnt below knows six or four copies per wave per stage");
   extern __shared__ uint4 g_lds[];  // ring [3][S][F][64]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int NG = (p.NB + TN - 1) / TN;
@@ -647,8 +647,12 @@ __global__ __launch_bounds__(512) void k_gemm_lds8(GemmParams p) {
     for (int i = 0; i < LPW; ++i) gemm_glds16(src[i] + (int64_t)S * 64, g_lds + BUF + dst[i]);
   }
   for (int s = 0; s < nstages; ++s) {
-    if (s + 1 < nstages) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // LPW copies of stage s+1 stay in flight
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (s + 1 < nstages) {  // LPW copies of stage s+1 stay in flight
+      if (LPW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     if (s + 2 < nstages) {
@@ -911,9 +915,15 @@ int plain_copy(const float *host, int64_t n, float **dst) {
 
 template <int EPI, int TN>
 void launch_gemm8(anr_encoder *e, GemmParams &g, int64_t blocks) {
-  constexpr int lds8 = 3 * 3 * (8 + TN) * 1024;
-  (void)ensure_dynamic_lds(reinterpret_cast<const void *>(&k_gemm_lds8<EPI, TN>), lds8);
-  hipLaunchKernelGGL((k_gemm_lds8<EPI, TN>), dim3((unsigned)blocks), dim3(512), lds8, e->stream, g);
+  if (g.KB % 3 == 0) {
+    constexpr int lds8 = 3 * 3 * (8 + TN) * 1024;
+    (void)ensure_dynamic_lds(reinterpret_cast<const void *>(&k_gemm_lds8<EPI, TN, 3>), lds8);
+    hipLaunchKernelGGL((k_gemm_lds8<EPI, TN, 3>), dim3((unsigned)blocks), dim3(512), lds8, e->stream, g);
+  } else {  // KB is even (hidden sizes are multiples of 32): two k-steps per slot, e.g. H = 1024 (bge-m3, XLM-R large)
+    constexpr int lds8 = 3 * 2 * (8 + TN) * 1024;
+    (void)ensure_dynamic_lds(reinterpret_cast<const void *>(&k_gemm_lds8<EPI, TN, 2>), lds8);
+    hipLaunchKernelGGL((k_gemm_lds8<EPI, TN, 2>), dim3((unsigned)blocks), dim3(512), lds8, e->stream, g);
+  }
 }
 
 template <int EPI>
@@ -934,7 +944,7 @@ void launch_gemm(anr_encoder *e, GemmParams &g) {
     return;
   }
   static const bool wide = getenv("ANORAG_GEMM_NARROW") == nullptr;  // developer switch: the 4-wave tile everywhere
-  if (wide && g.KB % 3 == 0 && g.TB >= 8 * 16) {
+  if (wide && g.KB % 2 == 0 && g.TB >= 8 * 16) {
     // tile width by grid shape: fewest rounds of workgroups over the CUs, weighted by the work per workgroup
     const int64_t b8 = ceil_div(g.TB, 8) * ceil_div(g.NB, 8), b6 = ceil_div(g.TB, 8) * ceil_div(g.NB, 6);
     const int64_t cost8 = ceil_div(b8, e->n_cu) * 8, cost6 = ceil_div(b6, e->n_cu) * 6;

@@ -80,3 +80,21 @@ def test_mpnet_relative_position_bias(tmp_path):
     assert cos.min() >= 0.9995, cos.min()
     assert np.max(np.abs(got - ref)) <= 5e-3
     enc.close()
+
+
+def test_large_batch_takes_the_tiled_gemm_paths(tmp_path):
+    """> 5120 tokens in one forward: the 256 x 256 / 256 x 192 LDS-staged GEMM tiles instead of the skinny kernel,
+    here with a hidden size whose K depth is not a multiple of 3 k-steps (the two-k-step ring, as for H = 1024 /
+    bge-m3), ragged sentence lengths, token and feature tails that do not fill a tile"""
+    d = oenc.make_synthetic_model(str(tmp_path / "m"), layers=2, hidden=256, heads=4, intermediate=1024, pooling="mean")
+    sents = oenc.synthetic_sentences(d, 230, seed=9, min_words=10, max_words=34)
+    from anorag_hip.encoder import SentenceEncoder
+    ref = oenc.encode(d, sents, batch_size=230, normalize=True)
+    enc = SentenceEncoder(d)
+    ids, lens, _ = enc.tokenize(sents)
+    assert ids.shape[0] * ((ids.shape[1] + 31) // 32 * 32) > 5120 + 512     # really past the skinny kernel's range
+    got = enc.encode(sents, batch_size=230, normalize_embeddings=True)
+    cos = np.sum(got * ref, axis=1)
+    assert cos.min() >= 0.9995, cos.min()
+    assert np.max(np.abs(got - ref)) <= 5e-3
+    enc.close()

@@ -8,8 +8,11 @@ from oracle import encoder as oenc
 from anorag_hip.encoder import SentenceEncoder
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-md = oenc.make_synthetic_model(os.path.join(tempfile.mkdtemp(), "bge-base-synth"), layers=12, hidden=768, heads=12,
-                               intermediate=3072, vocab=30522, max_pos=512, pooling="cls", weight_std=0.03)
+SHAPE = os.environ.get("SHAPE", "bge-base")  # or bge-m3 (XLM-R large: the reference's default model), minilm
+LAYERS, H, HEADS, I = {"bge-base": (12, 768, 12, 3072), "bge-m3": (24, 1024, 16, 4096), "minilm": (6, 384, 12, 1536)}[SHAPE]
+md = oenc.make_synthetic_model(os.path.join(tempfile.mkdtemp(), SHAPE + "-synth"), layers=LAYERS, hidden=H, heads=HEADS,
+                               intermediate=I, vocab=30522, max_pos=512, pooling="cls", weight_std=0.03,
+                               model_type="xlm-roberta" if SHAPE == "bge-m3" else "bert")
 enc = SentenceEncoder(md)
 ids = np.random.default_rng(0).integers(5, 30000, size=(B, L)).astype(np.int32)
 lens = np.full((B,), L, dtype=np.int32)
@@ -19,5 +22,5 @@ n = 10
 for _ in range(n): enc._enc.forward(ids, lens, np.zeros_like(ids), normalize=True)
 dt = (time.perf_counter() - t0) / n
 T = B * L
-flops = 12 * (2 * T * (4 * 768 * 768 + 2 * 768 * 3072)) + 12 * 4 * B * L * L * 768
-print(f"B={B} L={L} tokens={T}: {dt*1e3:.3f} ms/forward  {flops/dt/1e12:.1f} TFLOP/s  {B/dt:.0f} seq/s")
+flops = LAYERS * (2 * T * (4 * H * H + 2 * H * I)) + LAYERS * 4 * B * L * L * H
+print(f"{SHAPE} B={B} L={L} tokens={T}: {dt*1e3:.3f} ms/forward  {flops/dt/1e12:.1f} TFLOP/s  {B/dt:.0f} seq/s")
