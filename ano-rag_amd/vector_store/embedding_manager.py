@@ -258,13 +258,14 @@ class EmbeddingManager:
                             device=self.hip_device)
             try:
                 idx.add(b)
+                # exact value of every (row of a, row of b) pair: the gather-dot kernel over all ids, in column
+                # blocks so that the id matrix stays small
                 sim = np.empty((a.shape[0], n), dtype=np.float64)
-                kmax = 1024
-                if n <= kmax:
-                    D, I = idx.search(a, n)
-                    np.put_along_axis(sim, I, D.astype(np.float64), axis=1)
-                else:
-                    raise ValueError(f"compute_similarity handles at most {kmax} candidates on the device")
+                a32 = np.ascontiguousarray(a, dtype=np.float32)
+                step = 4096
+                for c0 in range(0, n, step):
+                    ids = np.tile(np.arange(c0, min(n, c0 + step), dtype=np.int64), (a32.shape[0], 1))
+                    sim[:, c0:c0 + ids.shape[1]] = idx.score_rows(a32, ids)
             finally:
                 idx.close()
             if metric == "euclidean":

@@ -111,6 +111,16 @@ def test_embedding_manager_and_retriever(cfg, model_dir):
     assert t == f"t0 || {words[0]} || ENTITIES: e1, e2"
     sim = em.compute_similarity(e1, e1)
     assert sim.shape == (5, 5) and np.allclose(np.diag(sim), 1.0, atol=1e-4)
+    # any number of candidates, all three metrics, against the reference's formulas (embedding_manager.py:602-620)
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((7, 128)).astype(np.float32)
+    Bm = rng.standard_normal((5003, 128)).astype(np.float32)
+    An = A / (np.linalg.norm(A, axis=1, keepdims=True) + 1e-8)
+    Bn = Bm / (np.linalg.norm(Bm, axis=1, keepdims=True) + 1e-8)
+    assert np.allclose(em.compute_similarity(A, Bm, "cosine"), An @ Bn.T, atol=2e-6)
+    assert np.allclose(em.compute_similarity(A, Bm, "dot"), A.astype(np.float64) @ Bm.astype(np.float64).T, rtol=1e-5, atol=1e-4)
+    dist = np.sqrt(((A[:, None, :].astype(np.float64) - Bm[None, :, :]) ** 2).sum(-1))
+    assert np.allclose(em.compute_similarity(A, Bm, "euclidean"), 1.0 / (1.0 + dist), atol=1e-5)
     top = em.find_most_similar(e1[0], e1, top_k=2)
     assert top[0]["index"] == 0 and set(top[0]) == {"index", "similarity"}
     ok, _ = em.validate_model_consistency()
