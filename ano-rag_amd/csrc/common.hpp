@@ -48,6 +48,18 @@ struct DeviceGuard {
 
 int device_cu_count(int device);
 
+// top-k beyond the select window (largek.hip): full device sort of one query's exact scores
+struct LargeKScratch {
+  unsigned *iota = nullptr, *rows = nullptr;
+  float *keys = nullptr;
+  void *temp = nullptr;
+  size_t temp_bytes = 0;
+  int64_t n = 0;
+};
+int sort_topk(const float *scores_dev, int64_t n, int k, bool larger_is_better, int64_t id_offset, float *D_row,
+              int64_t *I_row, LargeKScratch *s, hipStream_t st);
+void free_largek(LargeKScratch *s);
+
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, current device): the attribute belongs to the
 // device's copy of the kernel, so a process that drives several GPUs needs it on each; thread-safe
 int ensure_dynamic_lds(const void *kernel, int bytes);

@@ -93,6 +93,7 @@ struct anr_index {
   bool xstat_dirty = true;
 
   float *xdense = nullptr;      // exact dense path [4][xdense_ld]
+  LargeKScratch largek;         // device sort scratch of the k > 1024 path
   int64_t xdense_ld = 0;
   float *d_out = nullptr;       // staging for host-pointer searches
   int64_t *i_out = nullptr;
@@ -722,17 +723,74 @@ int write_empty(const anr_index *h, int64_t nq, int32_t k, float *D, int64_t *I,
   return ANR_OK;
 }
 
-int check_search_args(const anr_index *h, const void *q, int64_t nq, int32_t k, const void *D, const void *I) {
+constexpr int kMaxLargeK = 1 << 20;
+
+int check_search_args(const anr_index *h, const void *q, int64_t nq, int32_t k, const void *D, const void *I,
+                      bool allow_large_k) {
   if (!h || !q || !D || !I) return fail(ANR_EINVAL, "null argument");
   if (nq < 0 || k <= 0) return fail(ANR_EINVAL, "nq must be >= 0 and k > 0");
-  if (k > kMaxSel) return fail(ANR_EINVAL, "k = %d exceeds the supported maximum %d", k, kMaxSel);
+  if (k > (allow_large_k ? kMaxLargeK : kMaxSel))
+    return fail(ANR_EINVAL, "k = %d exceeds the supported maximum %d%s", k, allow_large_k ? kMaxLargeK : kMaxSel,
+                allow_large_k ? "" : " of asynchronous searches (use the synchronous call)");
+  return ANR_OK;
+}
+
+// k beyond the select window: exact scores of every row (k_exact_dense, 4 queries per pass), device radix sort, first k
+// pairs (largek.hip).  Synchronous; D / I are device memory here.
+int search_large_k(anr_index *h, const float *q, bool q_on_host, int64_t nq, int k, float *Dd, int64_t *Id) {
+  hipStream_t st = h->stream;
+  Workspace &w = h->ws[0];
+  const int64_t ld = round_up(h->ntotal, 32);
+  if (!h->xdense || h->xdense_ld < ld) {
+    dev_free(h->xdense);
+    h->xdense_ld = ld;
+    ANR_TRY(dev_alloc(&h->xdense, 4 * ld, false));
+  }
+  for (int64_t q0 = 0; q0 < nq; q0 += kQB) {
+    const int nb = (int)std::min<int64_t>(kQB, nq - q0);
+    ANR_HIP(hipMemcpyAsync(w.qstage, q + q0 * h->dim, (size_t)nb * h->dim * sizeof(float),
+                           q_on_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, st));
+    PrepQParams qp{};
+    qp.qin = w.qstage;
+    qp.nq = nb;
+    qp.dim = h->dim;
+    qp.dimp = h->dimp;
+    qp.kb = h->kb;
+    qp.normalize = h->normalize;
+    qp.q32 = w.q32;
+    qp.q16 = w.q16;
+    qp.qstat = w.qstat;
+    hipLaunchKernelGGL(k_prepq, dim3(kQB), dim3(256), 0, st, qp);
+    for (int b = 0; b < nb; b += 4) {
+      const int nf = std::min(4, nb - b);
+      ExactParams ep{};
+      ep.x32 = h->x32;
+      ep.q32 = w.q32;
+      ep.dim = h->dim;
+      ep.dimp = h->dimp;
+      ep.metric = h->metric;
+      ep.n_rows = h->ntotal;
+      ep.nf = nf;
+      for (int f = 0; f < nf; ++f) ep.qidx[f] = b + f;
+      ep.dense = h->xdense;
+      ep.ld = h->xdense_ld;
+      int64_t grid = ceil_div(h->ntotal, 4);
+      if (grid > (int64_t)h->n_cu * 16) grid = (int64_t)h->n_cu * 16;
+      hipLaunchKernelGGL(k_exact_dense, dim3((unsigned)grid), dim3(256), 0, st, ep);
+      for (int f = 0; f < nf; ++f)
+        ANR_TRY(sort_topk(h->xdense + (int64_t)f * h->xdense_ld, h->ntotal, k, h->metric == ANR_METRIC_IP, h->id_offset,
+                          Dd + (q0 + b + f) * (int64_t)k, Id + (q0 + b + f) * (int64_t)k, &h->largek, st));
+    }
+    ANR_HIP(hipStreamSynchronize(st));  // qstage / q32 are reused by the next block of queries
+  }
+  h->stats.n_dense_exact += nq;
   return ANR_OK;
 }
 
 // synchronous search (host or device buffers): enqueue every batch, then retire them all
 int search_impl(anr_index *h, const float *q, bool q_on_host, int64_t nq, int32_t k, float *D, int64_t *I,
                 bool out_on_host, hipStream_t st) {
-  ANR_TRY(check_search_args(h, q, nq, k, D, I));
+  ANR_TRY(check_search_args(h, q, nq, k, D, I, true));
   DeviceGuard g(h->device);
   if (!g.ok) return fail(ANR_EHIP, "hipSetDevice(%d) failed", h->device);
   std::lock_guard<std::mutex> lk(h->mu);
@@ -775,20 +833,24 @@ int search_impl(anr_index *h, const float *q, bool q_on_host, int64_t nq, int32_
     Id = h->i_out;
   }
   if (h->timing) ANR_HIP(hipEventRecord(h->ev_call[0], st));
-  for (int64_t q0 = 0; q0 < nq; q0 += kQB) {
-    const int nb = (int)std::min<int64_t>(kQB, nq - q0);
-    const float *qd = q + q0 * h->dim;
-    const float *pinned_src = nullptr;
-    if (q_on_host) {
-      Workspace &w = h->ws[h->next_ws];
-      ANR_TRY(retire(h, w));  // its staging buffer is about to be overwritten
-      memcpy(w.qpin, qd, (size_t)nb * h->dim * sizeof(float));
-      pinned_src = w.qpin;
-      qd = w.qstage;
+  if (k > kMaxSel) {
+    ANR_TRY(search_large_k(h, q, q_on_host, nq, k, Dd, Id));
+  } else {
+    for (int64_t q0 = 0; q0 < nq; q0 += kQB) {
+      const int nb = (int)std::min<int64_t>(kQB, nq - q0);
+      const float *qd = q + q0 * h->dim;
+      const float *pinned_src = nullptr;
+      if (q_on_host) {
+        Workspace &w = h->ws[h->next_ws];
+        ANR_TRY(retire(h, w));  // its staging buffer is about to be overwritten
+        memcpy(w.qpin, qd, (size_t)nb * h->dim * sizeof(float));
+        pinned_src = w.qpin;
+        qd = w.qstage;
+      }
+      ANR_TRY(enqueue_batch(h, qd, nb, k, q0, Dd, Id, st, zero_copy_out, pinned_src));
     }
-    ANR_TRY(enqueue_batch(h, qd, nb, k, q0, Dd, Id, st, zero_copy_out, pinned_src));
+    ANR_TRY(drain(h));
   }
-  ANR_TRY(drain(h));
   if (h->timing) {
     ANR_HIP(hipEventRecord(h->ev_call[1], st));
     ANR_HIP(hipEventSynchronize(h->ev_call[1]));
@@ -907,6 +969,7 @@ int anr_index_destroy(anr_index *h) {
   dev_free(h->xstat);
   free_workspaces(h);
   dev_free(h->xdense);
+  free_largek(&h->largek);
   dev_free(h->d_out);
   dev_free(h->i_out);
   if (h->out_pin) (void)hipHostFree(h->out_pin);
@@ -1000,7 +1063,7 @@ int anr_index_search_dev(anr_index *h, const float *q_dev, int64_t nq, int32_t k
 
 int anr_index_search_dev_async(anr_index *h, const float *q_dev, int64_t nq, int32_t k, float *D_dev,
                                int64_t *I_dev, void *stream) {
-  ANR_TRY(check_search_args(h, q_dev, nq, k, D_dev, I_dev));
+  ANR_TRY(check_search_args(h, q_dev, nq, k, D_dev, I_dev, false));
   DeviceGuard g(h->device);
   if (!g.ok) return fail(ANR_EHIP, "hipSetDevice(%d) failed", h->device);
   std::lock_guard<std::mutex> lk(h->mu);

@@ -292,7 +292,7 @@ class EmbeddingManager:
                             device=self.hip_device)
             try:
                 idx.add(c)
-                k = min(int(top_k), c.shape[0], 1024)
+                k = min(int(top_k), c.shape[0])
                 D, I = idx.search(q, k)
             finally:
                 idx.close()

@@ -62,7 +62,8 @@ int anr_index_reconstruct(anr_index *h, int64_t i0, int64_t n, float *out_host);
 /* Search nq queries for the k best rows (vector_index.py:223).  D[nq*k] scores best-first (inner
  * product, or squared L2), I[nq*k] row ids, padded with -1 (and -FLT_MAX / +FLT_MAX scores) when
  * k > ntotal, the faiss convention vector_index.py:234 relies on.  Ties in score are ordered by
- * ascending id.  Results are the exact top-k of the stored float32 rows. */
+ * ascending id.  Results are the exact top-k of the stored float32 rows.  k <= 1024 runs the streaming
+ * pipeline; larger k (up to 2^20, synchronous calls only) computes every row's exact score and sorts on the device. */
 int anr_index_search(anr_index *h, const float *q_host, int64_t nq, int32_t k, float *D, int64_t *I);
 /* same with device buffers, asynchronous on `stream` apart from one small status read-back */
 int anr_index_search_dev(anr_index *h, const float *q_dev, int64_t nq, int32_t k, float *D_dev,

@@ -455,3 +455,26 @@ def test_concurrent_searches_from_worker_threads():
     for (Dr, Ir), (Dg, Ig) in zip(ref, got):
         assert np.array_equal(Ir, Ig) and np.array_equal(Dr, Dg)
     idx.close()
+
+
+def test_k_beyond_the_select_window_uses_the_device_sort():
+    """k > 1024 (faiss accepts any k; retrieve() over-fetches top_k x 3): exact scores of every row + device radix
+    sort; cosine and L2, k > n padding, ties by ascending id, id offset"""
+    from anorag_hip import FlatIndex, METRIC_IP, METRIC_L2
+    from anorag_hip._lib import OPT_ID_OFFSET
+    x, q = _data(20_011, 96, 5)
+    x[100:110] = x[7]                                    # duplicate rows: equal scores, ascending ids expected
+    q[0] = x[7]                                          # ... and query 0 finds them first
+    idx = FlatIndex(96, METRIC_IP, normalize=True)
+    idx.add(x)
+    D, I, Dr, Ir = _check(idx, x, q, 3000, "ip", True)
+    assert idx.last_stats()["n_dense_exact"] == 5
+    assert list(I[0, :11]) == [7] + list(range(100, 110))
+    idx.set_option(OPT_ID_OFFSET, 5000)
+    D2, I2 = idx.search(q[:2], 2048)
+    assert np.array_equal(I2, I[:2, :2048] + 5000) and np.array_equal(D2, D[:2, :2048])
+    idx.close()
+    l2 = FlatIndex(96, METRIC_L2, normalize=False)
+    l2.add(x[:1500])
+    _check(l2, x[:1500], q, 2000, "l2", False)          # k > n: -1 padding
+    l2.close()
