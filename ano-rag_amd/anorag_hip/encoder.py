@@ -143,8 +143,12 @@ def relative_bias_table(weight: np.ndarray, span: int, max_distance: int = 128) 
 def load_weights(path: str) -> Dict[str, np.ndarray]:
     st = os.path.join(path, "model.safetensors")
     if os.path.exists(st):
-        from safetensors.numpy import load_file
-        raw = load_file(st)
+        try:
+            from safetensors.numpy import load_file
+            raw = load_file(st)
+        except (TypeError, ValueError):  # bfloat16 checkpoints have no numpy dtype: go through torch
+            from safetensors.torch import load_file as load_torch
+            raw = {k: v.float().numpy() for k, v in load_torch(st).items()}
     else:
         import torch
         raw = {k: v.float().numpy() for k, v in torch.load(os.path.join(path, "pytorch_model.bin"),

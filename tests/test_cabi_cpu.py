@@ -137,3 +137,23 @@ def test_mpnet_parameter_names_map_to_encoder_tensors():
     assert map_hf_name("encoder.relative_attention_bias.weight") == "rel.weight"
     assert map_hf_name("embeddings.word_embeddings.weight") == "emb.word"
     assert map_hf_name("pooler.dense.weight") is None
+
+
+def test_bfloat16_and_float16_checkpoints_load_as_float32(tmp_path):
+    """host logic: safetensors checkpoints stored in f16 or bf16 (no numpy dtype for the latter) arrive as float32"""
+    import os
+    import torch
+    from safetensors.torch import load_file, save_file
+    from oracle import encoder as oenc
+    from anorag_hip import encoder as penc
+    d = oenc.make_synthetic_model(str(tmp_path / "m"), layers=1, hidden=64, heads=2, intermediate=128, vocab=300, max_pos=64)
+    ref = penc.load_weights(d)
+    st = os.path.join(d, "model.safetensors")
+    t = load_file(st)
+    for dt, tol in ((torch.float16, 2e-3), (torch.bfloat16, 2e-2)):
+        save_file({k: v.to(dt) for k, v in t.items()}, st)
+        w = penc.load_weights(d)
+        assert set(w) == set(ref)
+        for k in ref:
+            assert w[k].dtype == np.float32 and w[k].shape == ref[k].shape
+            assert np.max(np.abs(w[k] - ref[k])) <= tol * max(1.0, float(np.max(np.abs(ref[k]))))
