@@ -478,3 +478,29 @@ def test_k_beyond_the_select_window_uses_the_device_sort():
     l2.add(x[:1500])
     _check(l2, x[:1500], q, 2000, "l2", False)          # k > n: -1 padding
     l2.close()
+
+
+def test_candidate_list_overflow_falls_back_to_the_dense_exact_path():
+    """a list capacity far too small for the data (ANR_OPT_CAND_CAP = 64 entries per workgroup and query, every row
+    of a 40 000-row cluster that the sample never sees is above the threshold): the overflow is detected and the dense exact path answers, exactly"""
+    from anorag_hip import FlatIndex, METRIC_IP
+    from anorag_hip._lib import OPT_CAND_CAP
+    rng = np.random.default_rng(21)
+    n, d, nq, k = 200_000, 64, 6, 20
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    c = rng.standard_normal(d).astype(np.float32)
+    from anorag_hip._lib import OPT_SAMPLE_ROWS
+    sample_rows = 12288                                  # 384 sample tiles -> every 16th tile is sampled
+    tiles = np.arange(n // 32)
+    unsampled = tiles[tiles % ((n // 32) // (sample_rows // 32)) != 0]
+    hot = (rng.choice(unsampled, 1250, replace=False)[:, None] * 32 + np.arange(32)[None, :]).ravel()  # 40 000 rows
+    x[hot] = c + 0.15 * rng.standard_normal((len(hot), d)).astype(np.float32)  # a cluster the sample never sees
+    q = (c + 0.15 * rng.standard_normal((nq, d))).astype(np.float32)
+    idx = FlatIndex(d, METRIC_IP, normalize=True)
+    idx.add(x)
+    idx.set_option(OPT_SAMPLE_ROWS, sample_rows)
+    idx.set_option(OPT_CAND_CAP, 64)
+    _check(idx, x, q, k, "ip", True)
+    st = idx.last_stats()
+    assert st["n_overflow"] > 0 and st["n_dense_exact"] > 0, st
+    idx.close()
