@@ -86,6 +86,7 @@ SIGNATURES = {
         [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],
     ),
     "anr_index_sync": (C.c_int, [C.c_void_p]),
+    "anr_index_wait": (C.c_int, [C.c_void_p, C.c_int32]),
     "anr_index_reset_stats": (C.c_int, [C.c_void_p]),
     "anr_index_score_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]),
     "anr_index_self_join": (
@@ -104,6 +105,10 @@ SIGNATURES = {
         C.c_int,
         [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
          C.c_void_p, C.c_void_p, C.c_void_p],
+    ),
+    "anr_merge_topk_host": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p],
     ),
     "anr_fuse_lists": (
         C.c_int,

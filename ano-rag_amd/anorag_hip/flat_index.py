@@ -141,6 +141,10 @@ class FlatIndex:
     def sync(self) -> None:
         _lib.check(self._lib.anr_index_sync(self._h), "anr_index_sync")
 
+    def wait(self, keep: int = 0) -> None:
+        """retire the oldest in-flight batches until at most ``keep`` remain: their results are final"""
+        _lib.check(self._lib.anr_index_wait(self._h, int(keep)), "anr_index_wait")
+
     def reset_stats(self) -> None:
         _lib.check(self._lib.anr_index_reset_stats(self._h), "anr_index_reset_stats")
 

@@ -1,16 +1,28 @@
-"""Row-sharded exact search over the GPUs of one node: one process per GPU
-(``torch.distributed``; backend "nccl" is RCCL over xGMI on ROCm), shard g holds the contiguous rows
-``[g*ceil(N/P), ...)``, every rank scans its shard for the same query batch, the ``[B, k]`` partial results
-(score f32, global id i64 — ~0.6 MB in total for B=64, k=100, P=8) are all-gathered and merged.
+"""Row-sharded exact search over the GPUs of one node.
 
-Two merge paths with identical results (score order, ties by ascending global id, -1 padding last):
-``merge_topk_host`` (numpy; what BASELINE.json's north_star prescribes, also used by the CPU/gloo tests) and
-the device kernel ``anr_merge_topk_dev`` used when the partials already sit on the GPU.
+Shard g holds contiguous rows, every shard scans for the same query batch, and only the ``[B, k]`` partial
+results (score f32 + global id i64 — 0.6 MB in total for B=64, k=100, P=8) are exchanged and merged
+(score order, ties by ascending global id, -1 padding last).  Two front ends over the same C ABI:
+
+``ShardedFlatIndex``  ONE process drives P handles (one per listed device) — the form the drop-in ``VectorIndex``
+    uses when ``anorag_hip.devices`` names several GPUs, because the reference's caller builds one
+    ``VectorRetriever`` per process (query/query_processor.py:260-293).  The shard searches run concurrently from a
+    thread pool (ctypes releases the GIL; every handle has its own streams), each writes its partial top-k straight
+    into pinned host memory, and the partials are merged on the host (``anr_merge_topk_host``) — BASELINE.json
+    north_star: "per-shard local top-k merged on the host".
+
+``ShardedSearcher``  one process per GPU under ``torch.distributed`` (bench.py's layout).  With the "nccl" backend
+    (RCCL over xGMI) everything stays on the device: the shard writes scores and ids into one packed buffer
+    ``[B*k f32 | B*k i64]``, the batch is made final (``FlatIndex.wait`` — certificate recovery included), the
+    partials of all ranks travel in ONE ``all_gather_into_tensor`` and ``anr_merge_topk_strided_dev`` merges out of
+    the receive buffer.  With "gloo" (CPU rehearsal / tests) the same packed buffer is gathered as a host tensor
+    and merged with ``anr_merge_topk_host`` (``merge_topk_host`` is the numpy statement of the same merge).
 """
 from __future__ import annotations
 
 import ctypes as C
-from typing import Callable, Tuple
+from concurrent.futures import ThreadPoolExecutor
+from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -25,7 +37,7 @@ def shard_bounds(n_total: int, world: int, rank: int) -> Tuple[int, int]:
 
 
 def merge_topk_host(Dp: np.ndarray, Ip: np.ndarray, k: int, larger_is_better: bool = True):
-    """Dp/Ip: [P, B, k] partial lists (global ids, -1 padded).  Returns (D [B,k], I [B,k])."""
+    """numpy statement of the merge.  Dp/Ip: [P, B, k'] partial lists (global ids, -1 padded) -> (D [B,k], I [B,k])."""
     P, B, kk = Dp.shape
     D = np.full((B, k), -FLT_MAX if larger_is_better else FLT_MAX, dtype=np.float32)
     I = np.full((B, k), -1, dtype=np.int64)
@@ -41,32 +53,259 @@ def merge_topk_host(Dp: np.ndarray, Ip: np.ndarray, k: int, larger_is_better: bo
     return D, I
 
 
-class ShardedSearcher:
-    """Distributed front end.  ``local_search(q, k) -> (D, I_local)`` is the rank's own shard search (numpy in /
-    numpy out); ids are offset by the shard's first row before the exchange."""
+def merge_topk_host_c(Dp: np.ndarray, Ip: np.ndarray, larger_is_better: bool = True):
+    """the library's host merge (anr_merge_topk_host): Dp/Ip [P, B, k] sorted partial lists -> (D [B,k], I [B,k])"""
+    from . import _lib
+    P, B, k = Dp.shape
+    Dp = np.ascontiguousarray(Dp, dtype=np.float32)
+    Ip = np.ascontiguousarray(Ip, dtype=np.int64)
+    D = np.empty((B, k), dtype=np.float32)
+    I = np.empty((B, k), dtype=np.int64)
+    _lib.check(_lib.load().anr_merge_topk_host(Dp.ctypes.data_as(C.c_void_p), Ip.ctypes.data_as(C.c_void_p), int(P),
+                                               int(B), int(k), int(bool(larger_is_better)),
+                                               D.ctypes.data_as(C.c_void_p), I.ctypes.data_as(C.c_void_p)),
+               "anr_merge_topk_host")
+    return D, I
 
-    def __init__(self, local_search: Callable, row_offset: int, larger_is_better: bool = True, group=None):
+
+class ShardedFlatIndex:
+    """``FlatIndex`` surface over P row shards driven by one process (one handle per entry of ``devices``; a device
+    may be listed more than once).  Every ``add`` call is cut into P contiguous pieces, piece p appended to shard p,
+    and ids stay the sequential ids of the add order (faiss ``IndexFlat.add``, reference vector_index.py:196)."""
+
+    def __init__(self, d: int, metric: int = 0, normalize: bool = False, devices: Sequence[int] = (0,)):
+        from .flat_index import FlatIndex
+        if not devices:
+            raise ValueError("ShardedFlatIndex needs at least one device")
+        self.d, self.metric, self.normalize = int(d), int(metric), bool(normalize)
+        self.devices = [int(v) for v in devices]
+        self.device = self.devices[0]
+        self.is_trained = True
+        self.shards: List = []
+        try:
+            for dev in self.devices:
+                self.shards.append(FlatIndex(d, metric, normalize, device=dev))
+        except Exception:
+            self.close()
+            raise
+        # per shard the segments (local_start, global_start, count) of its rows, in add order
+        self._segs: List[List[Tuple[int, int, int]]] = [[] for _ in self.devices]
+        self._ntotal = 0
+        self._offset_mode = True  # every shard holds one segment: it returns global ids itself (ANR_OPT_ID_OFFSET)
+        self._pool = ThreadPoolExecutor(max_workers=len(self.devices), thread_name_prefix="anr-shard")
+
+    # -- bookkeeping ---------------------------------------------------------------------------------
+    @property
+    def ntotal(self) -> int:
+        return self._ntotal
+
+    @property
+    def larger_is_better(self) -> bool:
+        return self.metric == 0
+
+    def _sync_offsets(self) -> None:
+        from ._lib import OPT_ID_OFFSET
+        single = all(len(s) <= 1 for s in self._segs)
+        for sh, segs in zip(self.shards, self._segs):
+            sh.set_option(OPT_ID_OFFSET, segs[0][1] if (single and segs) else 0)
+        self._offset_mode = single
+
+    def _to_global(self, p: int, I: np.ndarray) -> np.ndarray:
+        segs = self._segs[p]
+        if not segs:
+            return I
+        starts = np.array([s[0] for s in segs], dtype=np.int64)
+        shift = np.array([s[1] - s[0] for s in segs], dtype=np.int64)
+        j = np.clip(np.searchsorted(starts, I, side="right") - 1, 0, len(segs) - 1)
+        return np.where(I >= 0, I + shift[j], -1)
+
+    # -- FlatIndex surface ---------------------------------------------------------------------------
+    def reserve(self, n: int) -> None:
+        per = (int(n) + len(self.shards) - 1) // len(self.shards)
+        for sh in self.shards:
+            sh.reserve(max(per, sh.ntotal))
+
+    def add(self, x) -> None:
+        x = np.asarray(x)
+        if x.ndim != 2 or x.shape[1] != self.d:
+            raise ValueError(f"add: expected a 2-D array with {self.d} columns, got shape {x.shape}")
+        n, P = x.shape[0], len(self.shards)
+        if n == 0:
+            return
+        pieces = []
+        for p in range(P):
+            lo, hi = shard_bounds(n, P, p)
+            if hi > lo:
+                pieces.append((p, lo, hi))
+        list(self._pool.map(lambda t: self.shards[t[0]].add(x[t[1]:t[2]]), pieces))
+        for p, lo, hi in pieces:
+            self._segs[p].append((self.shards[p].ntotal - (hi - lo), self._ntotal + lo, hi - lo))
+        self._ntotal += n
+        self._sync_offsets()
+
+    def search(self, q, k: int):
+        q = np.ascontiguousarray(np.asarray(q), dtype=np.float32)
+        if q.ndim != 2 or q.shape[1] != self.d:
+            raise ValueError(f"search: expected a 2-D array with {self.d} columns, got shape {q.shape}")
+        k = int(k)
+        live = [p for p, sh in enumerate(self.shards) if sh.ntotal > 0]
+        if not live:
+            return (np.full((q.shape[0], k), -FLT_MAX if self.larger_is_better else FLT_MAX, dtype=np.float32),
+                    np.full((q.shape[0], k), -1, dtype=np.int64))
+        parts = list(self._pool.map(lambda p: self.shards[p].search(q, k), live))
+        if len(live) == 1 and self._offset_mode:
+            return parts[0]
+        Dp = np.stack([d for d, _ in parts])
+        Ip = np.stack([i if self._offset_mode else self._to_global(p, i) for p, (_, i) in zip(live, parts)])
+        return merge_topk_host_c(Dp, Ip, self.larger_is_better)
+
+    def reconstruct_n(self, i0: int, n: int) -> np.ndarray:
+        i0, n = int(i0), int(n)
+        if i0 < 0 or n < 0 or i0 + n > self._ntotal:
+            raise ValueError("row range out of bounds")
+        out = np.empty((n, self.d), dtype=np.float32)
+        for p, segs in enumerate(self._segs):
+            for ls, gs, cnt in segs:
+                lo, hi = max(gs, i0), min(gs + cnt, i0 + n)
+                if hi > lo:
+                    out[lo - i0:hi - i0] = self.shards[p].reconstruct_n(ls + (lo - gs), hi - lo)
+        return out
+
+    def score_rows(self, q, ids) -> np.ndarray:
+        q = np.ascontiguousarray(np.asarray(q), dtype=np.float32)
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        out = np.full(ids.shape, np.nan, dtype=np.float32)
+        for p, segs in enumerate(self._segs):
+            local = np.full(ids.shape, -1, dtype=np.int64)
+            for ls, gs, cnt in segs:
+                m = (ids >= gs) & (ids < gs + cnt)
+                local[m] = ids[m] - gs + ls
+            if (local >= 0).any():
+                got = self.shards[p].score_rows(q, local)
+                out[local >= 0] = got[local >= 0]
+        return out
+
+    def self_join(self, *a, **kw):
+        raise NotImplementedError("self_join runs on a single-device FlatIndex (graph_scans builds its own)")
+
+    def reset(self) -> None:
+        for sh in self.shards:
+            sh.reset()
+        self._segs = [[] for _ in self.shards]
+        self._ntotal = 0
+        self._sync_offsets()
+
+    def set_option(self, opt: int, value: int) -> None:
+        from ._lib import OPT_ID_OFFSET
+        if int(opt) == OPT_ID_OFFSET:
+            raise ValueError("the id offsets of a sharded index are managed by the index")
+        for sh in self.shards:
+            sh.set_option(opt, value)
+
+    def last_stats(self) -> dict:
+        tot: dict = {}
+        for sh in self.shards:
+            for key, v in sh.last_stats().items():
+                tot[key] = (max(tot.get(key, 0), v) if key in ("overfetch", "sample_rows", "scan_ms", "total_ms", "n_queries")
+                            else tot.get(key, 0) + v)
+        return tot
+
+    def close(self) -> None:
+        for sh in getattr(self, "shards", []):
+            sh.close()
+        self.shards = []
+        pool = getattr(self, "_pool", None)
+        if pool is not None:
+            pool.shutdown(wait=False)
+            self._pool = None
+
+    def __del__(self):  # pragma: no cover - best effort
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ShardedSearcher:
+    """One rank of a ``torch.distributed`` job (one process per GPU).  ``index`` is this rank's ``FlatIndex`` holding
+    its row shard (first global row = ``row_offset``); alternatively a ``local_search(q, k) -> (D, I_local)``
+    callable (numpy in / numpy out) for shard searches that do not come from the library (the CPU test uses the
+    oracle).  ``search`` returns the merged global top-k on every rank."""
+
+    def __init__(self, index_or_search, row_offset: int, larger_is_better: Optional[bool] = None, group=None):
         import torch.distributed as dist
         self.dist = dist
-        self.local_search = local_search
         self.row_offset = int(row_offset)
-        self.larger = bool(larger_is_better)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.backend = dist.get_backend(group) if dist.is_initialized() else None
+        self.index = None
+        self.local_search: Optional[Callable] = None
+        if callable(index_or_search):
+            self.local_search = index_or_search
+            self.larger = True if larger_is_better is None else bool(larger_is_better)
+        else:
+            from ._lib import OPT_ID_OFFSET
+            self.index = index_or_search
+            self.index.set_option(OPT_ID_OFFSET, self.row_offset)  # the shard returns global ids itself
+            self.larger = (self.index.metric == 0) if larger_is_better is None else bool(larger_is_better)
+        self._bufs = {}
 
-    def search(self, q: np.ndarray, k: int):
+    # -- device path: RCCL ---------------------------------------------------------------------------
+    def _search_device(self, q: np.ndarray, k: int):
         import torch
-        D, I = self.local_search(q, k)
-        I = np.where(I >= 0, I + self.row_offset, -1).astype(np.int64)
+        from . import _lib
+        idx = self.index
+        dev = torch.device("cuda", idx.device)
+        B = q.shape[0]
+        nres = B * k
+        key = (B, k)
+        if key not in self._bufs:
+            self._bufs[key] = (torch.empty(nres * 12, device=dev, dtype=torch.uint8),
+                               torch.empty(self.world * nres * 12, device=dev, dtype=torch.uint8),
+                               torch.empty((B, k), device=dev, dtype=torch.float32),
+                               torch.empty((B, k), device=dev, dtype=torch.int64))
+        mine, allp, Dm, Im = self._bufs[key]
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream(dev)
+            qd = torch.from_numpy(np.ascontiguousarray(q, dtype=np.float32)).to(dev, non_blocking=False)
+            idx.search_device_async(qd.data_ptr(), B, k, mine.data_ptr(), mine.data_ptr() + nres * 4, st.cuda_stream)
+            idx.wait(0)  # final on this shard (certificate recovery done) BEFORE anything leaves it
+            self.dist.all_gather_into_tensor(allp, mine, group=self.group)
+            _lib.check(_lib.load().anr_merge_topk_strided_dev(
+                idx.device, C.c_void_p(allp.data_ptr()), C.c_void_p(allp.data_ptr() + nres * 4), nres * 3,
+                (nres * 3) // 2, self.world, B, k, int(self.larger), C.c_void_p(Dm.data_ptr()),
+                C.c_void_p(Im.data_ptr()), C.c_void_p(st.cuda_stream)), "anr_merge_topk_strided_dev")
+            return Dm.cpu().numpy(), Im.cpu().numpy()
+
+    # -- host path: gloo / single rank -----------------------------------------------------------------
+    def _search_host(self, q: np.ndarray, k: int):
+        import torch
+        if self.index is not None:
+            D, I = self.index.search(q, k)  # global ids (ANR_OPT_ID_OFFSET)
+        else:
+            D, I = self.local_search(q, k)
+            I = np.where(I >= 0, I + self.row_offset, -1)
         D = np.ascontiguousarray(D, dtype=np.float32)
+        I = np.ascontiguousarray(I, dtype=np.int64)
         if self.world == 1:
             return D, I
-        dt, it = torch.from_numpy(D), torch.from_numpy(I)
-        dg = [torch.empty_like(dt) for _ in range(self.world)]
-        ig = [torch.empty_like(it) for _ in range(self.world)]
-        self.dist.all_gather(dg, dt, group=self.group)
-        self.dist.all_gather(ig, it, group=self.group)
-        return merge_topk_host(torch.stack(dg).numpy(), torch.stack(ig).numpy(), k, self.larger)
+        B = q.shape[0]
+        nres = B * k
+        packed = torch.empty(nres * 12, dtype=torch.uint8)  # one exchange: [B*k f32 | B*k i64]
+        packed[: nres * 4] = torch.from_numpy(D.reshape(-1).view(np.uint8))
+        packed[nres * 4:] = torch.from_numpy(I.reshape(-1).view(np.uint8))
+        parts = [torch.empty_like(packed) for _ in range(self.world)]
+        self.dist.all_gather(parts, packed, group=self.group)
+        Dp = np.stack([p[: nres * 4].numpy().view(np.float32).reshape(B, k) for p in parts])
+        Ip = np.stack([p[nres * 4:].numpy().view(np.int64).reshape(B, k) for p in parts])
+        return merge_topk_host_c(Dp, Ip, self.larger)
+
+    def search(self, q: np.ndarray, k: int):
+        q = np.asarray(q)
+        if self.index is not None and self.backend == "nccl" and self.world > 1:
+            return self._search_device(q, int(k))
+        return self._search_host(q, int(k))
 
 
 def merge_topk_device(device: int, Dg, Ig, k: int, larger_is_better: bool, D_out, I_out, stream: int = 0) -> None:

@@ -52,7 +52,8 @@ struct Workspace {
   unsigned *cnt_dev = nullptr;     // the same memory as the device addresses it
   hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
   // the batch in flight
-  bool in_flight = false;
+  bool in_flight = false;   // set once the batch's completion event has been recorded, cleared when it is final
+  bool folded = false;      // its statistics have been added to the handle's
   bool sparse = false, timed = false, exact_all = false;
   int nq = 0, k = 0, M = 0;
   int64_t out_off = 0, sample_rows = 0, scan_bytes = 0;
@@ -455,33 +456,40 @@ int run_second_pass(anr_index *h, Workspace &w, const std::vector<int> &slots, s
   return finish_from_lists(rescan, grid, false);
 }
 
-// wait for a workspace's batch, fold its statistics, run the exact path where the certificate failed
+// wait for a workspace's batch, fold its statistics, run the exact path where the certificate failed.
+// The batch stays "in flight" until its recovery passes have succeeded: if one fails the error is returned and a
+// later retire() of the same workspace tries again (statistics are folded once), so a batch is never reported
+// final while some of its D / I rows are not.
 int retire(anr_index *h, Workspace &w) {
   if (!w.in_flight) return ANR_OK;
-  w.in_flight = false;
   ANR_HIP(hipEventSynchronize(w.ev_done));
   std::vector<int> fallback;
   if (w.exact_all) {
     for (int q = 0; q < w.nq; ++q) fallback.push_back(q);
   } else {
-    if (w.timed) {
-      float ms = 0.f;
-      if (hipEventElapsedTime(&ms, w.ev_t0, w.ev_t1) == hipSuccess) h->stats.scan_ms += ms;
-    }
-    h->stats.scan_bytes += w.scan_bytes;
-    h->stats.overfetch = w.M;
-    h->stats.sample_rows = (int)w.sample_rows;
-    for (int q = 0; q < w.nq; ++q) {
-      if (w.sparse) {
-        h->stats.n_candidates += w.cnt_host[q];
-        if (w.cnt_host[kQB + q]) h->stats.n_overflow += 1;
-      }
+    for (int q = 0; q < w.nq; ++q)
       if (w.cnt_host[2 * kQB + q]) fallback.push_back(q);
-    }
   }
-  if (!w.exact_all) adapt_overfetch(h, w.nq, (int)fallback.size());
-  if (!fallback.empty()) {
+  if (!w.folded) {
+    w.folded = true;
+    if (!w.exact_all) {
+      if (w.timed) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, w.ev_t0, w.ev_t1) == hipSuccess) h->stats.scan_ms += ms;
+      }
+      h->stats.scan_bytes += w.scan_bytes;
+      h->stats.overfetch = w.M;
+      h->stats.sample_rows = (int)w.sample_rows;
+      if (w.sparse)
+        for (int q = 0; q < w.nq; ++q) {
+          h->stats.n_candidates += w.cnt_host[q];
+          if (w.cnt_host[kQB + q]) h->stats.n_overflow += 1;
+        }
+      adapt_overfetch(h, w.nq, (int)fallback.size());
+    }
     h->stats.n_fallback += (int64_t)fallback.size();
+  }
+  if (!fallback.empty()) {
     std::vector<int> dense;
     if (w.sparse && !w.exact_all) ANR_TRY(run_second_pass(h, w, fallback, &dense));
     else dense = fallback;
@@ -490,6 +498,7 @@ int retire(anr_index *h, Workspace &w) {
       ANR_TRY(run_exact(h, w, dense));
     }
   }
+  w.in_flight = false;
   return ANR_OK;
 }
 
@@ -507,7 +516,7 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
   Workspace &w = h->ws[ws_index];
   h->next_ws = (h->next_ws + 1) % kWorkspaces;
   ANR_TRY(retire(h, w));  // back-pressure: the workspace's previous batch must be complete
-  w.in_flight = true;
+  w.folded = false;
   w.nq = nq;
   w.k = k;
   w.out_off = out_off;
@@ -546,6 +555,7 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
 
   if (w.exact_all) {
     ANR_HIP(hipEventRecord(w.ev_done, bs));
+    w.in_flight = true;  // only now: a failure above leaves no half-enqueued batch to retire
     ANR_HIP(hipStreamWaitEvent(user, w.ev_done, 0));
     return ANR_OK;
   }
@@ -628,6 +638,7 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
     ss.ladder = w.ladder;
     ss.lvl_init = w.lvlmax;
     ss.lvl_init_value = lvl0;
+    ss.live_q = nq;  // slots beyond the batch stay inert in the scan
     ANR_TRY(launch_select(kQB, ss, bs));
     // scan
     sc.tile0 = 0;
@@ -695,6 +706,7 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
   hipLaunchKernelGGL(k_finalize, dim3(nq), dim3(256), 0, bs, fp);
   ANR_HIP(hipGetLastError());
   ANR_HIP(hipEventRecord(w.ev_done, bs));
+  w.in_flight = true;
   ANR_HIP(hipStreamWaitEvent(user, w.ev_done, 0));
   return ANR_OK;
 }
@@ -815,7 +827,9 @@ int search_impl(anr_index *h, const float *q, bool q_on_host, int64_t nq, int32_
       h->out_pin = h->out_pin_dev = nullptr;
       h->out_pin_alloc = 0;
       const int64_t want = std::max<int64_t>(nq * k, 4096);
-      ANR_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->out_pin), (size_t)want * 12, hipHostMallocDefault));
+      // [want f32, padded to 8 B | want i64]
+      ANR_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->out_pin), (size_t)round_up(want * 4, 8) + (size_t)want * 8,
+                            hipHostMallocDefault));
       ANR_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&h->out_pin_dev), h->out_pin, 0));
       h->out_pin_alloc = want;
     }
@@ -1087,6 +1101,24 @@ int anr_index_sync(anr_index *h) {
   return drain(h);
 }
 
+int anr_index_wait(anr_index *h, int32_t keep) {
+  if (!h) return fail(ANR_EINVAL, "null handle");
+  if (keep < 0) return fail(ANR_EINVAL, "keep must be >= 0");
+  DeviceGuard g(h->device);
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (!h->ws_ready) return ANR_OK;
+  int flying = 0;
+  for (const auto &w : h->ws) flying += w.in_flight ? 1 : 0;
+  // oldest first: next_ws is the workspace the next batch will take, i.e. the one used longest ago
+  for (int i = 0; i < kWorkspaces && flying > keep; ++i) {
+    Workspace &w = h->ws[(h->next_ws + i) % kWorkspaces];
+    if (!w.in_flight) continue;
+    ANR_TRY(retire(h, w));
+    --flying;
+  }
+  return ANR_OK;
+}
+
 int anr_index_score_rows(anr_index *h, const float *q_host, int64_t nq, const int64_t *ids_host, int32_t per_query,
                          float *out_host) {
   if (!h || !q_host || !ids_host || !out_host || nq < 0 || per_query < 0) return fail(ANR_EINVAL, "bad argument");
@@ -1314,6 +1346,45 @@ int anr_merge_topk_strided_dev(int32_t device, const float *Dp_dev, const int64_
   MergeParams mp{Dp_dev, Ip_dev, d_stride, i_stride, P, nq, k, larger_is_better, D_dev, I_dev};
   hipLaunchKernelGGL(k_merge, dim3((unsigned)nq), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), mp);
   ANR_HIP(hipGetLastError());
+  return ANR_OK;
+}
+
+int anr_merge_topk_host(const float *Dp, const int64_t *Ip, int32_t P, int64_t nq, int32_t k, int32_t larger_is_better,
+                        float *D, int64_t *I) {
+  if (!Dp || !Ip || !D || !I || P <= 0 || nq < 0 || k <= 0) return fail(ANR_EINVAL, "bad argument");
+  // P-way merge of sorted lists per query (P is the GPU count of one node: a linear scan over the heads)
+  std::vector<int> head((size_t)P);
+  auto before = [&](float sa, int64_t ia, float sb, int64_t ib) {
+    if (ia < 0) return false;  // padding goes last
+    if (ib < 0) return true;
+    if (sa != sb) return larger_is_better ? (sa > sb) : (sa < sb);
+    return ia < ib;
+  };
+  for (int64_t q = 0; q < nq; ++q) {
+    std::fill(head.begin(), head.end(), 0);
+    for (int j = 0; j < k; ++j) {
+      int best = -1;
+      for (int p = 0; p < P; ++p) {
+        if (head[p] >= k) continue;
+        const int64_t e = ((int64_t)p * nq + q) * k + head[p];
+        if (Ip[e] < 0) continue;
+        if (best < 0) {
+          best = p;
+          continue;
+        }
+        const int64_t b = ((int64_t)best * nq + q) * k + head[best];
+        if (before(Dp[e], Ip[e], Dp[b], Ip[b])) best = p;
+      }
+      if (best < 0) {
+        D[q * k + j] = larger_is_better ? -3.402823466e+38f : 3.402823466e+38f;
+        I[q * k + j] = -1;
+      } else {
+        const int64_t b = ((int64_t)best * nq + q) * k + head[best]++;
+        D[q * k + j] = Dp[b];
+        I[q * k + j] = Ip[b];
+      }
+    }
+  }
   return ANR_OK;
 }
 

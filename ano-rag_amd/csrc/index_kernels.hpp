@@ -499,6 +499,9 @@ struct SelParams {
   const int *qslots;     // optional: block b handles query slot qslots[b]
   int *lvl_init;         // optional (ladder mode): lvl_init[q] = lvl_init_value, the scan's start level
   int lvl_init_value;
+  int live_q;            // ladder mode, > 0: query slots >= live_q carry no query — their ladder is +inf, so the scan
+                         // never emits for them (a zero query would otherwise pass its own all-zero thresholds on
+                         // every row of every tile)
 };
 
 struct SelShared {
@@ -539,6 +542,12 @@ __global__ __launch_bounds__(1024) void k_select(SelParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int NT = blockDim.x, NW = NT >> 6;
   const int q = p.qslots ? p.qslots[blockIdx.x] : blockIdx.x;
+  if (p.ladder && p.live_q > 0 && q >= p.live_q) {
+    if (tid == 0) p.out_m[q] = 0;
+    if (tid < kLadder) p.ladder[q * kLadder + tid] = __builtin_inff();
+    if (p.lvl_init && tid == 0) p.lvl_init[q] = p.lvl_init_value;
+    return;
+  }
   int64_t n;
   if (p.dense) {
     n = p.n;

@@ -28,6 +28,24 @@ from anorag_hip.compat import FileUtils, config, default_tmp, hip_available, log
 _SUPPORTED = ("Flat", "IVFFlat", "IVFPQ", "HNSW", "LSH")
 _MAGIC = b"ANRFLAT1"
 
+try:  # C shaping of the (scores, indices) arrays into the reference's list of dicts (csrc/pyshape.c)
+    from anorag_hip import _pyshape
+except ImportError:  # pragma: no cover - the extension is built by `make` next to libanorag_hip.so
+    _pyshape = None
+
+
+def _shape_hits(indices: np.ndarray, scores: np.ndarray, cosine: bool) -> List[List[Dict[str, Any]]]:
+    """The result loop of the reference (vector_index.py:226-259) for a whole batch: -1 ids dropped, rank = the
+    position in the row, similarity = score (cosine) or 1 / (1 + score).  Formatting only — no device work."""
+    nq, k = indices.shape
+    if _pyshape is not None:
+        return _pyshape.shape_hits(indices, scores, nq, k, bool(cosine))
+    ix, sc = indices.tolist(), scores.tolist()
+    sim = sc if cosine else (1.0 / (1.0 + scores.astype(np.float64))).tolist()
+    return [[{"index": i, "score": s, "rank": r, "similarity": m}
+             for r, (i, s, m) in enumerate(zip(a, b, c)) if i != -1] for a, b, c in zip(ix, sc, sim)]
+
+
 
 class VectorIndex:
     """Builds and manages the vector index (reference vector_index.py:9)."""
@@ -55,12 +73,24 @@ class VectorIndex:
 
         self.gpu_resource = None  # the reference's faiss.StandardGpuResources slot; nothing to hold here
         self.device = int(config.get("anorag_hip.device", 0) or 0)
+        # anorag_hip.devices: a list of HIP ordinals (or a count) — the corpus is then row-sharded over those GPUs
+        # inside this one process (anorag_hip.sharded.ShardedFlatIndex); absent / one entry = single device
+        devs = config.get("anorag_hip.devices", None)
+        if isinstance(devs, int):
+            devs = list(range(devs))
+        self.devices = [int(v) for v in devs] if devs else [self.device]
         logger.info(f"VectorIndex initialized: dim={self.embedding_dim}, type={self.index_type}, gpu={self.use_gpu}")
 
     # ------------------------------------------------------------------------------------------
     def _cosine(self) -> bool:
         # anything that is not 'cosine' means L2 (reference vector_index.py:69-74)
         return self.similarity_metric == "cosine"
+
+    def _new_index(self, dim: int, metric: int, normalize: bool):
+        if len(self.devices) > 1:
+            from anorag_hip.sharded import ShardedFlatIndex
+            return ShardedFlatIndex(dim, metric, normalize=normalize, devices=self.devices)
+        return FlatIndex(dim, metric, normalize=normalize, device=self.devices[0])
 
     def create_index(self, index_type: str = None) -> bool:
         index_type = index_type or self.index_type
@@ -69,13 +99,13 @@ class VectorIndex:
                 raise ValueError(f"Unsupported index type: {index_type}")
             if self.index is not None:
                 self.index.close()
-            self.index = FlatIndex(int(self.embedding_dim), METRIC_IP if self._cosine() else METRIC_L2,
-                                   normalize=self._cosine(), device=self.device)
+            self.index = self._new_index(int(self.embedding_dim), METRIC_IP if self._cosine() else METRIC_L2,
+                                         self._cosine())
             self._ids = None
             if index_type in ("Flat", "HNSW", "LSH"):
                 self.is_trained = True
             self.index_type = index_type
-            logger.info(f"Index created successfully: {index_type} (exact scan on HIP device {self.device})")
+            logger.info(f"Index created successfully: {index_type} (exact scan on HIP device(s) {self.devices})")
             return True
         except Exception as e:
             logger.error(f"Failed to create index: {e}")
@@ -147,19 +177,8 @@ class VectorIndex:
             scores, indices = self.index.search(q, int(top_k))
             if self._ids is not None:
                 indices = np.where(indices >= 0, self._ids[np.clip(indices, 0, len(self._ids) - 1)], -1)
-            cosine = self._cosine()
-            results = []
-            for qi in range(len(q)):
-                hits = []
-                row_i, row_s = indices[qi], scores[qi]
-                for rank in range(int(top_k)):
-                    idx = row_i[rank]
-                    if idx == -1:
-                        continue
-                    score = float(row_s[rank])
-                    hits.append({"index": int(idx), "score": score, "rank": rank,
-                                 "similarity": score if cosine else 1.0 / (1.0 + score)})
-                results.append(hits)
+            results = _shape_hits(np.ascontiguousarray(indices, dtype=np.int64),
+                                  np.ascontiguousarray(scores, dtype=np.float32), self._cosine())
             return results[0] if len(results) == 1 else results
         except Exception as e:
             logger.error(f"Failed to search index: {e}")
@@ -223,7 +242,7 @@ class VectorIndex:
                 ids = np.fromfile(f, dtype="<i8", count=n) if has_ids else None
                 if self.index is not None:
                     self.index.close()
-                self.index = FlatIndex(dim, metric, normalize=bool(normalize), device=self.device)
+                self.index = self._new_index(dim, metric, bool(normalize))
                 self.index.reserve(n)
                 self.index.set_option(OPT_ADD_RAW, 1)  # rows were stored already preprocessed
                 step = 1 << 16
@@ -265,25 +284,35 @@ class VectorIndex:
         return stats
 
     def remove_vectors(self, ids: np.ndarray) -> bool:
-        """faiss ``remove_ids`` semantics for a flat index: rows are dropped and the rest renumbered."""
+        """faiss ``remove_ids`` semantics (reference vector_index.py:395-412): a Flat / HNSW / LSH index drops the rows
+        and renumbers the rest (IndexFlat.remove_ids shifts sequential ids down); an IVF-typed index
+        (IVFFlat / IVFPQ, the reference's default type) keeps the surviving rows' original ids."""
         if self.index is None:
             logger.error("Index not created yet")
             return False
         try:
-            ids = np.unique(np.asarray(ids, dtype=np.int64))
+            n_requested = len(ids)
+            drop = np.unique(np.asarray(ids, dtype=np.int64))
             n = self.index.ntotal
             cur = self._ids if self._ids is not None else np.arange(n, dtype=np.int64)
-            keep = ~np.isin(cur, ids)
+            keep = ~np.isin(cur, drop)
             rows = self.index.reconstruct_n(0, n)[keep] if n else np.zeros((0, self.embedding_dim), np.float32)
-            self.index.reset()
-            self.index.set_option(OPT_ADD_RAW, 1)
-            if len(rows):
-                self.index.add(rows)
-            self.index.set_option(OPT_ADD_RAW, 0)
-            if self._ids is not None:
-                self._ids = cur[keep]
-            self.total_vectors -= len(ids)
-            logger.info(f"Removed {len(ids)} vectors from index")
+            # build the replacement beside the live index and swap only when it is complete
+            fresh = self._new_index(int(self.index.d), self.index.metric, self.index.normalize)
+            try:
+                fresh.set_option(OPT_ADD_RAW, 1)  # the rows are stored already preprocessed
+                if len(rows):
+                    fresh.add(rows)
+                fresh.set_option(OPT_ADD_RAW, 0)
+            except Exception:
+                fresh.close()
+                raise
+            old, self.index = self.index, fresh
+            old.close()
+            if self._ids is not None or self.index_type in ("IVFFlat", "IVFPQ"):
+                self._ids = cur[keep]  # IVF: ids survive removal; Flat with sequential ids: renumbered (None)
+            self.total_vectors -= n_requested
+            logger.info(f"Removed {n_requested} vectors from index")
             return True
         except Exception as e:
             logger.error(f"Failed to remove vectors: {e}")

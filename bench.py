@@ -10,7 +10,8 @@ batch of 64 queries answered end to end (query prep, scan, select, exact re-scor
 N = 1: the whole corpus sits on one MI355X (fp32 rows + blocked f16 image = 46 GB).
 N > 1 (launched by torch.distributed.run, one rank per GPU): the corpus is row-sharded, every rank
 scans its shard for the same batch, the [64,100] partial top-k (score f32 + global id i64) are
-all-gathered over RCCL and merged; strong scaling (total corpus fixed).
+all-gathered over RCCL and merged — each batch only after anr_index_wait() has made it final on its shard
+(certificate recovery included); strong scaling (total corpus fixed).
 
 Rank 0 prints ONE JSON line.  `value` = queries/s of the whole job with the corpus resident in HBM.
 `roofline` is for the dominant kernel (k_scan): algorithmic bytes = rows x 768 x 2 B (the f16 image
@@ -48,14 +49,17 @@ def parse():
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--cpu-rows", type=int, default=200_000, help="rows of the CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--recall-queries", type=int, default=4)
+    ap.add_argument("--recall-queries", type=int, default=-1,
+                    help="queries of the last batch checked against the oracle (-1 = the whole batch, 0 = skip)")
+    ap.add_argument("--no-facade", action="store_true", help="skip the VectorIndex.search (host in, dicts out) leg")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsal)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     return ap.parse_args()
 
 
 def gen_shard(rows, dim, shard, device, chunk=262_144):
-    """unit-norm-able Gaussian rows, generated on the device chunk by chunk (seed [1234, shard])."""
+    """unit-norm-able Gaussian rows, generated on the device chunk by chunk (torch Philox, seed 1234000 + shard:
+    a 30 GB host array from numpy's default_rng([1234, s]) would take minutes; same distribution, other stream)."""
     g = torch.Generator(device=device)
     g.manual_seed(1234 * 1000 + shard)
     done = 0
@@ -108,25 +112,14 @@ def cpu_baseline(args, world):
 
 
 def oracle_partial_topk(args, shards_host_iter, q_host, row0):
-    """float64-arbitrated top-k of a few queries over this rank's rows (global ids): (scores [nq,k], ids [nq,k])"""
+    """float64-arbitrated top-k of the given queries over this rank's rows (global ids): (scores [nq,k], ids [nq,k])"""
     from oracle import flat_index as orc
-    nq = q_host.shape[0]
-    qn = orc.preprocess_vectors(q_host)
-    best_s = np.full((nq, 0), 0.0)
-    best_i = np.zeros((nq, 0), dtype=np.int64)
+    top = orc.BlockedTopK(orc.preprocess_vectors(q_host), args.k, "ip")
     base = row0
     for xb in shards_host_iter():
-        xn = orc.preprocess_vectors(xb)
-        s = qn.astype(np.float64) @ xn.astype(np.float64).T
-        kk = min(args.k, s.shape[1])
-        part = np.argpartition(-s, kk - 1, axis=1)[:, :kk]
-        best_s = np.concatenate([best_s, np.take_along_axis(s, part, axis=1)], axis=1)
-        best_i = np.concatenate([best_i, part + base], axis=1)
-        o = np.argsort(-best_s, axis=1, kind="stable")[:, :args.k]
-        best_s = np.take_along_axis(best_s, o, axis=1)
-        best_i = np.take_along_axis(best_i, o, axis=1)
+        top.push(orc.preprocess_vectors(xb), base)
         base += xb.shape[0]
-    return best_s, best_i
+    return top.result()
 
 
 def recall_from_partials(parts, I_gpu, k):
@@ -138,17 +131,54 @@ def recall_from_partials(parts, I_gpu, k):
     return hits / float(ref.shape[0] * k)
 
 
-def pmc_traffic(rows_total, rows_per_gpu, dim):
-    """HBM bytes per k_scan launch from the committed PMC pass (profiles/r01_pmc_traffic_k_scan.json: FETCH_SIZE
-    doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE), scaled by rows when the shard differs."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_k_scan.json")) as f:
-            p = json.load(f)
-        if p["dim"] != dim:
-            return None
-        return p["traffic_bytes_per_launch"] * rows_per_gpu / p["rows"]
-    except Exception:
+def pmc_traffic(rows_per_gpu, dim, notes):
+    """HBM bytes per k_scan launch from the committed PMC passes (profiles/*_pmc_traffic_k_scan.json: FETCH_SIZE
+    doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE, separate --pmc runs), scaled by rows when the
+    shard differs.  The file records the sha256 of csrc/index_kernels.hpp it was measured on: when the kernel source
+    has changed since, the figure is stale and is NOT reported (traffic = null, the reason goes to `traffic_note` and
+    stderr) — re-run tools/refresh_profiles.sh."""
+    import glob
+    import hashlib
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_k_scan.json")))
+    if not files:
+        notes.append("no profiles/*_pmc_traffic_k_scan.json")
         return None
+    with open(files[-1]) as f:
+        p = json.load(f)
+    src = os.path.join(ROOT, "ano-rag_amd", "csrc", "index_kernels.hpp")
+    sha = hashlib.sha256(open(src, "rb").read()).hexdigest()
+    if p.get("kernel_source_sha256") != sha:
+        msg = (f"{os.path.basename(files[-1])} was measured on another version of index_kernels.hpp "
+               f"(recorded {str(p.get('kernel_source_sha256'))[:12]}, current {sha[:12]}): traffic not reported")
+        print("bench.py: " + msg, file=sys.stderr)
+        notes.append(msg)
+        return None
+    if p["dim"] != dim:
+        notes.append("PMC profile taken at another dim")
+        return None
+    notes.append(os.path.basename(files[-1]))
+    return p["traffic_bytes_per_launch"] * rows_per_gpu / p["rows"]
+
+
+def facade_leg(idx, args, q_host):
+    """The reference-facing call: VectorIndex.search(np.ndarray[B, D], top_k) -> list of per-query lists of dicts
+    (reference vector_store/vector_index.py:206-263), timed end to end on the same resident corpus."""
+    from vector_store.vector_index import VectorIndex
+    vi = VectorIndex(embedding_dim=args.dim)
+    vi.index_type, vi.similarity_metric = "Flat", "cosine"
+    vi.index, vi.is_trained, vi.total_vectors = idx, True, idx.ntotal  # the corpus already on the device
+    for _ in range(3):
+        res = vi.search(q_host, top_k=args.k)
+    n = 20
+    t0 = time.perf_counter()
+    for _ in range(n):
+        res = vi.search(q_host, top_k=args.k)
+    dt = (time.perf_counter() - t0) / n
+    ok = len(res) == args.batch and all(len(r) == args.k for r in res) and set(res[0][0]) == {"index", "score", "rank", "similarity"}
+    vi.index = None  # the bench owns the handle
+    return {"call": f"VectorIndex.search(np.float32[{args.batch},{args.dim}], top_k={args.k}) -> list[list[dict]]",
+            "ms_per_call": dt * 1e3, "value": args.batch / dt, "unit": "queries/s", "calls": n, "shape_ok": bool(ok),
+            "note": "host numpy in, Python dicts out, synchronous, one batch at a time (not `value`)"}
 
 
 def main():
@@ -215,30 +245,46 @@ def main():
     lib = _lib.load()
     torch.cuda.synchronize()
 
-    def step(i):
+    # N > 1: the exchange of batch i runs only once batch i is FINAL on its shard (anr_index_wait: certificate
+    # recovery done), LAG batches behind the search front so the device never idles on the host
+    LAG = NSLOT - 1
+    pending = []
+    merged = {}
+
+    def exchange(i):
         s = i % NSLOT
         st = streams[s]
+        idx.wait(len(pending))  # everything older than the still-pending batches is final
+        with torch.cuda.stream(st):
+            if args.backend == "nccl":
+                dist.all_gather_into_tensor(Pg[s], Pl[s])
+            else:  # rehearsal path (gloo has no all_gather_into_tensor for device tensors)
+                st.synchronize()
+                ph = [torch.empty(nres * 12, dtype=torch.uint8) for _ in range(world)]
+                dist.all_gather(ph, Pl[s].cpu())
+                Pg[s].copy_(torch.cat(ph))
+            _lib.check(lib.anr_merge_topk_strided_dev(
+                local_rank, C.c_void_p(Pg[s].data_ptr()), C.c_void_p(Pg[s].data_ptr() + nres * 4),
+                nres * 3, (nres * 3) // 2, world, args.batch, args.k, 1,
+                C.c_void_p(Dm[s].data_ptr()), C.c_void_p(Im[s].data_ptr()),
+                C.c_void_p(st.cuda_stream)), "anr_merge_topk_strided_dev")
+        merged["last"] = (Dm[s], Im[s])
+
+    def step(i):
+        s = i % NSLOT
         idx.search_device_async(Q[i].data_ptr(), args.batch, args.k, Dl[s].data_ptr(), Il[s].data_ptr(),
-                                st.cuda_stream)
+                                streams[s].cuda_stream)
         if world > 1:
-            with torch.cuda.stream(st):
-                if args.backend == "nccl":
-                    dist.all_gather_into_tensor(Pg[s], Pl[s])
-                else:  # rehearsal path (gloo has no all_gather_into_tensor for device tensors)
-                    st.synchronize()
-                    ph = [torch.empty(nres * 12, dtype=torch.uint8) for _ in range(world)]
-                    dist.all_gather(ph, Pl[s].cpu())
-                    Pg[s].copy_(torch.cat(ph))
-                _lib.check(lib.anr_merge_topk_strided_dev(
-                    local_rank, C.c_void_p(Pg[s].data_ptr()), C.c_void_p(Pg[s].data_ptr() + nres * 4),
-                    nres * 3, (nres * 3) // 2, world, args.batch, args.k, 1,
-                    C.c_void_p(Dm[s].data_ptr()), C.c_void_p(Im[s].data_ptr()),
-                    C.c_void_p(st.cuda_stream)), "anr_merge_topk_strided_dev")
-            return Dm[s], Im[s]
-        return Dl[s], Il[s]
+            pending.append(i)
+            if len(pending) > LAG:
+                exchange(pending.pop(0))
+        else:
+            merged["last"] = (Dl[s], Il[s])
 
     def finish():
         idx.sync()              # retires every batch; runs the exact path where a certificate failed
+        while pending:
+            exchange(pending.pop(0))
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
@@ -250,8 +296,9 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.warmup, nb):
-        Dres, Ires = step(i)
+        step(i)
     finish()
+    Dres, Ires = merged["last"]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -267,8 +314,8 @@ def main():
     # recall@k of the last batch's first few queries vs the oracle: every rank ranks its own rows on the CPU
     # (float64), rank 0 merges the partial lists and compares with the ids the GPU path returned
     recall = None
-    if args.recall_queries > 0:
-        nrq = min(args.recall_queries, args.batch)
+    if args.recall_queries != 0:
+        nrq = args.batch if args.recall_queries < 0 else min(args.recall_queries, args.batch)
         I_gpu = Ires[:nrq].cpu().numpy()
         qh = Q[nb - 1, :nrq].cpu().numpy()
 
@@ -284,8 +331,13 @@ def main():
             parts = [part]
         if rank == 0:
             recall = recall_from_partials(parts, I_gpu, args.k)
+    facade = None
+    if rank == 0 and world == 1 and not args.no_facade:
+        facade = facade_leg(idx, args, Q[nb - 1].cpu().numpy())
 
     if rank == 0:
+        tnotes = []
+        traffic = pmc_traffic(per, args.dim, tnotes)
         qps = args.batch * args.steps / dt
         achieved = (scan_bytes / 1e9) / (scan_ms / 1e3) if scan_ms > 0 else None
         out = {
@@ -312,6 +364,7 @@ def main():
                 "parallelism": f"row-shard x{world}" if world > 1 else "single GPU",
             },
             "recall_at_k": recall,
+            "recall_queries": (args.batch if args.recall_queries < 0 else args.recall_queries),
             "exact_fallback_queries": n_fallback,
             "candidates_per_query": n_cand / max(1, args.steps * args.batch),
             "roofline": {
@@ -321,11 +374,14 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
-                "traffic": pmc_traffic(rows_total, per, args.dim),
+                "traffic": traffic,
+                "traffic_note": "; ".join(tnotes),
                 "bytes_per_launch": scan_bytes / max(1, args.steps),
                 "ms_per_launch": scan_ms / max(1, args.steps),
             },
         }
+        if facade is not None:
+            out["facade"] = facade
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, world)
         print(json.dumps(out), flush=True)

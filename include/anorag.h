@@ -78,6 +78,12 @@ int anr_index_search_dev(anr_index *h, const float *q_dev, int64_t nq, int32_t k
 int anr_index_search_dev_async(anr_index *h, const float *q_dev, int64_t nq, int32_t k, float *D_dev,
                                int64_t *I_dev, void *stream);
 int anr_index_sync(anr_index *h);
+/* Partial form of anr_index_sync(): retires the OLDEST in-flight batches (a batch = up to 64 queries of one
+ * asynchronous call) until at most `keep` (0..2) are still in flight.  The retired batches' D_dev / I_dev rows are
+ * FINAL on return, while the newer ones keep the device busy — what a caller that must hand results on (the
+ * row-sharded exchange of bench.py / anorag_hip/sharded.py) uses to stay pipelined without ever merging a
+ * batch whose certificate recovery has not run. */
+int anr_index_wait(anr_index *h, int32_t keep);
 
 /* Exact scores of given rows: out[q][j] = score(query q, stored row ids[q][j]) — the
  * gather(note_embeddings, ids) . q that query/query_processor.py:3543-3589 recomputes per candidate
@@ -139,6 +145,10 @@ int anr_merge_topk_dev(int32_t device, const float *Dp_dev, const int64_t *Ip_de
 int anr_merge_topk_strided_dev(int32_t device, const float *Dp_dev, const int64_t *Ip_dev, int64_t d_stride,
                                int64_t i_stride, int32_t P, int64_t nq, int32_t k, int32_t larger_is_better,
                                float *D_dev, int64_t *I_dev, void *stream);
+/* The same merge for partial lists that already sit in host memory ([P][nq][k], e.g. written there by P
+ * single-process shard searches): BASELINE.json north_star "per-shard local top-k merged on the host". */
+int anr_merge_topk_host(const float *Dp, const int64_t *Ip, int32_t P, int64_t nq, int32_t k,
+                        int32_t larger_is_better, float *D, int64_t *I);
 
 /* ------------------------------------------------------------------------------------------------
  * Score fusion: the arithmetic of HybridSearcher.fuse, retrieval/hybrid_search.py:34-103, for a batch

@@ -83,6 +83,63 @@ def flat_search(q: np.ndarray, x: np.ndarray, k: int, metric: str = "ip"):
     return D, I
 
 
+class BlockedTopK:
+    """Streaming form of ``flat_search`` for corpora that are generated / loaded block by block (bench.py's recall
+    leg at 10 M rows, the large parity tests): feed preprocessed float32 row blocks with ``push``; per block a
+    float32 sgemm nominates every row within ``margin`` of the block's k-th best score, the nominees are re-scored
+    with float64 accumulation (the arbiter, as in ``flat_search``) and merged into the running top-k
+    (score desc / distance asc, ties by ascending id)."""
+
+    def __init__(self, q: np.ndarray, k: int, metric: str = "ip", margin: float = 1e-4):
+        self.q = np.ascontiguousarray(q, dtype=np.float32)
+        self.q64 = self.q.astype(np.float64)
+        self.k, self.metric, self.margin = int(k), metric, float(margin)
+        nq = self.q.shape[0]
+        self.S = np.zeros((nq, 0), dtype=np.float64)
+        self.I = np.zeros((nq, 0), dtype=np.int64)
+
+    def push(self, xb: np.ndarray, row0: int) -> None:
+        n = xb.shape[0]
+        if n == 0:
+            return
+        if self.metric == "ip":
+            s = self.q @ xb.T
+        else:
+            s = -((self.q * self.q).sum(1)[:, None] - 2.0 * (self.q @ xb.T) + (xb * xb).sum(1)[None, :])
+        kk = min(self.k, n)
+        newS, newI = [], []
+        for i in range(self.q.shape[0]):
+            if kk < n:
+                part = np.argpartition(-s[i], kk - 1)[:kk]
+                cand = np.nonzero(s[i] >= s[i][part].min() - self.margin)[0]
+            else:
+                cand = np.arange(n)
+            xc = xb[cand].astype(np.float64)
+            if self.metric == "ip":
+                e = xc @ self.q64[i]
+            else:
+                d = xc - self.q64[i]
+                e = -np.einsum("nd,nd->n", d, d)
+            newS.append(e)
+            newI.append(cand.astype(np.int64) + int(row0))
+        for i in range(self.q.shape[0]):
+            S = np.concatenate([self.S[i], newS[i]]) if self.S.shape[1] else newS[i]
+            I = np.concatenate([self.I[i], newI[i]]) if self.I.shape[1] else newI[i]
+            # ranking on the float32-rounded value reported, ties by id — the order flat_search uses
+            order = np.lexsort((I, -S.astype(np.float32).astype(np.float64)))[: self.k]
+            newS[i], newI[i] = S[order], I[order]
+        width = max(len(v) for v in newS)
+        self.S = np.full((len(newS), width), -np.inf)
+        self.I = np.full((len(newS), width), -1, dtype=np.int64)
+        for i in range(len(newS)):
+            self.S[i, : len(newS[i])] = newS[i]
+            self.I[i, : len(newI[i])] = newI[i]
+
+    def result(self):
+        """(scores float64 [nq, <=k] — inner products, or MINUS squared distances for 'l2' — and ids int64)"""
+        return self.S, self.I
+
+
 def near_tie_equal(I_a: np.ndarray, I_ref: np.ndarray, scores64: np.ndarray, k: int, tol: float) -> bool:
     """True when the id sets agree up to rows whose exact score is within `tol` of the k-th best."""
     for i in range(I_ref.shape[0]):

@@ -98,3 +98,63 @@ def test_large_batch_takes_the_tiled_gemm_paths(tmp_path):
     assert cos.min() >= 0.9995, cos.min()
     assert np.max(np.abs(got - ref)) <= 5e-3
     enc.close()
+
+
+def test_c4_full_shape_bge_base_12_layers_batch256_encode_then_search_1m(tmp_path):
+    """BASELINE.json config C4 at its real shape: bge-base-en (12 layers, H 768, 12 heads, I 3072, vocab 30522, CLS
+    pooling + normalise, seeded weights), ONE batch of 256 query strings (8-24 words + the bge query prefix,
+    SURVEY.md §8d), then top-100 over a 1 M x 768 corpus.  (a) every embedding against the float32 CPU oracle;
+    (b) the search of those embeddings against the flat-index oracle run on the SAME embeddings (north_star:
+    "results match the reference CPU path on the same embeddings"); (c) the two legs end to end: ids found from the
+    device embeddings vs ids found from the oracle's embeddings (f16 MFMA operands move scores by ~1e-3, so this
+    is a recall figure, not an identity)."""
+    import torch
+    from anorag_hip import FlatIndex, METRIC_IP
+    from anorag_hip.encoder import SentenceEncoder
+    from oracle import flat_index as orc
+    d = oenc.make_synthetic_model(str(tmp_path / "bge"), layers=12, hidden=768, heads=12, intermediate=3072,
+                                  vocab=30522, pooling="cls", weight_std=0.02)
+    prefix = "Represent this sentence for searching relevant passages: "  # embedding_manager.py:551-564
+    sents = [prefix + s for s in oenc.synthetic_sentences(d, 256, seed=7, min_words=8, max_words=24)]
+    ref = oenc.encode(d, sents, batch_size=256, normalize=True)
+    enc = SentenceEncoder(d)
+    got = enc.encode(sents, batch_size=256, normalize_embeddings=True)
+    cos = np.sum(got * ref, axis=1)
+    assert got.shape == (256, 768) and cos.min() >= 0.9995, cos.min()
+    assert np.max(np.abs(got - ref)) <= 5e-3
+    enc.close()
+
+    dev = torch.device("cuda", 0)
+    n, k = 1_000_000, 100
+    idx = FlatIndex(768, METRIC_IP, normalize=True)
+    idx.reserve(n)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234)
+    blocks = []
+    for s in range(0, n, 250_000):
+        xb = torch.randn((250_000, 768), generator=g, device=dev)
+        torch.cuda.synchronize()
+        idx.add_device(xb.data_ptr(), xb.shape[0])
+        blocks.append(orc.preprocess_vectors(xb.cpu().numpy()))
+    D, I = idx.search(got, k)                       # 4 batches of 64
+    top = orc.BlockedTopK(orc.preprocess_vectors(got), k + 16, "ip")
+    top_ref = orc.BlockedTopK(orc.preprocess_vectors(ref), k, "ip")
+    for bi, xb in enumerate(blocks):
+        top.push(xb, bi * 250_000)
+        top_ref.push(xb, bi * 250_000)
+    S, Ir = top.result()
+    assert np.array_equal(I, Ir[:, :k]) or all(
+        set(I[r]) ^ set(Ir[r, :k]) <= {i for i, s in zip(Ir[r], S[r]) if abs(s - S[r, k - 1]) <= 1e-6} for r in range(256))
+    assert np.max(np.abs(D - S[:, :k].astype(np.float32))) <= 1e-4
+    _, I_ref_emb = top_ref.result()
+    recall = np.mean([len(set(I[r]) & set(I_ref_emb[r])) / k for r in range(256)])
+    assert recall >= 0.85, recall
+    idx.close()
+
+
+def test_xlm_roberta_large_shape_24_layers(tmp_path):
+    """bge-m3 (the reference's default model, embedding_manager.py:82): XLM-R large shape — 24 layers, H 1024,
+    16 heads, I 4096 — full depth, one forward of 48 ragged sentences (small vocabulary: the table size does not
+    change the arithmetic)."""
+    _check(tmp_path, n=48, layers=24, hidden=1024, heads=16, intermediate=4096, pooling="cls",
+           model_type="xlm-roberta", max_pos=512, weight_std=0.02)
