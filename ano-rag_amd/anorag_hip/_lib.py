@@ -50,6 +50,16 @@ class SearchStats(C.Structure):
         return {name: getattr(self, name) for name, _ in self._fields_}
 
 
+class FuseSource(C.Structure):
+    _fields_ = [("array_dev", C.c_void_p), ("array_len", C.c_int64), ("array_dtype", C.c_int32),
+                ("list_ids", C.c_void_p), ("list_scores", C.c_void_p), ("list_offs", C.c_void_p)]
+
+
+class FuseDenseStats(C.Structure):
+    _fields_ = [("n_queries", C.c_int64), ("scan_bytes", C.c_int64), ("n_candidates", C.c_int64),
+                ("scan_ms", C.c_float)]
+
+
 class EncoderConfig(C.Structure):
     _fields_ = [
         ("n_layers", C.c_int32), ("hidden", C.c_int32), ("n_heads", C.c_int32), ("intermediate", C.c_int32),
@@ -67,6 +77,9 @@ SIGNATURES = {
     "anr_last_error": (C.c_char_p, []),
     "anr_version": (C.c_char_p, []),
     "anr_device_count": (C.c_int, []),
+    "anr_device_malloc": (C.c_int, [C.c_int32, C.c_int64, C.POINTER(C.c_void_p)]),
+    "anr_device_free": (C.c_int, [C.c_int32, C.c_void_p]),
+    "anr_device_copy": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
     "anr_index_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     "anr_index_destroy": (C.c_int, [C.c_void_p]),
     "anr_index_reserve": (C.c_int, [C.c_void_p, C.c_int64]),
@@ -115,6 +128,12 @@ SIGNATURES = {
         [C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int32,
          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     ),
+    "anr_fuse_dense": (
+        C.c_int,
+        [C.c_int32, C.c_int32, C.c_int64, C.POINTER(FuseSource), C.c_void_p, C.c_double, C.c_int32, C.c_void_p,
+         C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(FuseDenseStats)],
+    ),
+    "anr_bm25_scores_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "anr_bm25_create": (C.c_int, [C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.POINTER(C.c_void_p)]),
     "anr_bm25_destroy": (C.c_int, [C.c_void_p]),

@@ -35,6 +35,7 @@ class DeviceBM25:
 
     def __init__(self, corpus: List[List[str]], k1: float = 1.5, b: float = 0.75, device: int = 0):
         self.k1, self.b = k1, b
+        self.device = int(device)
         self.doc_len = [len(d) for d in corpus]
         self.doc_count = len(corpus)
         self.avgdl = sum(self.doc_len) / len(self.doc_len) if self.doc_len else 0
@@ -95,6 +96,17 @@ class DeviceBM25:
         _lib.check(self._lib.anr_bm25_scores(self._h, len(queries), indptr.ctypes.data_as(C.c_void_p),
                                              terms.ctypes.data_as(C.c_void_p), int(bool(normalize)),
                                              out.ctypes.data_as(C.c_void_p)), "anr_bm25_scores")
+        return out
+
+    def scores_device(self, queries: Sequence[Sequence[str]], normalize: bool = True):
+        """[nq, n_docs] float64 left in device memory (an ``anorag_hip.fusion.DeviceArray``): the array source of
+        ``anr_fuse_dense`` — the N-vector never crosses PCIe"""
+        from .fusion import DeviceArray
+        indptr, terms = self._encode_queries(queries)
+        out = DeviceArray(len(queries), self.doc_count, np.float64, self.device)
+        _lib.check(self._lib.anr_bm25_scores_dev(self._h, len(queries), indptr.ctypes.data_as(C.c_void_p),
+                                                 terms.ctypes.data_as(C.c_void_p), int(bool(normalize)),
+                                                 C.c_void_p(out.ptr)), "anr_bm25_scores_dev")
         return out
 
     def nonzero_batch(self, queries: Sequence[Sequence[str]], normalize: bool = True, cap: int = 4096):

@@ -1,0 +1,110 @@
+"""Host binding of the N-array score fusion (``anr_fuse_dense``, include/anorag.h): HybridSearcher.fuse of the
+reference (retrieval/hybrid_search.py:34-103) when a source is a full-corpus score vector — what
+``bm25_scores`` returns (utils/bm25_search.py:286-340) — rather than a short (id, score) list.
+
+``DeviceArray`` is a plain device buffer obtained through the C ABI (no torch needed); ``fuse_dense`` takes, per
+source, a ``DeviceArray`` / a device pointer triple, per-query short lists, or ``None``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import FuseDenseStats, FuseSource
+
+SOURCES = ("dense", "bm25", "graph", "path")
+
+
+class DeviceArray:
+    """[nq, n] float64 / float32 array in device memory (row-major)."""
+
+    def __init__(self, nq: int, n: int, dtype=np.float64, device: int = 0):
+        self.nq, self.n, self.device = int(nq), int(n), int(device)
+        self.dtype = np.dtype(dtype)
+        if self.dtype not in (np.dtype(np.float64), np.dtype(np.float32)):
+            raise ValueError("DeviceArray holds float64 or float32")
+        self.nbytes = self.nq * self.n * self.dtype.itemsize
+        p = C.c_void_p()
+        _lib.check(_lib.load().anr_device_malloc(self.device, self.nbytes, C.byref(p)), "anr_device_malloc")
+        self.ptr = p.value
+
+    @classmethod
+    def from_numpy(cls, a: np.ndarray, device: int = 0) -> "DeviceArray":
+        a = np.ascontiguousarray(a)
+        if a.ndim != 2:
+            raise ValueError("expected [nq, n]")
+        if a.dtype not in (np.float64, np.float32):
+            a = a.astype(np.float64)
+        out = cls(a.shape[0], a.shape[1], a.dtype, device)
+        _lib.check(_lib.load().anr_device_copy(device, C.c_void_p(out.ptr), a.ctypes.data_as(C.c_void_p), a.nbytes, 0),
+                   "anr_device_copy")
+        return out
+
+    def numpy(self) -> np.ndarray:
+        out = np.empty((self.nq, self.n), dtype=self.dtype)
+        _lib.check(_lib.load().anr_device_copy(self.device, out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr),
+                                               self.nbytes, 1), "anr_device_copy")
+        return out
+
+    def free(self) -> None:
+        if getattr(self, "ptr", None):
+            _lib.load().anr_device_free(self.device, C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):  # pragma: no cover - best effort
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def fuse_dense(method: str, weights: Dict[str, float], rrf_k: float, pool: int, nq: int,
+               sources: Dict[str, Any], device: int = 0, want_stats: bool = False):
+    """sources[name] is a ``DeviceArray`` ([nq, N]: every id < N present, NaN = absent), or a sequence of nq
+    ``(ids int64[], scores float64[])`` short lists (the caller's order), or None / missing.
+    Returns (ids [nq, pool] int64 (-1 padded), finals [nq, pool] float64, src [nq, pool, 4] float64 (NaN = absent),
+    counts [nq] int32[, stats dict])."""
+    lib = _lib.load()
+    src = (FuseSource * 4)()
+    keep = []  # keeps the numpy buffers alive across the call
+    for si, name in enumerate(SOURCES):
+        v = sources.get(name)
+        if v is None:
+            continue
+        if isinstance(v, DeviceArray):
+            if v.nq != nq:
+                raise ValueError(f"{name}: array has {v.nq} rows, expected {nq}")
+            src[si].array_dev = v.ptr
+            src[si].array_len = v.n
+            src[si].array_dtype = 0 if v.dtype == np.float64 else 1
+            continue
+        if len(v) != nq:
+            raise ValueError(f"{name}: {len(v)} lists for {nq} queries")
+        offs = np.zeros(nq + 1, dtype=np.int64)
+        for i, (ids, _) in enumerate(v):
+            offs[i + 1] = offs[i] + len(ids)
+        ids = (np.concatenate([np.asarray(a, dtype=np.int64).reshape(-1) for a, _ in v])
+               if offs[-1] else np.zeros(0, dtype=np.int64))
+        sc = (np.concatenate([np.asarray(b, dtype=np.float64).reshape(-1) for _, b in v])
+              if offs[-1] else np.zeros(0, dtype=np.float64))
+        keep += [offs, ids, sc]
+        src[si].list_offs = offs.ctypes.data
+        src[si].list_ids = ids.ctypes.data
+        src[si].list_scores = sc.ctypes.data
+    w = np.asarray([float(weights.get(k, 0.0)) for k in SOURCES], dtype=np.float64)
+    o_ids = np.empty((nq, pool), dtype=np.int64)
+    o_fin = np.empty((nq, pool), dtype=np.float64)
+    o_src = np.empty((nq, pool, 4), dtype=np.float64)
+    o_cnt = np.empty((nq,), dtype=np.int32)
+    st = FuseDenseStats()
+    _lib.check(lib.anr_fuse_dense(int(device), 1 if method == "rrf" else 0, int(nq), src, w.ctypes.data_as(C.c_void_p),
+                                  float(rrf_k), int(pool), o_ids.ctypes.data_as(C.c_void_p),
+                                  o_fin.ctypes.data_as(C.c_void_p), o_src.ctypes.data_as(C.c_void_p),
+                                  o_cnt.ctypes.data_as(C.c_void_p), C.byref(st) if want_stats else None),
+               "anr_fuse_dense")
+    if want_stats:
+        return o_ids, o_fin, o_src, o_cnt, {k: getattr(st, k) for k, _ in st._fields_}
+    return o_ids, o_fin, o_src, o_cnt

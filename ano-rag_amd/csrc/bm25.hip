@@ -133,9 +133,10 @@ int validate_queries(const anr_bm25 *h, int64_t nq, const int64_t *q_indptr, con
   return ANR_OK;
 }
 
-// runs the scoring of one chunk of queries into a fresh device buffer; caller frees *d_scores
+// runs the scoring of one chunk of queries into a fresh device buffer (caller frees *d_scores) or, when `into` is
+// given, into that caller-owned device buffer
 int score_chunk(anr_bm25 *h, int64_t nq, const int64_t *q_indptr, const int32_t *q_terms, int normalize,
-                double **d_scores) {
+                double **d_scores, double *into = nullptr) {
   int64_t *dq = nullptr;
   int32_t *dt = nullptr;
   const int64_t nt = q_indptr[nq] - q_indptr[0];
@@ -143,7 +144,10 @@ int score_chunk(anr_bm25 *h, int64_t nq, const int64_t *q_indptr, const int32_t 
   for (int64_t i = 0; i <= nq; ++i) rel[i] = q_indptr[i] - q_indptr[0];
   ANR_TRY(b_alloc(&dq, nq + 1));
   int rc = b_alloc(&dt, nt);
-  if (rc == ANR_OK) rc = b_alloc(d_scores, nq * h->n_docs);
+  if (rc == ANR_OK) {
+    if (into) *d_scores = into;
+    else rc = b_alloc(d_scores, nq * h->n_docs);
+  }
   hipError_t e = hipSuccess;
   if (rc == ANR_OK) {
     e = hipMemcpyAsync(dq, rel.data(), (size_t)(nq + 1) * 8, hipMemcpyHostToDevice, h->stream);
@@ -239,6 +243,17 @@ int anr_bm25_scores(anr_bm25 *h, int64_t nq, const int64_t *q_indptr, const int3
     if (rc != ANR_OK) return rc;
   }
   return ANR_OK;
+}
+
+int anr_bm25_scores_dev(anr_bm25 *h, int64_t nq, const int64_t *q_indptr, const int32_t *q_terms, int32_t normalize,
+                        double *out_dev) {
+  ANR_TRY(validate_queries(h, nq, q_indptr, q_terms));
+  if (!out_dev) return fail(ANR_EINVAL, "out is null");
+  if (nq == 0 || h->n_docs == 0) return ANR_OK;
+  DeviceGuard g(h->device);
+  std::lock_guard<std::mutex> lk(h->mu);
+  double *d = nullptr;
+  return score_chunk(h, nq, q_indptr, q_terms, normalize, &d, out_dev);
 }
 
 int anr_bm25_nonzero(anr_bm25 *h, int64_t nq, const int64_t *q_indptr, const int32_t *q_terms, int32_t normalize,

@@ -47,7 +47,7 @@ extern "C" {
 
 const char *anr_last_error(void) { return anr::last_error_ref().c_str(); }
 
-const char *anr_version(void) { return "anorag-hip 0.1 (gfx950)"; }
+const char *anr_version(void) { return "anorag-hip 0.2 (gfx950)"; }
 
 int anr_device_count(void) {
   int n = 0;
@@ -56,6 +56,33 @@ int anr_device_count(void) {
     return 0;
   }
   return n;
+}
+
+int anr_device_malloc(int32_t device, int64_t bytes, void **out) {
+  if (!out || bytes < 0) return anr::fail(ANR_EINVAL, "bad argument");
+  *out = nullptr;
+  anr::DeviceGuard g(device);
+  if (!g.ok) return anr::fail(ANR_EHIP, "hipSetDevice(%d) failed", device);
+  ANR_HIP(hipMalloc(out, (size_t)(bytes > 0 ? bytes : 8)));
+  return ANR_OK;
+}
+
+int anr_device_free(int32_t device, void *ptr) {
+  if (!ptr) return ANR_OK;
+  anr::DeviceGuard g(device);
+  ANR_HIP(hipFree(ptr));
+  return ANR_OK;
+}
+
+int anr_device_copy(int32_t device, void *dst, const void *src, int64_t bytes, int32_t kind) {
+  if (bytes < 0 || (bytes > 0 && (!dst || !src))) return anr::fail(ANR_EINVAL, "bad argument");
+  if (kind < 0 || kind > 2) return anr::fail(ANR_EINVAL, "kind must be 0 (host to device), 1 (device to host) or 2 (device to device)");
+  if (bytes == 0) return ANR_OK;
+  anr::DeviceGuard g(device);
+  if (!g.ok) return anr::fail(ANR_EHIP, "hipSetDevice(%d) failed", device);
+  static const hipMemcpyKind k[3] = {hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice};
+  ANR_HIP(hipMemcpy(dst, src, (size_t)bytes, k[kind]));
+  return ANR_OK;
 }
 
 }  // extern "C"

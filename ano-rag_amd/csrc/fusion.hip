@@ -1,222 +1,5 @@
-// Device score fusion behind anr_fuse_lists (include/anorag.h): the arithmetic of the reference's
-// HybridSearcher.fuse (retrieval/hybrid_search.py:34-103) for a batch of queries, one workgroup per query,
-// everything LDS-resident.  All arithmetic is float64 in the reference's own order of operations, so the
-// final similarities are bit-identical to the Python implementation:
-//   linear : final = w_d*(s_d/max_d) + w_b*(s_b/max_b) + w_g*(s_g/max_g) + w_p*s_p   (max == 0 -> 0.0)
-//   rrf    : final = ((w_d/(k+r_d) + w_b/(k+r_b)) + w_g/(k+r_g)) + w_p*s_p, ranks from a stable descending
-//            sort of each source (ties keep list order); ids that occur only in `path` are dropped.
-// Result order: final descending; ties by the reference's ranks-dict insertion order (rrf) or by id (linear,
-// where the reference iterates a set).
-#include "common.hpp"
-
-namespace anr {
-
-constexpr int kFuseMax = 4096;  // total list entries per query (LDS-resident: 28 B each)
-
-struct FuseParams {
-  int method;            // 0 linear, 1 rrf
-  const int64_t *ids;    // concatenated entries of all queries
-  const double *scores;
-  const int64_t *offs;   // [nq][5] entry offsets of the 4 sources of each query (+ end)
-  double w[4];
-  double rrf_k;
-  int pool;
-  int64_t *out_ids;      // [nq][pool]
-  double *out_final;     // [nq][pool]
-  double *out_src;       // [nq][pool][4] raw source scores, NaN when the id is not in that source
-  int *out_count;        // [nq]
-};
-
-struct FuseShared {
-  unsigned long long key[kFuseMax];  // id << 2 | source
-  double val[kFuseMax];              // contribution of the entry; for a segment head: the fused final
-  unsigned tie[kFuseMax];            // rrf: source << 16 | rank of the first source holding the id
-  unsigned idx[kFuseMax];
-  unsigned keep[kFuseMax];
-  double red[16];
-  double smax[4];
-  unsigned cnt;
-};
-
-template <typename F>
-__device__ void bitonic_idx(unsigned *idx, int n_pow2, F less) {
-  // sorts idx[0..n_pow2) ascending under `less`
-  const int tid = threadIdx.x;
-  for (int k2 = 2; k2 <= n_pow2; k2 <<= 1) {
-    for (int j = k2 >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < n_pow2; i += blockDim.x) {
-        const int ixj = i ^ j;
-        if (ixj > i) {
-          const unsigned a = idx[i], b = idx[ixj];
-          const bool up = ((i & k2) == 0);
-          if (up ? less(b, a) : less(a, b)) {
-            idx[i] = b;
-            idx[ixj] = a;
-          }
-        }
-      }
-      __syncthreads();
-    }
-  }
-}
-
-__global__ __launch_bounds__(1024) void k_fuse(FuseParams p) {
-  extern __shared__ unsigned char fuse_smem[];
-  FuseShared &sh = *reinterpret_cast<FuseShared *>(fuse_smem);
-  const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t *off = p.offs + (int64_t)q * 5;
-  const int64_t base = off[0];
-  const int T = (int)(off[4] - off[0]);
-  const unsigned INVALID = 0xffffffffu;
-
-  // 1) per-source maxima (linear normalisation, hybrid_search.py:26-32)
-  for (int s = 0; s < 3; ++s) {
-    double m = -__builtin_inf();
-    for (int64_t e = off[s] + tid; e < off[s + 1]; e += 1024) m = fmax(m, p.scores[e]);
-    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
-    if (lane == 0) sh.red[wave] = m;
-    __syncthreads();
-    if (tid == 0) {
-      double mm = sh.red[0];
-      for (int w = 1; w < 16; ++w) mm = fmax(mm, sh.red[w]);
-      sh.smax[s] = mm;
-    }
-    __syncthreads();
-  }
-  // 2) contribution of every entry
-  for (int e = tid; e < T; e += 1024) {
-    const int64_t g = base + e;
-    int s = 0;
-    while (s < 3 && g >= off[s + 1]) ++s;
-    const double sc = p.scores[g];
-    sh.key[e] = ((unsigned long long)p.ids[g] << 2) | (unsigned long long)s;
-    double c;
-    unsigned tie = INVALID;
-    if (s == 3) {
-      c = p.w[3] * sc;
-    } else if (p.method == 0) {
-      const double m = sh.smax[s];
-      c = p.w[s] * (m == 0.0 ? 0.0 : sc / m);
-    } else {
-      // rank = 1 + entries of this source ordered before e in a stable descending sort (:66-67)
-      int rank = 1;
-      for (int64_t o = off[s]; o < off[s + 1]; ++o) {
-        const double so = p.scores[o];
-        rank += (so > sc || (so == sc && o < g)) ? 1 : 0;
-      }
-      c = p.w[s] / (p.rrf_k + (double)rank);
-      tie = ((unsigned)s << 16) | (unsigned)rank;
-    }
-    sh.val[e] = c;
-    sh.tie[e] = tie;
-    sh.keep[e] = 0;
-  }
-  int Tp = 1;
-  while (Tp < T) Tp <<= 1;
-  for (int e = tid; e < Tp; e += 1024) sh.idx[e] = e < T ? (unsigned)e : INVALID;
-  if (tid == 0) sh.cnt = 0;
-  __syncthreads();
-
-  // 3) group by id: sort entry indices by (id, source)
-  {
-    const unsigned long long *key = sh.key;
-    bitonic_idx(sh.idx, Tp, [key](unsigned a, unsigned b) {
-      if (a == INVALID) return false;
-      if (b == INVALID) return true;
-      return key[a] < key[b];
-    });
-  }
-  // 4) each segment head sums its sources in the reference's order dense -> bm25 -> graph, then path
-  for (int i = tid; i < T; i += 1024) {
-    const unsigned e = sh.idx[i];
-    const unsigned long long id = sh.key[e] >> 2;
-    if (i > 0 && (sh.key[sh.idx[i - 1]] >> 2) == id) continue;
-    double f = 0.0, path_c = 0.0;
-    unsigned tie = INVALID;
-    bool nonpath = false, has_path = false;
-    for (int j = i; j < T; ++j) {
-      const unsigned ej = sh.idx[j];
-      if ((sh.key[ej] >> 2) != id) break;
-      if ((sh.key[ej] & 3ull) == 3ull) {
-        path_c = sh.val[ej];
-        has_path = true;
-      } else {
-        f += sh.val[ej];
-        nonpath = true;
-        tie = sh.tie[ej] < tie ? sh.tie[ej] : tie;
-      }
-    }
-    f = f + (has_path ? path_c : p.w[3] * 0.0);
-    if (p.method == 0 || nonpath) {  // rrf drops ids that occur only in `path` (:68-69)
-      sh.val[e] = f;
-      sh.tie[e] = tie;
-      sh.keep[e] = 1;
-      atomicAdd(&sh.cnt, 1u);
-    }
-  }
-  __syncthreads();
-  const int U = (int)sh.cnt;
-  __syncthreads();
-  // compact the surviving heads into idx (order irrelevant, sorted next)
-  if (tid == 0) sh.cnt = 0;
-  __syncthreads();
-  unsigned mine[(kFuseMax + 1023) / 1024];
-  int nm = 0;
-  for (int e = tid; e < T; e += 1024)
-    if (sh.keep[e]) mine[nm++] = (unsigned)e;
-  __syncthreads();
-  int Up = 1;
-  while (Up < U) Up <<= 1;
-  for (int k = 0; k < nm; ++k) sh.idx[atomicAdd(&sh.cnt, 1u)] = mine[k];
-  __syncthreads();
-  for (int e = U + tid; e < Up; e += 1024) sh.idx[e] = INVALID;
-  __syncthreads();
-  // 5) order by final descending; ties: rrf -> the reference's dict insertion order, linear -> id
-  {
-    const double *val = sh.val;
-    const unsigned *tie = sh.tie;
-    const unsigned long long *key = sh.key;
-    const int method = p.method;
-    bitonic_idx(sh.idx, Up, [val, tie, key, method](unsigned a, unsigned b) {
-      if (a == INVALID) return false;
-      if (b == INVALID) return true;
-      if (val[a] != val[b]) return val[a] > val[b];
-      if (method == 1 && tie[a] != tie[b]) return tie[a] < tie[b];
-      return key[a] < key[b];
-    });
-  }
-  // 6) emit
-  const int n_out = U < p.pool ? U : p.pool;
-  if (tid == 0) p.out_count[q] = n_out;
-  const double nan = __builtin_nan("");
-  for (int i = tid; i < p.pool; i += 1024) {
-    double *osr = p.out_src + ((int64_t)q * p.pool + i) * 4;
-    osr[0] = osr[1] = osr[2] = osr[3] = nan;
-    if (i < n_out) {
-      const unsigned e = sh.idx[i];
-      p.out_ids[(int64_t)q * p.pool + i] = (int64_t)(sh.key[e] >> 2);
-      p.out_final[(int64_t)q * p.pool + i] = sh.val[e];
-    } else {
-      p.out_ids[(int64_t)q * p.pool + i] = -1;
-      p.out_final[(int64_t)q * p.pool + i] = 0.0;
-    }
-  }
-  __syncthreads();
-  // raw source scores of the emitted ids: walk each emitted segment again
-  for (int e = tid; e < T; e += 1024) {
-    const unsigned long long id = sh.key[e] >> 2;
-    const int s = (int)(sh.key[e] & 3ull);
-    for (int i = 0; i < n_out; ++i) {
-      const unsigned h = sh.idx[i];
-      if ((sh.key[h] >> 2) == id) {
-        p.out_src[((int64_t)q * p.pool + i) * 4 + s] = p.scores[base + e];
-        break;
-      }
-    }
-  }
-}
-
-}  // namespace anr
+// Host side of anr_fuse_lists (include/anorag.h); the kernel lives in fusion_kernels.hpp.
+#include "fusion_kernels.hpp"
 
 using namespace anr;
 
@@ -287,9 +70,9 @@ extern "C" int anr_fuse_lists(int32_t device, int32_t method, int64_t nq, const 
   p.out_final = d_of;
   p.out_src = d_os;
   p.out_count = d_cnt;
-  FUSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fuse), hipFuncAttributeMaxDynamicSharedMemorySize,
+  FUSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fuse<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)sizeof(FuseShared)));
-  hipLaunchKernelGGL(k_fuse, dim3((unsigned)nq), dim3(1024), sizeof(FuseShared), 0, p);
+  hipLaunchKernelGGL(k_fuse<false>, dim3((unsigned)nq), dim3(1024), sizeof(FuseShared), 0, p);
   FUSE_HIP(hipGetLastError());
   FUSE_HIP(hipMemcpy(out_ids, d_oid, (size_t)nq * pool * 8, hipMemcpyDeviceToHost));
   FUSE_HIP(hipMemcpy(out_final, d_of, (size_t)nq * pool * 8, hipMemcpyDeviceToHost));

@@ -1,0 +1,901 @@
+// N-array score fusion behind anr_fuse_dense (include/anorag.h): HybridSearcher.fuse (reference
+// retrieval/hybrid_search.py:34-103) when a source is the full-corpus score vector that
+// utils/bm25_search.py:286-340 (bm25_scores) returns — one score per note, N of them — instead of a short list.
+//
+// BASELINE.json north_star: "linear/RRF fusion with the existing utils/bm25_search.py scores happens on-device as a
+// fused elementwise+argk kernel".  An array source stands for the list [(0, a[0]), (1, a[1]), ... (N-1, a[N-1])]:
+// every id present (NaN marks an absent id), list order = id order.  The other sources stay short (id, score) lists.
+//
+// Pipeline per batch of queries (everything float64, bit-identical finals):
+//   k_fd_prep    unique ids of the short lists; K' = pool + that count; (rrf) their keys in the array, sorted
+//   k_fd_max     linear: per-source maximum over the whole array (the reference max-normalises, :26-32)
+//   k_fd_scan    THE kernel, HBM-bound: streams the arrays once, computes the fused value of every id from its array
+//                sources ("elementwise"), and keeps the K' best per 8192-id chunk ("arg-k"): chunk 0 first (its K'-th
+//                value is a strict threshold for all later ids — they rank below chunk 0's K' on ties), then all
+//                other chunks, threshold-gated; a chunk that lets more than its list holds through selects its own
+//                K' best in LDS (radix select) and raises a shared running threshold.  rrf with one array source
+//                ranks by the raw array value and, in the same pass, counts for every short-list id how many array
+//                entries beat it (its exact 1-based rank among all N) — so no sort of the N-vector is needed.
+//   k_fd_build   per query: the K' best of all chunk lists, ordered; composes SHORT lists (candidates + short-list
+//                ids, raw scores, whole-source maxima / ranks as overrides)
+//   k_fuse<true> the reference arithmetic on those short lists (the kernel anr_fuse_lists uses; golden-pinned)
+// Exactness: an id outside the short lists has the same fused value in the stream as in the reference (all its
+// terms come from arrays), so the best `pool` of those are among the stream's K' best; ids of the short lists are
+// always candidates.  Ties: final desc, then the reference's order (rrf: ranks-dict insertion; linear: lower id,
+// where the reference iterates a set).
+#include <algorithm>
+#include <vector>
+
+#include "fusion_kernels.hpp"
+
+namespace anr {
+
+constexpr int kFdChunk = 8192;      // ids per scan workgroup
+constexpr int kFdThreads = 1024;
+constexpr int kFdPer = kFdChunk / kFdThreads;
+constexpr int kFdMaxSparse = 1024;  // unique short-list ids per query
+constexpr int kFdMaxK = 2048;       // K' = pool + unique short-list ids
+
+__device__ __forceinline__ unsigned long long d2ord(double v) {
+  // monotone double -> u64; NaN -> 1 (below every number, above the "no threshold" value 0); -0.0 == +0.0
+  if (v != v) return 1ull;
+  if (v == 0.0) v = 0.0;
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double ord2d(unsigned long long o) {
+  const unsigned long long u = (o >> 63) ? (o & 0x7fffffffffffffffull) : ~o;
+  return __longlong_as_double((long long)u);
+}
+
+struct FdSrc {
+  const void *arr;  // device [nq][len] or nullptr (short list / absent)
+  int dtype;        // 0 float64, 1 float32
+  int64_t len;      // ids >= len are absent from this source
+};
+
+struct FdParams {
+  int method;     // 0 linear, 1 rrf
+  int r1_src;     // rrf: the one array source (0..2), ranked by raw value; -1 for linear
+  int pool;
+  FdSrc src[4];
+  double w[4];
+  double rrf_k;
+  int64_t U;      // id universe of the stream: max array length
+  int64_t q0;     // first query of this sub-batch in the array sources
+  // short lists of the sub-batch (device copies of the caller's, same layout as anr_fuse_lists)
+  const int64_t *l_ids;
+  const double *l_sc;
+  const int64_t *l_offs;  // [nq][5]
+  // prep outputs
+  int *kprime;                   // [nq]
+  unsigned *su_id;               // [nq][kFdMaxSparse] unique short-list ids (ascending)
+  int *su_n;                     // [nq]
+  unsigned long long *sk_hi;     // [nq][kFdMaxSparse] rrf: keys of the short-list ids present in the array, descending
+  unsigned *sk_id;
+  int *sk_n;
+  unsigned *H;                   // [nq][kFdMaxSparse + 1] rrf rank histogram
+  unsigned long long *smax_ord;  // [nq][4] ordinal of the array maxima (0 = no entry)
+  unsigned long long *tau0;      // [nq] strict threshold from chunk 0 (0 = none)
+  unsigned long long *T;         // [nq] running (>=) threshold
+  unsigned long long *c_hi;      // [nq][n_chunks][lcap] candidate keys
+  unsigned *c_id;
+  unsigned *c_cnt;               // [nq][n_chunks]
+  int lcap, n_chunks;
+  int chunk0, prefix;            // scan launch: first chunk; prefix = 1 for the chunk-0 launch
+  // composed short lists for k_fuse<true>
+  int64_t *o_ids;                // [nq][kFuseMax]
+  double *o_sc;
+  int *o_rank;
+  int64_t *o_offs;               // [nq][5]
+  double *o_smax;                // [nq][4]
+};
+
+__device__ __forceinline__ bool fd_val(const FdSrc &s, int64_t q, int64_t i, double &v) {
+  if (!s.arr || i >= s.len) return false;
+  v = s.dtype == 0 ? reinterpret_cast<const double *>(s.arr)[q * s.len + i]
+                   : (double)reinterpret_cast<const float *>(s.arr)[q * s.len + i];
+  return v == v;
+}
+
+// fused value of id i from the ARRAY sources only, in the reference's order of operations (dense, bm25, graph, then
+// path; an absent term contributes w * 0.0 exactly as `normed[k].get(nid, 0.0)` does); false: the id occurs in none
+__device__ __forceinline__ bool fd_key(const FdParams &p, const double (&smax)[4], int64_t q, int64_t i,
+                                       unsigned long long &key) {
+  double v;
+  if (p.method == 1) {
+    if (!fd_val(p.src[p.r1_src], q, i, v)) return false;
+    key = d2ord(v);
+    return true;
+  }
+  double f = 0.0;
+  bool any = false;
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+    if (fd_val(p.src[s], q, i, v)) {
+      f += p.w[s] * (smax[s] == 0.0 ? 0.0 : v / smax[s]);
+      any = true;
+    }
+  const bool hp = fd_val(p.src[3], q, i, v);
+  f = f + (hp ? p.w[3] * v : p.w[3] * 0.0);
+  key = d2ord(f);
+  return any || hp;
+}
+
+struct FdShared {
+  unsigned long long hi[kFdChunk];
+  unsigned idx[kFdChunk];
+  unsigned long long sk_hi[kFdMaxSparse];
+  unsigned sk_id[kFdMaxSparse];
+  unsigned H[kFdMaxSparse + 1];
+  unsigned hist[256];
+  unsigned long long red[2][16];
+  unsigned long long bnd;  // select boundary
+  unsigned cut;
+  unsigned n, cnt, above, d, hd;
+};
+
+// The need-th largest key among the participating entries i < n (8-bit radix passes, common leading bytes skipped);
+// on return *eq = entries equal to it, *need_eq = how many of those belong to the `need` largest.  All threads call.
+template <typename KeyFn, typename PartFn>
+__device__ unsigned long long fd_radix_kth(FdShared &sh, int n, unsigned need, int total_bits, KeyFn key, PartFn part,
+                                           unsigned *eq, unsigned *need_eq) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned long long kmin = ~0ull, kmax = 0ull;
+  unsigned np = 0;
+  for (int i = tid; i < n; i += kFdThreads)
+    if (part(i)) {
+      const unsigned long long k = key(i);
+      kmin = k < kmin ? k : kmin;
+      kmax = k > kmax ? k : kmax;
+      ++np;
+    }
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long a = __shfl_xor(kmin, o), b = __shfl_xor(kmax, o);
+    kmin = a < kmin ? a : kmin;
+    kmax = b > kmax ? b : kmax;
+    np += __shfl_xor(np, o);
+  }
+  __syncthreads();
+  if (lane == 0) {
+    sh.red[0][wave] = kmin;
+    sh.red[1][wave] = kmax;
+    sh.hist[wave] = np;
+  }
+  __syncthreads();
+  kmin = sh.red[0][0];
+  kmax = sh.red[1][0];
+  unsigned total = sh.hist[0];
+  for (int w = 1; w < kFdThreads / 64; ++w) {
+    kmin = sh.red[0][w] < kmin ? sh.red[0][w] : kmin;
+    kmax = sh.red[1][w] > kmax ? sh.red[1][w] : kmax;
+    total += sh.hist[w];
+  }
+  __syncthreads();
+  int bits = 0;
+  while (bits < total_bits && (kmin >> (total_bits - 8 - bits)) == (kmax >> (total_bits - 8 - bits))) bits += 8;
+  unsigned long long prefix = bits ? (kmax >> (total_bits - bits)) : 0ull;
+  unsigned count_eq = total;  // entries matching the current prefix
+  while (bits < total_bits) {
+    for (int i = tid; i < 256; i += kFdThreads) sh.hist[i] = 0;
+    __syncthreads();
+    const int sh_d = total_bits - 8 - bits;
+    for (int i0 = 0; i0 < n; i0 += kFdThreads) {
+      const int i = i0 + tid;
+      bool act = false;
+      unsigned dg = 0;
+      if (i < n && part(i)) {
+        const unsigned long long k = key(i);
+        if (bits == 0 || (k >> (total_bits - bits)) == prefix) {
+          act = true;
+          dg = (unsigned)(k >> sh_d) & 255u;
+        }
+      }
+      // one wave-aggregated round (the common digit of a tie storm), the rest one atomic each
+      const unsigned long long m = __ballot(act);
+      if (m) {
+        const int leader = __ffsll((long long)m) - 1;
+        const unsigned dl = __shfl(dg, leader);
+        const unsigned long long same = __ballot(act && dg == dl);
+        if (lane == leader) atomicAdd(&sh.hist[dl], (unsigned)__popcll(same));
+        if (act && dg != dl) atomicAdd(&sh.hist[dg], 1u);
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {
+      // lane l owns digits 255-4l .. 252-4l: the digit at which the count from the top reaches `need`
+      const int dtop = 255 - 4 * lane;
+      const unsigned h0 = sh.hist[dtop], h1 = sh.hist[dtop - 1], h2 = sh.hist[dtop - 2], h3 = sh.hist[dtop - 3];
+      const unsigned own = h0 + h1 + h2 + h3;
+      unsigned incl = own;
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+      }
+      const unsigned excl = incl - own;
+      if (excl < need && need <= incl) {
+        unsigned c = excl;
+        int d = dtop;
+        unsigned hd = h0;
+        if (c + h0 < need) { c += h0; d = dtop - 1; hd = h1;
+          if (c + h1 < need) { c += h1; d = dtop - 2; hd = h2;
+            if (c + h2 < need) { c += h2; d = dtop - 3; hd = h3; } } }
+        sh.d = (unsigned)d;
+        sh.above = c;
+        sh.hd = hd;
+      }
+    }
+    __syncthreads();
+    need -= sh.above;
+    prefix = (prefix << 8) | (unsigned long long)sh.d;
+    count_eq = sh.hd;
+    bits += 8;
+    __syncthreads();
+  }
+  *eq = count_eq;
+  *need_eq = need;
+  return prefix;
+}
+
+// boundary of the K largest (hi desc, idx asc) of the n staged pairs (n > K): selected <=> hi > bnd || (hi == bnd &&
+// idx <= cut).  All threads call; result in sh.bnd / sh.cut.
+__device__ void fd_select_boundary(FdShared &sh, int n, int K) {
+  unsigned eq, need_eq;
+  const unsigned long long B = fd_radix_kth(
+      sh, n, (unsigned)K, 64, [&](int i) { return sh.hi[i]; }, [](int) { return true; }, &eq, &need_eq);
+  unsigned cut = 0xffffffffu;
+  if (need_eq < eq) {
+    // more entries tie with the boundary value than are wanted: the need_eq smallest ids of them
+    unsigned e2, n2;
+    const unsigned long long r = fd_radix_kth(
+        sh, n, need_eq, 32, [&](int i) { return (unsigned long long)(~sh.idx[i]); },
+        [&](int i) { return sh.hi[i] == B; }, &e2, &n2);
+    cut = ~(unsigned)r;
+  }
+  if (threadIdx.x == 0) {
+    sh.bnd = B;
+    sh.cut = cut;
+  }
+  __syncthreads();
+}
+
+// ---- prep: unique short-list ids, K', (rrf) their sorted keys in the array ---------------------------------
+__global__ __launch_bounds__(kFdThreads) void k_fd_prep(FdParams p) {
+  __shared__ unsigned long long key[2 * kFdMaxSparse];
+  __shared__ unsigned ids[2 * kFdMaxSparse];
+  __shared__ unsigned cnt;
+  const int q = blockIdx.x, tid = threadIdx.x;
+  const int64_t *off = p.l_offs + (int64_t)q * 5;
+  const int m = (int)(off[4] - off[0]);  // <= kFdMaxSparse (host-checked)
+  // sort the ids (with duplicates) ascending: bitonic over 1024 slots
+  for (int i = tid; i < kFdMaxSparse; i += kFdThreads) ids[i] = i < m ? (unsigned)p.l_ids[off[0] + i] : 0xffffffffu;
+  if (tid == 0) cnt = 0;
+  __syncthreads();
+  for (int k2 = 2; k2 <= kFdMaxSparse; k2 <<= 1)
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < kFdMaxSparse; i += kFdThreads) {
+        const int x = i ^ j;
+        if (x > i) {
+          const unsigned a = ids[i], b = ids[x];
+          if (((i & k2) == 0) ? (b < a) : (a < b)) {
+            ids[i] = b;
+            ids[x] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  // unique -> su_id (ascending order kept: compaction by prefix count)
+  unsigned *su = p.su_id + (int64_t)q * kFdMaxSparse;
+  for (int i = tid; i < m; i += kFdThreads) {
+    const bool first = (i == 0) || ids[i] != ids[i - 1];
+    ids[kFdMaxSparse + i] = first ? 1u : 0u;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    unsigned c = 0;
+    for (int i = 0; i < m; ++i)
+      if (ids[kFdMaxSparse + i]) su[c++] = ids[i];
+    cnt = c;
+  }
+  __syncthreads();
+  const int mu = (int)cnt;
+  if (tid == 0) {
+    p.su_n[q] = mu;
+    int kp = p.pool + mu;
+    p.kprime[q] = kp < kFdMaxK ? kp : kFdMaxK;
+  }
+  if (p.method != 1) return;
+  // rrf: (key, id) of the unique ids present in the array source, descending by (value, lower id first)
+  const FdSrc &a = p.src[p.r1_src];
+  for (int i = tid; i < kFdMaxSparse; i += kFdThreads) {
+    unsigned long long k = 0ull;
+    unsigned id = 0xffffffffu;
+    double v;
+    if (i < mu && fd_val(a, p.q0 + q, (int64_t)su[i], v)) {
+      k = d2ord(v);
+      id = su[i];
+    }
+    key[i] = k;  // 0 = absent, sorts last
+    ids[i] = id;
+  }
+  __syncthreads();
+  for (int k2 = 2; k2 <= kFdMaxSparse; k2 <<= 1)
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < kFdMaxSparse; i += kFdThreads) {
+        const int x = i ^ j;
+        if (x > i) {
+          const unsigned long long ka = key[i], kb = key[x];
+          const unsigned ia = ids[i], ib = ids[x];
+          const bool b_first = kb > ka || (kb == ka && ib < ia);  // descending key, ascending id
+          const bool a_first = ka > kb || (ka == kb && ia < ib);
+          if (((i & k2) == 0) ? b_first : a_first) {
+            key[i] = kb; key[x] = ka;
+            ids[i] = ib; ids[x] = ia;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  __shared__ int s_present;
+  if (tid == 0) s_present = 0;
+  __syncthreads();
+  for (int i = tid; i < kFdMaxSparse; i += kFdThreads) {
+    p.sk_hi[(int64_t)q * kFdMaxSparse + i] = key[i];
+    p.sk_id[(int64_t)q * kFdMaxSparse + i] = ids[i];
+    if (key[i] != 0ull) atomicAdd(&s_present, 1);
+  }
+  __syncthreads();
+  if (tid == 0) p.sk_n[q] = s_present;
+}
+
+// ---- linear: per-source maximum over the arrays ----------------------------------------------------------
+__global__ __launch_bounds__(kFdThreads) void k_fd_max(FdParams p) {
+  const int q = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  const int64_t base = (int64_t)blockIdx.x * kFdChunk;
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    if (!p.src[s].arr) continue;
+    unsigned long long best = 0ull;
+#pragma unroll
+    for (int e = 0; e < kFdPer; ++e) {
+      double v;
+      if (fd_val(p.src[s], p.q0 + q, base + e * kFdThreads + tid, v)) {
+        const unsigned long long o = d2ord(v);
+        best = o > best ? o : best;
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long t = __shfl_xor(best, o);
+      best = t > best ? t : best;
+    }
+    if (lane == 0 && best) atomicMax(p.smax_ord + (int64_t)q * 4 + s, best);
+  }
+}
+
+// ---- the scan ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kFdThreads) void k_fd_scan(FdParams p) {
+  extern __shared__ unsigned char fd_smem[];
+  FdShared &sh = *reinterpret_cast<FdShared *>(fd_smem);
+  const int q = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  const int c = p.chunk0 + blockIdx.x;
+  const int64_t base = (int64_t)c * kFdChunk;
+  const int kp = p.kprime[q];
+  double smax[4] = {0.0, 0.0, 0.0, 0.0};
+  if (p.method == 0)
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const unsigned long long o = p.smax_ord[(int64_t)q * 4 + s];
+      smax[s] = o ? ord2d(o) : 0.0;
+    }
+  int skn = 0;
+  if (p.method == 1) {
+    skn = p.sk_n[q];
+    for (int i = tid; i < skn; i += kFdThreads) {
+      sh.sk_hi[i] = p.sk_hi[(int64_t)q * kFdMaxSparse + i];
+      sh.sk_id[i] = p.sk_id[(int64_t)q * kFdMaxSparse + i];
+    }
+    for (int i = tid; i <= skn; i += kFdThreads) sh.H[i] = 0;
+  }
+  if (tid == 0) {
+    sh.n = 0;
+    sh.cnt = 0;
+  }
+  __syncthreads();
+  const unsigned long long tau0 = p.prefix ? 0ull : p.tau0[q];
+  const unsigned long long T = p.prefix ? 0ull : __hip_atomic_load(p.T + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+  for (int e = 0; e < kFdPer; ++e) {
+    const int64_t i = base + e * kFdThreads + tid;
+    unsigned long long key = 0ull;
+    const bool valid = i < p.U && fd_key(p, smax, p.q0 + q, i, key);
+    if (p.method == 1 && skn > 0) {
+      // rank histogram: pb = short-list keys that beat this entry (they are sorted descending)
+      unsigned pb = 0;
+      if (valid) {
+        int lo = 0, hi = skn;  // keys [0, lo) beat the entry, keys [hi, skn) do not
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          const unsigned long long kh = sh.sk_hi[mid];
+          const bool beats = kh > key || (kh == key && (int64_t)sh.sk_id[mid] < i);
+          if (beats) lo = mid + 1;
+          else hi = mid;
+        }
+        pb = (unsigned)lo;
+      }
+      const unsigned long long m = __ballot(valid);
+      if (m) {
+        const int leader = __ffsll((long long)m) - 1;
+        const unsigned pl = __shfl(pb, leader);
+        const unsigned long long same = __ballot(valid && pb == pl);
+        if (lane == leader) atomicAdd(&sh.H[pl], (unsigned)__popcll(same));
+        if (valid && pb != pl) atomicAdd(&sh.H[pb], 1u);
+      }
+    }
+    const bool pass = valid && key > tau0 && key >= T;
+    const unsigned long long pm = __ballot(pass);
+    if (pm) {
+      unsigned wbase = 0;
+      if (lane == 0) wbase = atomicAdd(&sh.n, (unsigned)__popcll(pm));
+      wbase = __shfl(wbase, 0);
+      if (pass) {
+        const unsigned pos = wbase + (unsigned)__popcll(pm & ((1ull << lane) - 1ull));
+        sh.hi[pos] = key;
+        sh.idx[pos] = (unsigned)i;
+      }
+    }
+  }
+  __syncthreads();
+  if (p.method == 1 && skn > 0) {
+    unsigned *Hq = p.H + (int64_t)q * (kFdMaxSparse + 1);
+    for (int i = tid; i <= skn; i += kFdThreads)
+      if (sh.H[i]) atomicAdd(Hq + i, sh.H[i]);
+  }
+  const int n = (int)sh.n;
+  unsigned long long *lh = p.c_hi + ((int64_t)q * p.n_chunks + c) * p.lcap;
+  unsigned *li = p.c_id + ((int64_t)q * p.n_chunks + c) * p.lcap;
+  const int room = p.prefix ? kp : p.lcap;
+  if (n <= room) {
+    for (int i = tid; i < n; i += kFdThreads) {
+      lh[i] = sh.hi[i];
+      li[i] = sh.idx[i];
+    }
+    if (tid == 0) {
+      p.c_cnt[(int64_t)q * p.n_chunks + c] = (unsigned)n;
+      if (p.prefix) p.tau0[q] = 0ull;  // fewer than K' ids in chunk 0: no threshold
+    }
+    return;
+  }
+  fd_select_boundary(sh, n, kp);
+  const unsigned long long B = sh.bnd;
+  const unsigned cut = sh.cut;
+  for (int i0 = 0; i0 < n; i0 += kFdThreads) {
+    const int i = i0 + tid;
+    const bool sel = i < n && (sh.hi[i] > B || (sh.hi[i] == B && sh.idx[i] <= cut));
+    const unsigned long long sm = __ballot(sel);
+    if (sm) {
+      unsigned wbase = 0;
+      if (lane == 0) wbase = atomicAdd(&sh.cnt, (unsigned)__popcll(sm));
+      wbase = __shfl(wbase, 0);
+      if (sel) {
+        const unsigned pos = wbase + (unsigned)__popcll(sm & ((1ull << lane) - 1ull));
+        if (pos < (unsigned)p.lcap) {
+          lh[pos] = sh.hi[i];
+          li[pos] = sh.idx[i];
+        }
+      }
+    }
+  }
+  if (tid == 0) {
+    p.c_cnt[(int64_t)q * p.n_chunks + c] = (unsigned)kp;
+    if (p.prefix) p.tau0[q] = B;          // later ids tie-break below chunk 0's K': strictly greater only
+    else atomicMax(p.T + q, B);            // K' ids at or above B exist: a valid (>=) threshold for everyone
+  }
+}
+
+// ---- build: K' best of the chunk lists, ordered; compose the short lists k_fuse<true> consumes ------------------
+__global__ __launch_bounds__(kFdThreads) void k_fd_build(FdParams p) {
+  extern __shared__ unsigned char fd_smem[];
+  FdShared &sh = *reinterpret_cast<FdShared *>(fd_smem);
+  __shared__ unsigned s_off[6];
+  const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int kp = p.kprime[q];
+  int n = 0;
+  auto reduce = [&]() {  // keep the kp best of the n staged pairs, compacted to the front
+    if (n <= kp) return;
+    fd_select_boundary(sh, n, kp);
+    const unsigned long long B = sh.bnd;
+    const unsigned cut = sh.cut;
+    unsigned long long rh[kFdPer];
+    unsigned ri[kFdPer];
+    bool rs[kFdPer];
+#pragma unroll
+    for (int e = 0; e < kFdPer; ++e) {
+      const int i = e * kFdThreads + tid;
+      rs[e] = i < n && (sh.hi[i] > B || (sh.hi[i] == B && sh.idx[i] <= cut));
+      rh[e] = i < n ? sh.hi[i] : 0ull;
+      ri[e] = i < n ? sh.idx[i] : 0u;
+    }
+    if (tid == 0) sh.cnt = 0;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < kFdPer; ++e) {
+      const unsigned long long sm = __ballot(rs[e]);
+      if (sm) {
+        unsigned wbase = 0;
+        if (lane == 0) wbase = atomicAdd(&sh.cnt, (unsigned)__popcll(sm));
+        wbase = __shfl(wbase, 0);
+        if (rs[e]) {
+          const unsigned pos = wbase + (unsigned)__popcll(sm & ((1ull << lane) - 1ull));
+          sh.hi[pos] = rh[e];
+          sh.idx[pos] = ri[e];
+        }
+      }
+    }
+    __syncthreads();
+    n = kp;
+  };
+  for (int c = 0; c < p.n_chunks; ++c) {
+    const int cnt = (int)p.c_cnt[(int64_t)q * p.n_chunks + c];
+    if (cnt == 0) continue;
+    if (n + cnt > kFdChunk) reduce();
+    const unsigned long long *lh = p.c_hi + ((int64_t)q * p.n_chunks + c) * p.lcap;
+    const unsigned *li = p.c_id + ((int64_t)q * p.n_chunks + c) * p.lcap;
+    for (int i = tid; i < cnt; i += kFdThreads) {
+      sh.hi[n + i] = lh[i];
+      sh.idx[n + i] = li[i];
+    }
+    n += cnt;
+    __syncthreads();
+  }
+  reduce();
+  // order the n <= kFdMaxK candidates: (key desc, id asc) by rank counting into the upper half of the arrays
+  unsigned long long *s_hi = sh.hi + kFdChunk / 2;
+  unsigned *s_id = sh.idx + kFdChunk / 2;
+  for (int i = tid; i < n; i += kFdThreads) {
+    const unsigned long long k = sh.hi[i];
+    const unsigned id = sh.idx[i];
+    int r = 0;
+    for (int j = 0; j < n; ++j) r += (sh.hi[j] > k || (sh.hi[j] == k && sh.idx[j] < id)) ? 1 : 0;
+    s_hi[r] = k;
+    s_id[r] = id;
+  }
+  __syncthreads();
+  // rrf: exclusive prefix of the rank histogram -> rank of the j-th (0-based) sorted short-list key = sum H[0..j]
+  const int mu = p.su_n[q];
+  const unsigned *su = p.su_id + (int64_t)q * kFdMaxSparse;
+  int skn = 0;
+  if (p.method == 1) {
+    skn = p.sk_n[q];
+    const unsigned *Hq = p.H + (int64_t)q * (kFdMaxSparse + 1);
+    for (int i = tid; i < skn; i += kFdThreads) {
+      sh.sk_hi[i] = p.sk_hi[(int64_t)q * kFdMaxSparse + i];
+      sh.sk_id[i] = p.sk_id[(int64_t)q * kFdMaxSparse + i];
+    }
+    if (tid == 0) {
+      unsigned acc = 0;
+      for (int j = 0; j < skn; ++j) {
+        acc += Hq[j];
+        sh.H[j] = acc;  // entries at or above key j, itself included == its 1-based rank
+      }
+    }
+  }
+  __syncthreads();
+  // compose: per source either the caller's short list, or (array source) the candidates + the short-list ids
+  int64_t *oi = p.o_ids + (int64_t)q * kFuseMax;
+  double *os = p.o_sc + (int64_t)q * kFuseMax;
+  int *orank = p.o_rank + (int64_t)q * kFuseMax;
+  const int64_t *off = p.l_offs + (int64_t)q * 5;
+  if (tid == 0) s_off[0] = 0;
+  __syncthreads();
+  for (int s = 0; s < 4; ++s) {
+    const unsigned b0 = s_off[s];
+    if (tid == 0) sh.cnt = 0;
+    __syncthreads();
+    if (!p.src[s].arr) {
+      const int m = (int)(off[s + 1] - off[s]);
+      for (int i = tid; i < m; i += kFdThreads) {
+        oi[b0 + i] = p.l_ids[off[s] + i];
+        os[b0 + i] = p.l_sc[off[s] + i];
+        orank[b0 + i] = 0;
+      }
+      if (tid == 0) sh.cnt = (unsigned)m;
+    } else {
+      const bool r1 = p.method == 1 && s == p.r1_src;
+      // candidates (sorted position r -> rank r + 1 in the whole array)
+      for (int r0 = 0; r0 < n; r0 += kFdThreads) {
+        const int r = r0 + tid;
+        double v = 0.0;
+        const bool have = r < n && fd_val(p.src[s], p.q0 + q, (int64_t)s_id[r], v);
+        const unsigned long long hm = __ballot(have);
+        if (hm) {
+          unsigned wbase = 0;
+          if (lane == 0) wbase = atomicAdd(&sh.cnt, (unsigned)__popcll(hm));
+          wbase = __shfl(wbase, 0);
+          if (have) {
+            const unsigned pos = b0 + wbase + (unsigned)__popcll(hm & ((1ull << lane) - 1ull));
+            oi[pos] = (int64_t)s_id[r];
+            os[pos] = v;
+            orank[pos] = r1 ? r + 1 : 0;
+          }
+        }
+      }
+      // short-list ids that are not candidates
+      for (int j0 = 0; j0 < mu; j0 += kFdThreads) {
+        const int j = j0 + tid;
+        double v = 0.0;
+        bool have = j < mu && fd_val(p.src[s], p.q0 + q, (int64_t)su[j], v);
+        int rank = 0;
+        if (have) {
+          const unsigned id = su[j];
+          for (int r = 0; r < n; ++r)
+            if (s_id[r] == id) {
+              have = false;  // already listed as a candidate
+              break;
+            }
+          if (have && r1) {
+            const unsigned long long k = d2ord(v);
+            int lo = 0, hi = skn;  // position of (k, id) among the sorted short-list keys
+            while (lo < hi) {
+              const int mid = (lo + hi) >> 1;
+              const bool before = sh.sk_hi[mid] > k || (sh.sk_hi[mid] == k && sh.sk_id[mid] < id);
+              if (before) lo = mid + 1;
+              else hi = mid;
+            }
+            rank = (int)sh.H[lo];
+          }
+        }
+        const unsigned long long hm = __ballot(have);
+        if (hm) {
+          unsigned wbase = 0;
+          if (lane == 0) wbase = atomicAdd(&sh.cnt, (unsigned)__popcll(hm));
+          wbase = __shfl(wbase, 0);
+          if (have) {
+            const unsigned pos = b0 + wbase + (unsigned)__popcll(hm & ((1ull << lane) - 1ull));
+            oi[pos] = (int64_t)su[j];
+            os[pos] = v;
+            orank[pos] = rank;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (tid == 0) s_off[s + 1] = b0 + sh.cnt;
+    __syncthreads();
+  }
+  if (tid < 5) p.o_offs[(int64_t)q * 5 + tid] = (int64_t)q * kFuseMax + s_off[tid];
+  if (tid < 4) {
+    double m = __builtin_nan("");
+    if (p.method == 0 && tid < 3 && p.src[tid].arr) {
+      const unsigned long long o = p.smax_ord[(int64_t)q * 4 + tid];
+      m = o ? ord2d(o) : -__builtin_inf();
+    }
+    p.o_smax[(int64_t)q * 4 + tid] = m;
+  }
+}
+
+}  // namespace anr
+
+using namespace anr;
+
+namespace {
+struct DevBuf {
+  void *p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  template <typename T>
+  T *as() { return reinterpret_cast<T *>(p); }
+  int alloc(size_t bytes) {
+    if (hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) return fail(ANR_EHIP, "hipMalloc(%zu) failed", bytes);
+    return ANR_OK;
+  }
+};
+}  // namespace
+
+extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const anr_fuse_source *src,
+                              const double *weights, double rrf_k, int32_t pool, int64_t *out_ids, double *out_final,
+                              double *out_src, int32_t *out_count, anr_fuse_dense_stats *stats) {
+  if (nq < 0 || !src || !weights || pool <= 0 || !out_ids || !out_final || !out_src || !out_count)
+    return fail(ANR_EINVAL, "bad argument");
+  if (method != 0 && method != 1) return fail(ANR_EINVAL, "method must be 0 (linear) or 1 (rrf)");
+  if (pool > kFdMaxSparse) return fail(ANR_EINVAL, "pool must be <= %d", kFdMaxSparse);
+  if (nq == 0) return ANR_OK;
+  int n_arr = 0, r1 = -1;
+  int64_t U = 0;
+  for (int s = 0; s < 4; ++s) {
+    if (src[s].array_dev) {
+      if (src[s].list_offs) return fail(ANR_EINVAL, "source %d is given both as an array and as lists", s);
+      if (src[s].array_len <= 0 || src[s].array_len > 0xfffffff0ll) return fail(ANR_EINVAL, "source %d: bad array length", s);
+      if (src[s].array_dtype != 0 && src[s].array_dtype != 1) return fail(ANR_EINVAL, "source %d: dtype must be 0 (f64) or 1 (f32)", s);
+      ++n_arr;
+      U = std::max<int64_t>(U, src[s].array_len);
+      if (s < 3) r1 = s;
+      if (method == 1 && s == 3) return fail(ANR_EINVAL, "rrf: the path source must be a list");
+    } else if (src[s].list_offs && (!src[s].list_ids || !src[s].list_scores) && src[s].list_offs[nq] > src[s].list_offs[0]) {
+      return fail(ANR_EINVAL, "source %d: null list pointers", s);
+    }
+  }
+  if (n_arr == 0) return fail(ANR_EINVAL, "no array source: use anr_fuse_lists");
+  if (method == 1 && n_arr != 1)
+    return fail(ANR_EINVAL, "rrf handles ONE array source (its ranks are counted in the stream); %d given", n_arr);
+  // flatten the short lists of all queries into the anr_fuse_lists layout
+  std::vector<int64_t> offs((size_t)nq * 5), lids;
+  std::vector<double> lsc;
+  for (int64_t q = 0; q < nq; ++q) {
+    const int64_t start = (int64_t)lids.size();
+    for (int s = 0; s < 4; ++s) {
+      offs[q * 5 + s] = (int64_t)lids.size();
+      if (!src[s].array_dev && src[s].list_offs) {
+        const int64_t a = src[s].list_offs[q], b = src[s].list_offs[q + 1];
+        if (b < a) return fail(ANR_EINVAL, "source %d: offsets must be non-decreasing", s);
+        for (int64_t e = a; e < b; ++e) {
+          if (src[s].list_ids[e] < 0 || src[s].list_ids[e] > 0xfffffff0ll)
+            return fail(ANR_EINVAL, "source %d: id %lld out of range", s, (long long)src[s].list_ids[e]);
+          lids.push_back(src[s].list_ids[e]);
+          lsc.push_back(src[s].list_scores[e]);
+        }
+      }
+    }
+    offs[q * 5 + 4] = (int64_t)lids.size();
+    const int64_t m = (int64_t)lids.size() - start;
+    if (m > kFdMaxSparse)
+      return fail(ANR_EINVAL, "query %lld: %lld short-list entries beside the arrays (at most %d)", (long long)q,
+                  (long long)m, kFdMaxSparse);
+    if ((int64_t)n_arr * (pool + 2 * m) + m > kFuseMax)
+      return fail(ANR_EINVAL, "query %lld: pool %d with %lld short-list entries and %d arrays exceeds the fused kernel's %d entries",
+                  (long long)q, pool, (long long)m, n_arr, kFuseMax);
+  }
+  DeviceGuard g(device);
+  if (!g.ok) return fail(ANR_EHIP, "hipSetDevice(%d) failed", device);
+  const int n_chunks = (int)ceil_div(U, kFdChunk);
+  const int lcap = (int)std::max<int64_t>(256, round_up(std::min<int64_t>(kFdMaxK, pool + kFdMaxSparse), 64));
+  // query sub-batches so that the candidate lists stay below ~256 MiB
+  const int64_t per_q = (int64_t)n_chunks * lcap * 12;
+  const int64_t QB = std::max<int64_t>(1, std::min<int64_t>(nq, ((int64_t)256 << 20) / std::max<int64_t>(per_q, 1)));
+  DevBuf b_lids, b_lsc, b_offs, b_kp, b_su, b_sun, b_skh, b_ski, b_skn, b_H, b_smax, b_tau, b_T, b_chi, b_cid, b_ccnt,
+      b_oi, b_os, b_or, b_oo, b_om, b_xi, b_xf, b_xs, b_xc;
+  ANR_TRY(b_lids.alloc(lids.size() * 8));
+  ANR_TRY(b_lsc.alloc(lsc.size() * 8));
+  ANR_TRY(b_offs.alloc((size_t)QB * 5 * 8));
+  ANR_TRY(b_kp.alloc((size_t)QB * 4));
+  ANR_TRY(b_su.alloc((size_t)QB * kFdMaxSparse * 4));
+  ANR_TRY(b_sun.alloc((size_t)QB * 4));
+  ANR_TRY(b_skh.alloc((size_t)QB * kFdMaxSparse * 8));
+  ANR_TRY(b_ski.alloc((size_t)QB * kFdMaxSparse * 4));
+  ANR_TRY(b_skn.alloc((size_t)QB * 4));
+  ANR_TRY(b_H.alloc((size_t)QB * (kFdMaxSparse + 1) * 4));
+  ANR_TRY(b_smax.alloc((size_t)QB * 4 * 8));
+  ANR_TRY(b_tau.alloc((size_t)QB * 8));
+  ANR_TRY(b_T.alloc((size_t)QB * 8));
+  ANR_TRY(b_chi.alloc((size_t)QB * n_chunks * lcap * 8));
+  ANR_TRY(b_cid.alloc((size_t)QB * n_chunks * lcap * 4));
+  ANR_TRY(b_ccnt.alloc((size_t)QB * n_chunks * 4));
+  ANR_TRY(b_oi.alloc((size_t)QB * kFuseMax * 8));
+  ANR_TRY(b_os.alloc((size_t)QB * kFuseMax * 8));
+  ANR_TRY(b_or.alloc((size_t)QB * kFuseMax * 4));
+  ANR_TRY(b_oo.alloc((size_t)QB * 5 * 8));
+  ANR_TRY(b_om.alloc((size_t)QB * 4 * 8));
+  ANR_TRY(b_xi.alloc((size_t)QB * pool * 8));
+  ANR_TRY(b_xf.alloc((size_t)QB * pool * 8));
+  ANR_TRY(b_xs.alloc((size_t)QB * pool * 4 * 8));
+  ANR_TRY(b_xc.alloc((size_t)QB * 4));
+  if (!lids.empty()) {
+    ANR_HIP(hipMemcpy(b_lids.p, lids.data(), lids.size() * 8, hipMemcpyHostToDevice));
+    ANR_HIP(hipMemcpy(b_lsc.p, lsc.data(), lsc.size() * 8, hipMemcpyHostToDevice));
+  }
+  ANR_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_fd_scan), (int)sizeof(FdShared)));
+  ANR_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_fd_build), (int)sizeof(FdShared)));
+  ANR_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_fuse<true>), (int)sizeof(FuseShared)));
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  const bool timed = stats != nullptr;
+  if (timed) {
+    ANR_HIP(hipEventCreate(&ev[0]));
+    ANR_HIP(hipEventCreate(&ev[1]));
+    *stats = anr_fuse_dense_stats{};
+  }
+  int rc = ANR_OK;
+  hipStream_t st = nullptr;
+  for (int64_t q0 = 0; q0 < nq && rc == ANR_OK; q0 += QB) {
+    const int64_t nb = std::min(QB, nq - q0);
+    FdParams p{};
+    p.method = method;
+    p.r1_src = method == 1 ? r1 : -1;
+    p.pool = pool;
+    for (int s = 0; s < 4; ++s) {
+      p.src[s].arr = src[s].array_dev;
+      p.src[s].dtype = src[s].array_dtype;
+      p.src[s].len = src[s].array_dev ? src[s].array_len : 0;
+      p.w[s] = weights[s];
+    }
+    p.rrf_k = rrf_k;
+    p.U = U;
+    p.q0 = q0;
+    p.l_ids = b_lids.as<int64_t>();
+    p.l_sc = b_lsc.as<double>();
+    p.l_offs = b_offs.as<int64_t>();
+    p.kprime = b_kp.as<int>();
+    p.su_id = b_su.as<unsigned>();
+    p.su_n = b_sun.as<int>();
+    p.sk_hi = b_skh.as<unsigned long long>();
+    p.sk_id = b_ski.as<unsigned>();
+    p.sk_n = b_skn.as<int>();
+    p.H = b_H.as<unsigned>();
+    p.smax_ord = b_smax.as<unsigned long long>();
+    p.tau0 = b_tau.as<unsigned long long>();
+    p.T = b_T.as<unsigned long long>();
+    p.c_hi = b_chi.as<unsigned long long>();
+    p.c_id = b_cid.as<unsigned>();
+    p.c_cnt = b_ccnt.as<unsigned>();
+    p.lcap = lcap;
+    p.n_chunks = n_chunks;
+    p.o_ids = b_oi.as<int64_t>();
+    p.o_sc = b_os.as<double>();
+    p.o_rank = b_or.as<int>();
+    p.o_offs = b_oo.as<int64_t>();
+    p.o_smax = b_om.as<double>();
+    hipError_t e = hipMemcpyAsync(b_offs.p, offs.data() + q0 * 5, (size_t)nb * 5 * 8, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemsetAsync(b_H.p, 0, (size_t)nb * (kFdMaxSparse + 1) * 4, st);
+    if (e == hipSuccess) e = hipMemsetAsync(b_smax.p, 0, (size_t)nb * 4 * 8, st);
+    if (e == hipSuccess) e = hipMemsetAsync(b_T.p, 0, (size_t)nb * 8, st);
+    if (e == hipSuccess) e = hipMemsetAsync(b_tau.p, 0, (size_t)nb * 8, st);
+    if (e == hipSuccess) e = hipMemsetAsync(b_ccnt.p, 0, (size_t)nb * n_chunks * 4, st);
+    if (e != hipSuccess) {
+      rc = fail(ANR_EHIP, "fuse_dense setup failed: %s", hipGetErrorString(e));
+      break;
+    }
+    hipLaunchKernelGGL(k_fd_prep, dim3((unsigned)nb), dim3(kFdThreads), 0, st, p);
+    if (timed) (void)hipEventRecord(ev[0], st);
+    if (method == 0) hipLaunchKernelGGL(k_fd_max, dim3((unsigned)n_chunks, (unsigned)nb), dim3(kFdThreads), 0, st, p);
+    p.chunk0 = 0;
+    p.prefix = 1;
+    hipLaunchKernelGGL(k_fd_scan, dim3(1, (unsigned)nb), dim3(kFdThreads), sizeof(FdShared), st, p);
+    if (n_chunks > 1) {
+      p.chunk0 = 1;
+      p.prefix = 0;
+      hipLaunchKernelGGL(k_fd_scan, dim3((unsigned)(n_chunks - 1), (unsigned)nb), dim3(kFdThreads), sizeof(FdShared), st, p);
+    }
+    if (timed) (void)hipEventRecord(ev[1], st);
+    hipLaunchKernelGGL(k_fd_build, dim3((unsigned)nb), dim3(kFdThreads), sizeof(FdShared), st, p);
+    FuseParams fp{};
+    fp.method = method;
+    fp.ids = p.o_ids;
+    fp.scores = p.o_sc;
+    fp.offs = p.o_offs;
+    for (int s = 0; s < 4; ++s) fp.w[s] = weights[s];
+    fp.rrf_k = rrf_k;
+    fp.pool = pool;
+    fp.out_ids = b_xi.as<int64_t>();
+    fp.out_final = b_xf.as<double>();
+    fp.out_src = b_xs.as<double>();
+    fp.out_count = b_xc.as<int>();
+    fp.smax_ovr = p.o_smax;
+    fp.rank_ovr = p.o_rank;
+    hipLaunchKernelGGL(k_fuse<true>, dim3((unsigned)nb), dim3(1024), sizeof(FuseShared), st, fp);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out_ids + q0 * pool, b_xi.p, (size_t)nb * pool * 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(out_final + q0 * pool, b_xf.p, (size_t)nb * pool * 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(out_src + q0 * pool * 4, b_xs.p, (size_t)nb * pool * 32, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(out_count + q0, b_xc.p, (size_t)nb * 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+      rc = fail(ANR_EHIP, "fuse_dense failed: %s", hipGetErrorString(e));
+      break;
+    }
+    if (timed) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) stats->scan_ms += ms;
+      int64_t bytes = 0;
+      for (int s = 0; s < 4; ++s)
+        if (src[s].array_dev) bytes += src[s].array_len * (src[s].array_dtype == 0 ? 8 : 4);
+      stats->scan_bytes += bytes * nb;
+      stats->n_queries += nb;
+      std::vector<unsigned> cc((size_t)nb * n_chunks);
+      if (hipMemcpy(cc.data(), b_ccnt.p, cc.size() * 4, hipMemcpyDeviceToHost) == hipSuccess)
+        for (unsigned v : cc) stats->n_candidates += v;
+    }
+  }
+  for (auto &e : ev)
+    if (e) (void)hipEventDestroy(e);
+  return rc;
+}

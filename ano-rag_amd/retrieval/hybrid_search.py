@@ -5,8 +5,13 @@ final similarity of every note is the fusion of the dense, bm25 and graph retrie
 max-normalised weighted sum, ``rrf``: weighted reciprocal rank) plus an additive path score; the result is
 the list of ``{note_id, scores, final_similarity, tags}`` dicts, best first, cut to ``candidate_pool``.
 
-The arithmetic runs on the device (``anr_fuse_lists`` of libanorag_hip.so, float64 in the reference's order of
-operations, so ``final_similarity`` is bit-identical); this module only maps note ids to integers and back.
+The arithmetic runs on the device (libanorag_hip.so, float64 in the reference's order of operations, so
+``final_similarity`` is bit-identical); this module only maps note ids to integers and back.  Short inputs (at most
+4096 list entries per query) take ``anr_fuse_lists`` (everything LDS-resident); longer ones — e.g. the N-length
+``bm25_scores`` vector zipped with the note ids — take ``anr_fuse_dense``: the long source becomes a device array
+that is streamed once (fused elementwise + arg-k), so ``fuse`` accepts lists of any length, as the reference does.
+``fuse_arrays`` is the same kernel for callers that already hold integer ids and device-resident score vectors
+(``DeviceBM25.scores_device``): nothing but the pool-sized result leaves the device.
 There is no CPU fallback: without the HIP library ``fuse`` raises.
 """
 from __future__ import annotations
@@ -17,8 +22,11 @@ from typing import Any, Dict, List, Sequence, Tuple
 import numpy as np
 
 from anorag_hip import _lib
+from anorag_hip.fusion import DeviceArray, fuse_dense
 
 _SOURCES = ("dense", "bm25", "graph", "path")
+_LIST_MAX = 4096    # entries per query of the LDS-resident list kernel (csrc/fusion_kernels.hpp kFuseMax)
+_SHORT_MAX = 1024   # short-list entries per query beside the arrays of anr_fuse_dense
 
 
 class HybridSearcher:
@@ -67,6 +75,15 @@ class HybridSearcher:
         pool = int(self.candidate_pool)
         if pool <= 0:
             return [[] for _ in queries]
+        big = [qi for qi, lists in enumerate(queries) if sum(len(lst or ()) for lst in lists) > _LIST_MAX]
+        if big:  # long inputs: one anr_fuse_dense call each (every such query has its own id universe)
+            results: List[Any] = [None] * nq
+            for qi in big:
+                results[qi] = self._fuse_long(queries[qi], pool)
+            rest = [qi for qi in range(nq) if results[qi] is None]
+            for qi, r in zip(rest, self.fuse_batch([queries[qi] for qi in rest]) if rest else []):
+                results[qi] = r
+            return results
         all_ids: List[int] = []
         all_sc: List[float] = []
         offs = np.zeros((nq, 5), dtype=np.int64)
@@ -125,6 +142,98 @@ class HybridSearcher:
                 })
             results.append(res)
         return results
+
+
+    # -- long inputs -------------------------------------------------------------------------------------------
+    def _fuse_long(self, lists, pool: int) -> List[Dict[str, Any]]:
+        """one query whose lists exceed the LDS kernel: the long sources become device arrays over this query's id
+        universe (NaN = the id is absent from that source), the rest stay short lists"""
+        dicts = [{nid: s for nid, s in (lst or [])} for lst in lists]
+        lens = [len(d) for d in dicts]
+        rrf = self.fusion_method == "rrf"
+        order = sorted(range(3 if rrf else 4), key=lambda s: -lens[s])
+        arrays = [order[0]]
+        if rrf:
+            if sum(lens) - lens[arrays[0]] > _SHORT_MAX:
+                raise _lib.AnoragError(
+                    f"rrf fusion handles one long source per query (here {lens}); the others may hold {_SHORT_MAX} "
+                    "entries in all")
+        else:
+            for s in order[1:]:
+                if sum(lens[t] for t in range(4) if t not in arrays) <= _SHORT_MAX:
+                    break
+                arrays.append(s)
+        # id universe: the first array's ids in ITS list order (rrf ranks ties in list order: array order == list order)
+        to_int: Dict[Any, int] = {}
+        names: List[Any] = []
+        for s in arrays + [t for t in range(4) if t not in arrays]:
+            for nid in dicts[s]:
+                if nid not in to_int:
+                    to_int[nid] = len(names)
+                    names.append(nid)
+        sources: Dict[str, Any] = {}
+        held = []
+        for s in range(4):
+            if not dicts[s]:
+                continue
+            if s in arrays:
+                n = lens[s] if s == arrays[0] else len(names)
+                a = np.full((1, n), np.nan, dtype=np.float64)
+                a[0, [to_int[nid] for nid in dicts[s]]] = [float(v) for v in dicts[s].values()]
+                arr = DeviceArray.from_numpy(a, self.device)
+                held.append(arr)
+                sources[_SOURCES[s]] = arr
+            else:
+                sources[_SOURCES[s]] = [(np.fromiter((to_int[nid] for nid in dicts[s]), dtype=np.int64, count=lens[s]),
+                                         np.fromiter((float(v) for v in dicts[s].values()), dtype=np.float64,
+                                                     count=lens[s]))]
+        try:
+            o_ids, o_fin, _, o_cnt = fuse_dense(self.fusion_method, self.weights, float(self.rrf_k), pool, 1, sources,
+                                                device=self.device)
+        finally:
+            for arr in held:
+                arr.free()
+        res = []
+        for j in range(int(o_cnt[0])):
+            nid = names[int(o_ids[0, j])]
+            res.append({
+                "note_id": nid,
+                "scores": {k: dicts[si].get(nid) for si, k in enumerate(_SOURCES)},
+                "final_similarity": float(o_fin[0, j]),
+                "tags": {"source": "graph" if nid in dicts[2] else "semantic", "is_bridge": nid in dicts[3]},
+            })
+        return res
+
+    def fuse_arrays(self, nq: int, dense=None, bm25=None, graph=None, path=None, note_ids: Sequence[Any] | None = None,
+                    want_stats: bool = False):
+        """EXTENSION (same arithmetic, integer ids): batch fusion where a source is either a ``DeviceArray`` [nq, N]
+        (the score of EVERY note 0..N-1, e.g. ``DeviceBM25.scores_device``) or, per query, a short
+        ``(ids, scores)`` pair (e.g. the dense top-k of ``VectorIndex``).  Returns the reference's list of result
+        dicts per query (``note_id`` = ``note_ids[i]`` when given, else the integer id)."""
+        if not self.enabled:
+            return [[] for _ in range(nq)]
+        pool = int(self.candidate_pool)
+        if pool <= 0 or nq == 0:
+            return [[] for _ in range(nq)]
+        out = fuse_dense(self.fusion_method, self.weights, float(self.rrf_k), pool, nq,
+                         {"dense": dense, "bm25": bm25, "graph": graph, "path": path}, device=self.device,
+                         want_stats=want_stats)
+        o_ids, o_fin, o_src, o_cnt = out[:4]
+        results = []
+        ids_l, fin_l = o_ids.tolist(), o_fin.tolist()
+        src_l = np.where(np.isnan(o_src), None, o_src.astype(object)).tolist()
+        for qi in range(nq):
+            res = []
+            for j in range(int(o_cnt[qi])):
+                i = ids_l[qi][j]
+                sc = src_l[qi][j]
+                res.append({"note_id": note_ids[i] if note_ids is not None else i,
+                            "scores": dict(zip(_SOURCES, sc)),
+                            "final_similarity": fin_l[qi][j],
+                            "tags": {"source": "graph" if sc[2] is not None else "semantic",
+                                     "is_bridge": sc[3] is not None}})
+            results.append(res)
+        return (results, out[4]) if want_stats else results
 
 
 def create_hybrid_searcher(config: Dict[str, Any]) -> HybridSearcher:

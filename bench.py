@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--no-facade", action="store_true", help="skip the VectorIndex.search (host in, dicts out) leg")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsal)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal on one GPU: run the N > 1 pipeline (process group, all-gather, merge) with world size 1")
     return ap.parse_args()
 
 
@@ -190,9 +192,11 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     dist = None
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
         import torch.distributed as dist  # noqa: F811
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.one_device:
             local_rank = 0
@@ -236,7 +240,7 @@ def main():
     Pl = [torch.empty(nres * 12, device=dev, dtype=torch.uint8) for _ in range(NSLOT)]
     Dl = [p[: nres * 4].view(torch.float32).view(args.batch, args.k) for p in Pl]
     Il = [p[nres * 4:].view(torch.int64).view(args.batch, args.k) for p in Pl]
-    if world > 1:
+    if dist_on:
         from anorag_hip._lib import OPT_ID_OFFSET
         idx.set_option(OPT_ID_OFFSET, row0)  # the shard returns global ids (no -1 padding: every shard holds >= k rows)
         Pg = [torch.empty(world * nres * 12, device=dev, dtype=torch.uint8) for _ in range(NSLOT)]
@@ -274,7 +278,7 @@ def main():
         s = i % NSLOT
         idx.search_device_async(Q[i].data_ptr(), args.batch, args.k, Dl[s].data_ptr(), Il[s].data_ptr(),
                                 streams[s].cuda_stream)
-        if world > 1:
+        if dist_on:
             pending.append(i)
             if len(pending) > LAG:
                 exchange(pending.pop(0))
@@ -291,7 +295,7 @@ def main():
         step(i)
     finish()
     idx.reset_stats()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -299,14 +303,14 @@ def main():
         step(i)
     finish()
     Dres, Ires = merged["last"]
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     st_all = idx.last_stats()
     scan_ms, scan_bytes = st_all["scan_ms"], st_all["scan_bytes"]
     n_fallback, n_cand = st_all["n_fallback"], st_all["n_candidates"]
-    if world > 1:
+    if dist_on:
         t = torch.tensor([dt], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -324,7 +328,7 @@ def main():
                 yield xb.cpu().numpy()
 
         part = oracle_partial_topk(args, shards, qh, row0)
-        if world > 1:
+        if dist_on:
             parts = [None] * world
             dist.all_gather_object(parts, part)
         else:
@@ -386,7 +390,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, world)
         print(json.dumps(out), flush=True)
     idx.close()
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

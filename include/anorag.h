@@ -38,6 +38,12 @@ const char *anr_version(void);
 /* number of visible HIP devices (0 when there is none); never fails */
 int anr_device_count(void);
 
+/* Device buffers for callers that hold no GPU runtime of their own (the Python classes pass the array sources of
+ * anr_fuse_dense / the output of anr_bm25_scores_dev this way).  kind: 0 host->device, 1 device->host, 2 device->device. */
+int anr_device_malloc(int32_t device, int64_t bytes, void **out);
+int anr_device_free(int32_t device, void *ptr);
+int anr_device_copy(int32_t device, void *dst, const void *src, int64_t bytes, int32_t kind);
+
 /* ------------------------------------------------------------------------------------------------
  * Exact flat index: replaces faiss.IndexFlatIP / IndexFlatL2 as used by
  * vector_store/vector_index.py:77-80 (create), :187-196 (add), :223 (search), :415-426 (reset).
@@ -166,6 +172,33 @@ int anr_fuse_lists(int32_t device, int32_t method, int64_t nq, const int64_t *id
                    const int64_t *offs, const double *weights /*[4]*/, double rrf_k, int32_t pool,
                    int64_t *out_ids, double *out_final, double *out_src, int32_t *out_count);
 
+/* N-array form of the same fusion (BASELINE.json north_star: "fused elementwise+argk kernel"): a source may be the
+ * full-corpus score vector that bm25_scores() returns (utils/bm25_search.py:286-340: one score per note, N of them,
+ * zeros included) instead of a short list.  An ARRAY source is a device buffer [nq][array_len] and stands for the list
+ * [(0, a[0]), (1, a[1]), ...]: every id < array_len is present (NaN marks an absent id), list order = id order.  The
+ * other sources are short (id, score) lists in host memory (list_offs [nq + 1], at most 1024 entries per query in
+ * all) or absent (all pointers NULL).  linear: any of the four sources may be arrays; rrf: exactly one of
+ * dense / bm25 / graph (every id's exact rank among all N entries is counted in the streaming pass; no sort).
+ * Outputs as anr_fuse_lists, bit-identical to it on the equivalent lists; pool <= 1024.  Ties in `final`: rrf —
+ * the reference's ranks-dict insertion order; linear — lower id first (the reference iterates a set there). */
+typedef struct anr_fuse_source {
+  const void *array_dev;     /* device [nq][array_len], or NULL                  */
+  int64_t array_len;
+  int32_t array_dtype;       /* 0 = float64, 1 = float32                          */
+  const int64_t *list_ids;   /* host, concatenated over the queries, or NULL      */
+  const double *list_scores;
+  const int64_t *list_offs;  /* host [nq + 1], or NULL                            */
+} anr_fuse_source;
+typedef struct anr_fuse_dense_stats {
+  int64_t n_queries;
+  int64_t scan_bytes;        /* algorithmic bytes of the streaming pass: sum of array_len * sizeof(element) per query */
+  int64_t n_candidates;      /* ids the streaming pass kept, summed over queries                                    */
+  float scan_ms;             /* HIP-event time of the streaming kernels (max pass + scan) over all sub-batches       */
+} anr_fuse_dense_stats;
+int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const anr_fuse_source *sources /*[4]*/,
+                   const double *weights /*[4]*/, double rrf_k, int32_t pool, int64_t *out_ids, double *out_final,
+                   double *out_src, int32_t *out_count, anr_fuse_dense_stats *stats /* may be NULL */);
+
 /* ------------------------------------------------------------------------------------------------
  * Sentence encoder: replaces SentenceTransformer.encode as called at
  * vector_store/embedding_manager.py:392-399 (and :357) — transformer forward + pooling + optional L2
@@ -211,6 +244,10 @@ int anr_bm25_destroy(anr_bm25 *h);
  * tokens are simply omitted).  out_host: dense [nq][n_docs] float64. */
 int anr_bm25_scores(anr_bm25 *h, int64_t nq, const int64_t *q_indptr, const int32_t *q_terms, int32_t normalize,
                     double *out_host);
+/* the same scores left in DEVICE memory ([nq][n_docs] float64, caller-allocated on the handle's device): the array
+ * source anr_fuse_dense takes — the N-vector never crosses PCIe */
+int anr_bm25_scores_dev(anr_bm25 *h, int64_t nq, const int64_t *q_indptr, const int32_t *q_terms, int32_t normalize,
+                        double *out_dev);
 /* sparse form for the fusion: the documents with a non-zero score, unordered; out_count may exceed cap
  * (the lists are then truncated) */
 int anr_bm25_nonzero(anr_bm25 *h, int64_t nq, const int64_t *q_indptr, const int32_t *q_terms, int32_t normalize,

@@ -8,10 +8,10 @@ CPU restatement of the graph layer's two dense scans:
   * ``find_embedding_candidates``        follows ``GraphRetriever._find_embedding_candidates``
                                          (graph/graph_retriever.py:153-170) up to the index → note-id mapping.
 
-PINNED: tests/test_oracle_golden.py checks the first three against tests/golden/similarity_relation_cases.json,
-which tests/golden/make_golden.py produced by running the reference's own relation_extractor.py.
-``find_embedding_candidates`` is unpinned (graph_retriever.py needs networkx, absent here); it is five lines
-of numpy restated as they stand.
+PINNED: tests/test_oracle_golden.py checks the first three against tests/golden/similarity_relation_cases.json and
+``find_embedding_candidates`` against tests/golden/embedding_candidates_cases.json, both produced by
+tests/golden/make_golden.py running the reference's own relation_extractor.py / graph_retriever.py (their
+package-level imports satisfied by stand-in modules; networkx is installed).
 """
 from __future__ import annotations
 

@@ -8,6 +8,11 @@ Imports, by file path, the two reference files of the hot path that are importab
 stub, the same sys.modules technique the reference's own tests use for GPUtil).  Writes
   tests/golden/fusion_cases.json   inputs + the reference's HybridSearcher.fuse output
   tests/golden/bm25_cases.json     notes + queries + the reference's bm25_scores output (SimpleBM25 variant)
+  tests/golden/fusion_long_cases.json   HybridSearcher.fuse where bm25 (and, in some cases, dense) is a FULL-corpus
+      list — one (id, score) entry per note, what zipping the note ids with bm25_scores() gives — with integer note
+      ids; the long lists are stored sparsely (non-zero entries + the value every other entry has)
+  tests/golden/embedding_candidates_cases.json   GraphRetriever._find_embedding_candidates
+      (graph/graph_retriever.py:153-170), with `graph.graph_index` / `config` satisfied by stand-in modules
   tests/golden/similarity_relation_cases.json   embeddings + the reference's semantic-similarity relations
       (graph/relation_extractor.py:591-629, 769-791).  That file's module-level imports (`utils`, `config`) pull
       in packages that are absent here; the three methods used are pure numpy, so the two names are satisfied by
@@ -105,6 +110,101 @@ def fusion_cases(hs):
     return cases
 
 
+def fusion_long_cases(hs):
+    """full-corpus bm25 vectors (N entries, mostly zero) fused with a dense top-100, small graph / path lists"""
+    import numpy as np
+    rng = np.random.default_rng(20261004)
+    weights = {"dense": 1.0, "bm25": 0.5, "graph": 0.5, "path": 0.1}
+    cases = []
+
+    def sparse_vec(n, frac, ties=False, fill=0.0, normalise=True):
+        v = np.full(n, fill, dtype=np.float64)
+        nz = rng.choice(n, size=max(1, int(n * frac)), replace=False)
+        vals = np.abs(rng.standard_normal(len(nz)))
+        if ties:
+            vals = np.round(vals, 1)
+        if normalise and vals.max() > 0:
+            vals = vals / vals.max()          # bm25_scores divides by the maximum (bm25_search.py:329-333)
+        v[nz] = vals
+        return v
+
+    def pairs(n_total, m, lo=0.0, hi=1.0, ties=False):
+        ids = rng.choice(n_total, size=m, replace=False)
+        sc = rng.uniform(lo, hi, m)
+        if ties:
+            sc = np.round(sc, 1)
+        order = np.argsort(-sc, kind="stable")
+        return [[int(i), float(s)] for i, s in zip(ids[order], sc[order])]
+
+    def add(name, method, n, bm25_vec, dense, graph, path, dense_vec=None, pool=80, rrf_k=60, w=weights):
+        cfg = {"retrieval": {"candidate_pool": pool,
+                             "hybrid": {"enabled": True, "fusion_method": method, "weights": w, "rrf_k": rrf_k}}}
+        searcher = hs.HybridSearcher(cfg)
+        bm25 = [(i, float(bm25_vec[i])) for i in range(n)] if bm25_vec is not None else None
+        d = [(i, float(dense_vec[i])) for i in range(n)] if dense_vec is not None else [tuple(x) for x in dense]
+        out = searcher.fuse(dense=d, bm25=bm25, graph=[tuple(x) for x in graph], path=[tuple(x) for x in path])
+
+        def pack(vec):
+            if vec is None:
+                return None
+            vals, counts = np.unique(vec, return_counts=True)
+            fill = float(vals[np.argmax(counts)])
+            nz = np.nonzero(vec != fill)[0]
+            return {"n": int(n), "fill": fill, "idx": [int(i) for i in nz], "val": [float(vec[i]) for i in nz]}
+
+        cases.append({"name": name, "config": cfg, "n": int(n), "bm25_vec": pack(bm25_vec), "dense_vec": pack(dense_vec),
+                      "dense": dense if dense_vec is None else None, "graph": graph, "path": path, "expected": out})
+
+    for method in ("linear", "rrf"):
+        for t, (n, frac) in enumerate([(20_000, 0.004), (50_000, 0.001), (9_000, 0.02)]):
+            add(f"{method}_bm25_full_{t}", method, n, sparse_vec(n, frac), pairs(n, 100, 0.2, 0.9),
+                pairs(n, int(rng.integers(0, 30))), pairs(n, int(rng.integers(0, 10))),
+                pool=int(rng.choice([10, 50, 80])), rrf_k=int(rng.choice([1, 60])))
+        n = 12_000
+        add(f"{method}_bm25_ties", method, n, sparse_vec(n, 0.02, ties=True, normalise=False),
+            pairs(n, 100, 0.0, 1.0, ties=True), pairs(n, 20, ties=True), pairs(n, 8, ties=True), pool=120)
+        add(f"{method}_bm25_all_zero", method, n, np.zeros(n), pairs(n, 50, 0.1, 0.8), [], [], pool=60)
+        add(f"{method}_bm25_dense_overlap", method, n, sparse_vec(n, 0.01),
+            # dense hits placed on bm25 hits and on the first ids (which win the zero ties)
+            [[int(i), float(s)] for i, s in zip(list(range(0, 40)) + [int(x) for x in rng.choice(n, 60, replace=False)],
+                                                sorted(rng.uniform(0.3, 0.95, 100), reverse=True))],
+            pairs(n, 25), pairs(n, 6), pool=80)
+        add(f"{method}_bm25_negative_fill", method, 8_000, sparse_vec(8_000, 0.01, fill=-0.25, normalise=False),
+            pairs(8_000, 100, -0.5, 0.9), [], pairs(8_000, 5), pool=50)
+    # linear only: two full-length sources (a dense score for EVERY note as well)
+    n = 6_000
+    add("linear_two_full_vectors", "linear", n, sparse_vec(n, 0.01), None, pairs(n, 12), pairs(n, 4),
+        dense_vec=rng.uniform(-0.2, 0.9, n), pool=80)
+    return cases
+
+
+def embedding_candidate_cases(gr):
+    import numpy as np
+    rng = np.random.default_rng(20261005)
+    cases = []
+    for t, (n, d, k) in enumerate([(300, 16, 15), (40, 8, 15), (9, 8, 15), (120, 12, 5)]):
+        emb = (rng.standard_normal((n, d)) * rng.uniform(0.5, 2.0, (n, 1))).astype(np.float32)  # un-normalised rows
+        q = rng.standard_normal(d).astype(np.float32)
+        idx = types.SimpleNamespace(graph=None, embeddings=emb,
+                                    note_id_to_index={f"note_{i:04d}": i for i in range(n)})
+        r = gr.GraphRetriever(idx)
+        cases.append({"name": f"case_{t}", "top_k": k, "embeddings": [[float(v) for v in row] for row in emb],
+                      "query": [float(v) for v in q], "expected": r._find_embedding_candidates(q, top_k=k)})
+    return cases
+
+
+def load_graph_retriever():
+    """graph/graph_retriever.py imports `.graph_index` relatively and `config` / loguru / networkx at module level;
+    networkx is installed, the other three are stand-ins (no arithmetic lives in them)"""
+    pkg = types.ModuleType("graph")
+    pkg.__path__ = [os.path.join(REF, "graph")]
+    sys.modules["graph"] = pkg
+    gi = types.ModuleType("graph.graph_index")
+    gi.GraphIndex = type("GraphIndex", (), {})
+    sys.modules["graph.graph_index"] = gi
+    return load_by_path("graph.graph_retriever", os.path.join(REF, "graph", "graph_retriever.py"))
+
+
 def bm25_cases(bm):
     rng = random.Random(7)
     vocab = [f"w{i}" for i in range(300)] + ["natural", "language", "processing", "machine", "learning", "AI"]
@@ -197,12 +297,20 @@ def main():
     with open(os.path.join(HERE, "bm25_cases.json"), "w") as f:
         json.dump({"source": "reference utils/bm25_search.py build_bm25_corpus + bm25_scores (SimpleBM25)",
                    "cases": bm25_cases(bm)}, f)
+    with open(os.path.join(HERE, "fusion_long_cases.json"), "w") as f:
+        json.dump({"source": "reference retrieval/hybrid_search.py HybridSearcher.fuse, full-corpus bm25 lists",
+                   "cases": fusion_long_cases(hs)}, f)
     stub_utils_and_config()
+    gr = load_graph_retriever()
+    with open(os.path.join(HERE, "embedding_candidates_cases.json"), "w") as f:
+        json.dump({"source": "reference graph/graph_retriever.py GraphRetriever._find_embedding_candidates",
+                   "cases": embedding_candidate_cases(gr)}, f)
     rx = load_by_path("ref_relation_extractor", os.path.join(REF, "graph", "relation_extractor.py"))
     with open(os.path.join(HERE, "similarity_relation_cases.json"), "w") as f:
         json.dump({"source": "reference graph/relation_extractor.py extract_semantic_similarity_relations",
                    "cases": similarity_cases(rx)}, f)
-    print("wrote fusion_cases.json, bm25_cases.json, similarity_relation_cases.json")
+    print("wrote fusion_cases.json, fusion_long_cases.json, bm25_cases.json, embedding_candidates_cases.json, "
+          "similarity_relation_cases.json")
 
 
 if __name__ == "__main__":

@@ -77,10 +77,18 @@ def test_fuse_batch_random_vs_oracle(method):
         _compare(g, exp, 80, method)
 
 
-def test_fuse_rejects_oversized_lists():
-    from anorag_hip import AnoragError
+def test_fuse_accepts_lists_beyond_the_lds_kernel():
+    """more than 4096 entries in one query: the reference takes lists of any length, so does the drop-in (the long
+    source is streamed as a device array, anr_fuse_dense) — in one batch with a short query"""
     from retrieval.hybrid_search import HybridSearcher
-    hs = HybridSearcher({"retrieval": {"hybrid": {"weights": {"dense": 1.0}}}})
-    big = [(i, 1.0) for i in range(5000)]
-    with pytest.raises(AnoragError):
-        hs.fuse(dense=big)
+    cfg = {"retrieval": {"candidate_pool": 30, "hybrid": {"enabled": True, "fusion_method": "linear",
+                                                         "weights": {"dense": 1.0, "bm25": 0.5}}}}
+    hs = HybridSearcher(cfg)
+    rng = np.random.default_rng(1)
+    big = [(f"n{i}", float(s)) for i, s in enumerate(rng.uniform(0, 1, 5000))]
+    bm = [(f"n{int(i)}", float(s)) for i, s in zip(rng.choice(6000, 300, replace=False), rng.uniform(0, 3, 300))]
+    small = ([("a", 0.5), ("b", 0.25)], [("b", 2.0)], None, None)
+    got = hs.fuse_batch([(big, bm, None, None), small])
+    exp = ofu.fuse(big, bm, candidate_pool=30, fusion_method="linear", weights=hs.weights)
+    _compare(got[0], exp, 30, "linear")
+    _compare(got[1], ofu.fuse(*small, candidate_pool=30, fusion_method="linear", weights=hs.weights), 30, "linear")

@@ -106,3 +106,17 @@ def test_find_embedding_candidates_matches_oracle():
     exp = og.find_embedding_candidates(emb, q, 15)
     assert np.array_equal(got, exp)
     assert len(find_embedding_candidates(emb[:7], q, 15)) == 7      # fewer rows than top_k
+
+
+def test_find_embedding_candidates_matches_reference_golden():
+    """golden vectors produced by the reference's own GraphRetriever._find_embedding_candidates
+    (graph/graph_retriever.py:153-170; tests/golden/make_golden.py)"""
+    import json
+    import os
+    from anorag_hip.graph_scans import find_embedding_candidates
+    with open(os.path.join(os.path.dirname(__file__), "golden", "embedding_candidates_cases.json")) as f:
+        cases = json.load(f)["cases"]
+    for c in cases:
+        emb = np.asarray(c["embeddings"], dtype=np.float32)
+        got = find_embedding_candidates(emb, np.asarray(c["query"], dtype=np.float32), c["top_k"])
+        assert [f"note_{int(i):04d}" for i in got] == c["expected"], c["name"]

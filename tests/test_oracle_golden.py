@@ -122,3 +122,44 @@ def test_similarity_relations_oracle_matches_reference_golden():
             assert g["metadata"]["cosine_similarity"] == e["cosine_similarity"], case["name"]
             assert float(g["weight"]) == e["weight"], case["name"]
             assert g["metadata"]["similarity_rank"] == e["similarity_rank"], case["name"]
+
+
+def _unpack_vec(v):
+    a = np.full(v["n"], v["fill"], dtype=np.float64)
+    a[v["idx"]] = v["val"]
+    return a
+
+
+@pytest.mark.parametrize("case", _load("fusion_long_cases.json"), ids=lambda c: c["name"])
+def test_fusion_oracle_matches_reference_on_full_corpus_lists(case):
+    """the N-entry bm25 lists (one entry per note): both oracle forms against the reference's own output"""
+    h = case["config"]["retrieval"]["hybrid"]
+    pool, n = case["config"]["retrieval"]["candidate_pool"], case["n"]
+    bm = _unpack_vec(case["bm25_vec"]) if case["bm25_vec"] else None
+    dv = _unpack_vec(case["dense_vec"]) if case["dense_vec"] else None
+    dense = [(i, float(dv[i])) for i in range(n)] if dv is not None else _tup(case["dense"])
+    bm25 = [(i, float(bm[i])) for i in range(n)] if bm is not None else None
+    got = ofu.fuse(dense, bm25, _tup(case["graph"]), _tup(case["path"]), candidate_pool=pool,
+                   fusion_method=h["fusion_method"], weights=h["weights"], rrf_k=h["rrf_k"])
+    exp = case["expected"]
+    assert [r["final_similarity"] for r in got] == [r["final_similarity"] for r in exp]
+    if h["fusion_method"] == "rrf":
+        assert [r["note_id"] for r in got] == [r["note_id"] for r in exp]
+
+    def arr(lst):
+        return (np.array([p[0] for p in lst], dtype=np.int64), np.array([p[1] for p in lst], dtype=np.float64))
+    ids, fin = ofu.fuse_arrays(n, (arr(dense), arr(bm25) if bm25 else None, arr(case["graph"]), arr(case["path"])),
+                               [h["weights"].get(k, 0.0) for k in ("dense", "bm25", "graph", "path")],
+                               h["fusion_method"], h["rrf_k"], pool)
+    assert fin.tolist() == [r["final_similarity"] for r in exp]
+    if h["fusion_method"] == "rrf":
+        assert ids.tolist() == [r["note_id"] for r in exp]
+
+
+@pytest.mark.parametrize("case", _load("embedding_candidates_cases.json"), ids=lambda c: c["name"])
+def test_embedding_candidates_oracle_matches_reference_golden(case):
+    from oracle import graph_scans as og
+    emb = np.asarray(case["embeddings"], dtype=np.float32)
+    q = np.asarray(case["query"], dtype=np.float32)
+    got = og.find_embedding_candidates(emb, q, case["top_k"])
+    assert [f"note_{int(i):04d}" for i in got] == case["expected"]

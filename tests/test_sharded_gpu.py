@@ -150,10 +150,10 @@ def test_clustered_shards_failed_certificates_are_final_before_the_merge():
     P, per, dim, B, k = 8, 160_000, 768, 64, 100
     g = torch.Generator(device=dev)
     g.manual_seed(99)
-    cent = torch.randn((2560, dim), generator=g, device=dev)  # ~500 rows per cluster
+    cent = torch.randn((320, dim), generator=g, device=dev)  # ~500 rows per cluster in every shard: more than K'
     kw = dict(centroids=cent, sigma=0.02)
     shards = _build_shards(P, per, dim, dev, 7000, **kw)
-    Q = cent[torch.randint(0, 2560, (4, B), generator=g, device=dev)] + 0.02 * torch.randn((4, B, dim), generator=g, device=dev)
+    Q = cent[torch.randint(0, 320, (4, B), generator=g, device=dev)] + 0.02 * torch.randn((4, B, dim), generator=g, device=dev)
     out = _pipeline(shards, Q, B, k, dev)
     stats = [sh.last_stats() for sh in shards]
     assert sum(s["n_fallback"] for s in stats) > 0, stats  # the case this test exists for
