@@ -90,6 +90,7 @@ SIGNATURES = {
     "anr_index_reset": (C.c_int, [C.c_void_p]),
     "anr_index_reconstruct": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "anr_index_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "anr_index_search_devq": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "anr_index_search_dev": (
         C.c_int,
         [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],
@@ -147,6 +148,10 @@ SIGNATURES = {
     "anr_encoder_forward": (
         C.c_int,
         [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p],
+    ),
+    "anr_encoder_forward_dev": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p],
     ),
 }
 

@@ -224,6 +224,23 @@ class DeviceEncoder:
                                                  out.ctypes.data_as(C.c_void_p)), "anr_encoder_forward")
         return out
 
+    def forward_device(self, ids: np.ndarray, lengths: np.ndarray, type_ids: Optional[np.ndarray], normalize: bool,
+                       out_ptr: int, out_rows: Optional[np.ndarray] = None) -> None:
+        """the same forward, sequence b written to row out_rows[b] of the float32 [*, hidden] DEVICE buffer at out_ptr"""
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        lengths = np.ascontiguousarray(lengths, dtype=np.int32)
+        B, L = ids.shape
+        tp = rows = None
+        if type_ids is not None:
+            type_ids = np.ascontiguousarray(type_ids, dtype=np.int32)
+            tp = type_ids.ctypes.data_as(C.c_void_p)
+        if out_rows is not None:
+            out_rows = np.ascontiguousarray(out_rows, dtype=np.int32)
+            rows = out_rows.ctypes.data_as(C.c_void_p)
+        _lib.check(self._lib.anr_encoder_forward_dev(self._h, ids.ctypes.data_as(C.c_void_p),
+                                                     lengths.ctypes.data_as(C.c_void_p), tp, B, L, int(bool(normalize)),
+                                                     C.c_void_p(out_ptr), rows), "anr_encoder_forward_dev")
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.anr_encoder_destroy(self._h)
@@ -269,6 +286,24 @@ class SentenceEncoder:
             types[i, :lens[i]] = e.type_ids
         return ids, lens, types
 
+    def _batches(self, sentences, batch_size):
+        """length-sorted batches (longest first, as SentenceTransformer.encode), tokenised one batch AHEAD on a worker
+        thread: the tokenizer (Rust, releases the GIL) prepares batch i + 1 while the device runs the forward of
+        batch i (the ctypes call releases the GIL as well)"""
+        from concurrent.futures import ThreadPoolExecutor
+        n = len(sentences)
+        order = np.argsort([-len(s) for s in sentences], kind="stable")
+        sels = [order[s:s + batch_size] for s in range(0, n, batch_size)]
+        if not sels:
+            return
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            nxt = pool.submit(self.tokenize, [sentences[i] for i in sels[0]])
+            for bi, sel in enumerate(sels):
+                cur = nxt.result()
+                if bi + 1 < len(sels):
+                    nxt = pool.submit(self.tokenize, [sentences[i] for i in sels[bi + 1]])
+                yield sel, cur
+
     def encode(self, sentences, batch_size: int = 32, show_progress_bar: bool = False, convert_to_numpy: bool = True,
                normalize_embeddings: bool = False, device=None, **_):
         single = isinstance(sentences, str)
@@ -276,14 +311,23 @@ class SentenceEncoder:
             sentences = [sentences]
         n = len(sentences)
         out = np.zeros((n, self._enc.hidden), dtype=np.float32)
-        order = np.argsort([-len(s) for s in sentences], kind="stable")
         want_norm = bool(normalize_embeddings) or self._info["normalize_module"]
         use_types = self._info["hf"].get("type_vocab_size", 1) > 1
-        for s in range(0, n, batch_size):
-            sel = order[s:s + batch_size]
-            ids, lens, types = self.tokenize([sentences[i] for i in sel])
+        for sel, (ids, lens, types) in self._batches(sentences, batch_size):
             out[sel] = self._enc.forward(ids, lens, types if use_types else None, normalize=want_norm)
         return out[0] if single else out
+
+    def encode_device(self, sentences, batch_size: int = 32, normalize_embeddings: bool = False):
+        """``encode`` with the [n, hidden] float32 result left on the device (an ``anorag_hip.fusion.DeviceArray``, rows
+        in input order): what ``FlatIndex.add_device`` / ``search_device`` consume — no host round trip per batch"""
+        from .fusion import DeviceArray
+        n = len(sentences)
+        out = DeviceArray(n, self._enc.hidden, np.float32, self.device)
+        want_norm = bool(normalize_embeddings) or self._info["normalize_module"]
+        use_types = self._info["hf"].get("type_vocab_size", 1) > 1
+        for sel, (ids, lens, types) in self._batches(sentences, batch_size):
+            self._enc.forward_device(ids, lens, types if use_types else None, want_norm, out.ptr, out_rows=sel)
+        return out
 
     def close(self):
         self._enc.close()

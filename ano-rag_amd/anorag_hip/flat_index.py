@@ -123,6 +123,16 @@ class FlatIndex:
         _lib.check(self._lib.anr_index_add_dev(self._h, C.c_void_p(x_ptr), int(n), C.c_void_p(stream)),
                    "anr_index_add_dev")
 
+    def search_device_queries(self, q_ptr: int, nq: int, k: int):
+        """queries in device memory (float32 [nq, d] at q_ptr, e.g. ``SentenceEncoder.encode_device``), results as
+        numpy arrays"""
+        D = np.empty((nq, k), dtype=np.float32)
+        I = np.empty((nq, k), dtype=np.int64)
+        _lib.check(self._lib.anr_index_search_devq(self._h, C.c_void_p(q_ptr), int(nq), int(k),
+                                                   D.ctypes.data_as(C.c_void_p), I.ctypes.data_as(C.c_void_p)),
+                   "anr_index_search_devq")
+        return D, I
+
     def search_device(self, q_ptr: int, nq: int, k: int, d_ptr: int, i_ptr: int, stream: int = 0) -> None:
         _lib.check(
             self._lib.anr_index_search_dev(self._h, C.c_void_p(q_ptr), int(nq), int(k), C.c_void_p(d_ptr),

@@ -787,13 +787,15 @@ struct PoolParams {
   const float *res;  // final LayerNorm output, blocked f32
   const int *lens;
   int B, Lp, H, KB, pooling, normalize;
-  float *out;  // [B][H] row-major
+  float *out;           // [rows][H] row-major
+  const int *out_rows;  // optional [B]: sequence b is written to row out_rows[b] (else row b)
 };
 
 __global__ __launch_bounds__(256) void k_pool(PoolParams p) {
   __shared__ float s_red[4];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int len = p.lens[b];
+  float *orow = p.out + (int64_t)(p.out_rows ? p.out_rows[b] : b) * p.H;
   float ss = 0.f;
   for (int f = tid; f < p.H; f += 256) {
     const int kb = f / 16, off = f % 16, g = off / 8, hh = (off % 8) / 4, jj = off % 4, j = g * 4 + jj;
@@ -805,7 +807,7 @@ __global__ __launch_bounds__(256) void k_pool(PoolParams p) {
     }
     // sentence-transformers: sum / clamp(mask_sum, 1e-9)
     const float v = p.pooling == 1 ? acc : acc / fmaxf((float)len, 1e-9f);
-    p.out[(int64_t)b * p.H + f] = v;
+    orow[f] = v;
     ss += v * v;
   }
   if (p.normalize) {
@@ -814,7 +816,7 @@ __global__ __launch_bounds__(256) void k_pool(PoolParams p) {
     __syncthreads();
     // torch.nn.functional.normalize: x / max(||x||, 1e-12)
     const float nrm = fmaxf(sqrtf(s_red[0] + s_red[1] + s_red[2] + s_red[3]), 1e-12f);
-    for (int f = tid; f < p.H; f += 256) p.out[(int64_t)b * p.H + f] /= nrm;
+    for (int f = tid; f < p.H; f += 256) orow[f] /= nrm;
   }
 }
 
@@ -844,7 +846,7 @@ struct anr_encoder {
   bool finalized = false;
   // workspace
   int64_t ws_tokens = 0;
-  int *d_ids = nullptr, *d_types = nullptr, *d_lens = nullptr;
+  int *d_ids = nullptr, *d_types = nullptr, *d_lens = nullptr, *d_rows = nullptr;
   int64_t ws_b = 0, ws_bl = 0;
   float *res = nullptr, *res2 = nullptr, *out = nullptr;
   _Float16 *act = nullptr, *qk = nullptr, *vt = nullptr, *ctx = nullptr, *ffn = nullptr;
@@ -980,8 +982,10 @@ int ensure_ws(anr_encoder *e, int B, int L, int Lp) {
   }
   if (B > e->ws_b) {
     enc_free(e->d_lens);
+    enc_free(e->d_rows);
     enc_free(e->out);
     ANR_TRY(enc_alloc(&e->d_lens, B));
+    ANR_TRY(enc_alloc(&e->d_rows, B));
     ANR_TRY(enc_alloc(&e->out, (int64_t)B * c.hidden));
     e->ws_b = B;
   }
@@ -1039,7 +1043,7 @@ int anr_encoder_destroy(anr_encoder *e) {
     enc_free(l.bqk); enc_free(l.bv); enc_free(l.bo); enc_free(l.b1); enc_free(l.b2);
     enc_free(l.ln1g); enc_free(l.ln1b); enc_free(l.ln2g); enc_free(l.ln2b);
   }
-  enc_free(e->d_ids); enc_free(e->d_types); enc_free(e->d_lens);
+  enc_free(e->d_ids); enc_free(e->d_types); enc_free(e->d_lens); enc_free(e->d_rows);
   enc_free(e->res); enc_free(e->res2); enc_free(e->out);
   enc_free(e->act); enc_free(e->qk); enc_free(e->vt); enc_free(e->ctx); enc_free(e->ffn);
   if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -1111,9 +1115,13 @@ int anr_encoder_finalize(anr_encoder *e) {
   return ANR_OK;
 }
 
-int anr_encoder_forward(anr_encoder *e, const int32_t *ids, const int32_t *lengths, const int32_t *type_ids, int32_t B,
-                        int32_t L, int32_t normalize, float *out_host) {
-  if (!e || !ids || !lengths || !out_host) return fail(ANR_EINVAL, "null argument");
+}  // extern "C"
+
+namespace {
+// out_host: [B][hidden] host memory; or out_dev: device memory, sequence b written to row out_rows[b] (host [B], or row b)
+int forward_impl(anr_encoder *e, const int32_t *ids, const int32_t *lengths, const int32_t *type_ids, int32_t B,
+                 int32_t L, int32_t normalize, float *out_host, float *out_dev, const int32_t *out_rows) {
+  if (!e || !ids || !lengths || (!out_host && !out_dev)) return fail(ANR_EINVAL, "null argument");
   if (B <= 0 || L <= 0) return fail(ANR_EINVAL, "B and L must be positive");
   const auto &c = e->cfg;
   if (L + c.pos_offset > c.max_positions) return fail(ANR_EINVAL, "sequence length %d exceeds the position table", L);
@@ -1133,6 +1141,7 @@ int anr_encoder_forward(anr_encoder *e, const int32_t *ids, const int32_t *lengt
   ANR_HIP(hipMemcpyAsync(e->d_ids, ids, (size_t)B * L * sizeof(int), hipMemcpyHostToDevice, st));
   if (type_ids) ANR_HIP(hipMemcpyAsync(e->d_types, type_ids, (size_t)B * L * sizeof(int), hipMemcpyHostToDevice, st));
   ANR_HIP(hipMemcpyAsync(e->d_lens, lengths, (size_t)B * sizeof(int), hipMemcpyHostToDevice, st));
+  if (out_dev && out_rows) ANR_HIP(hipMemcpyAsync(e->d_rows, out_rows, (size_t)B * sizeof(int), hipMemcpyHostToDevice, st));
   const int H = c.hidden, I = c.intermediate, KB = H / 16;
   const int64_t TB = (int64_t)B * Lp / 32;
 
@@ -1183,12 +1192,31 @@ int anr_encoder_forward(anr_encoder *e, const int32_t *ids, const int32_t *lengt
     LnParams l2{e->res2, TB, H, KB, l.ln2g, l.ln2b, c.ln_eps, e->res, e->act};
     launch_layernorm(l2, st);
   }
-  PoolParams pp{e->res, e->d_lens, B, Lp, H, KB, c.pooling, normalize ? 1 : 0, e->out};
+  PoolParams pp{e->res, e->d_lens, B, Lp, H, KB, c.pooling, normalize ? 1 : 0, out_dev ? out_dev : e->out,
+                (out_dev && out_rows) ? e->d_rows : nullptr};
   hipLaunchKernelGGL(k_pool, dim3(B), dim3(256), 0, st, pp);
   ANR_HIP(hipGetLastError());
-  ANR_HIP(hipMemcpyAsync(out_host, e->out, (size_t)B * H * sizeof(float), hipMemcpyDeviceToHost, st));
+  if (out_host) ANR_HIP(hipMemcpyAsync(out_host, e->out, (size_t)B * H * sizeof(float), hipMemcpyDeviceToHost, st));
   ANR_HIP(hipStreamSynchronize(st));
   return ANR_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int anr_encoder_forward(anr_encoder *e, const int32_t *ids, const int32_t *lengths, const int32_t *type_ids, int32_t B,
+                        int32_t L, int32_t normalize, float *out_host) {
+  if (!out_host) return fail(ANR_EINVAL, "null argument");
+  return forward_impl(e, ids, lengths, type_ids, B, L, normalize, out_host, nullptr, nullptr);
+}
+
+int anr_encoder_forward_dev(anr_encoder *e, const int32_t *ids, const int32_t *lengths, const int32_t *type_ids, int32_t B,
+                            int32_t L, int32_t normalize, float *out_dev, const int32_t *out_rows) {
+  if (!out_dev) return fail(ANR_EINVAL, "null argument");
+  if (out_rows)
+    for (int b = 0; b < B; ++b)
+      if (out_rows[b] < 0) return fail(ANR_EINVAL, "out_rows[%d] is negative", b);
+  return forward_impl(e, ids, lengths, type_ids, B, L, normalize, nullptr, out_dev, out_rows);
 }
 
 }  // extern "C"

@@ -113,7 +113,13 @@ int dev_alloc(T **p, int64_t count, bool zero) {
   *p = nullptr;
   if (count <= 0) count = 1;
   ANR_HIP(hipMalloc(reinterpret_cast<void **>(p), (size_t)count * sizeof(T)));
-  if (zero) ANR_HIP(hipMemset(*p, 0, (size_t)count * sizeof(T)));
+  if (zero) {
+    // hipMemset on device memory is asynchronous to the host and runs on the NULL stream, which the handle's
+    // non-blocking streams do not wait for: without the synchronisation a k_add enqueued right after could run
+    // first and have its rows zeroed again
+    ANR_HIP(hipMemset(*p, 0, (size_t)count * sizeof(T)));
+    ANR_HIP(hipStreamSynchronize(nullptr));
+  }
   return ANR_OK;
 }
 
@@ -1051,6 +1057,7 @@ int anr_index_reset(anr_index *h) {
   if (h->x16) ANR_HIP(hipMemset(h->x16, 0, (size_t)h->cap * h->dimp * sizeof(_Float16)));
   if (h->rowbias) ANR_HIP(hipMemset(h->rowbias, 0, (size_t)h->cap * sizeof(float)));
   ANR_HIP(hipMemset(h->xstat, 0, 4 * sizeof(unsigned)));
+  ANR_HIP(hipStreamSynchronize(nullptr));  // the fills run on the NULL stream; later adds use the handle's own
   h->ntotal = 0;
   h->xstat_dirty = true;
   return ANR_OK;
@@ -1068,6 +1075,10 @@ int anr_index_reconstruct(anr_index *h, int64_t i0, int64_t n, float *out_host) 
 
 int anr_index_search(anr_index *h, const float *q_host, int64_t nq, int32_t k, float *D, int64_t *I) {
   return search_impl(h, q_host, true, nq, k, D, I, true, nullptr);
+}
+
+int anr_index_search_devq(anr_index *h, const float *q_dev, int64_t nq, int32_t k, float *D, int64_t *I) {
+  return search_impl(h, q_dev, false, nq, k, D, I, true, nullptr);
 }
 
 int anr_index_search_dev(anr_index *h, const float *q_dev, int64_t nq, int32_t k, float *D_dev, int64_t *I_dev,

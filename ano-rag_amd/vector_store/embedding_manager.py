@@ -155,10 +155,23 @@ class EmbeddingManager:
             logger.error(f"Text encoding failed: {e}")
             return np.zeros((len(texts), self.embedding_dim))  # float64 zeros, as in the reference (:407)
 
+    def encode_texts_device(self, texts: List[str], batch_size: Optional[int] = None, normalize: Optional[bool] = None):
+        """EXTENSION: ``encode_texts`` with the embeddings left in device memory (``anorag_hip.fusion.DeviceArray``
+        [n, D] float32) for ``VectorRetriever`` to hand straight to the index (reference flow
+        vector_store/retriever.py:140-157, :206-216).  Raises on failure instead of returning zeros — the caller falls
+        back to the host-array path."""
+        batch_size = batch_size or self.batch_size
+        normalize = normalize if normalize is not None else self.normalize_embeddings
+        return self.model.encode_device(self._preprocess_texts(texts), batch_size=batch_size,
+                                        normalize_embeddings=normalize)
+
     def encode_atomic_notes(self, atomic_notes: List[Dict[str, Any]], content_field: str = "content",
                             include_metadata: bool = True) -> np.ndarray:
         if not atomic_notes:
             return np.array([])
+        return self.encode_texts(self._assemble_note_texts(atomic_notes, content_field))
+
+    def _assemble_note_texts(self, atomic_notes: List[Dict[str, Any]], content_field: str = "content") -> List[str]:
         strat = (config.get("embedding_strategy", {}) or {}).get("atomic_note_embedding", {})
         text_strategy = strat.get("text_strategy", "title_raw_span")
         priority = strat.get("field_priority", ["title", "raw_span", "original_text", "content"])
@@ -182,7 +195,7 @@ class EmbeddingManager:
                 logger.warning(f"Note text assembly failed: {e}")
                 texts.append("Empty note" if qc.get("skip_invalid_encoding", True)
                              else note.get(content_field, "Empty note"))
-        return self.encode_texts(texts)
+        return texts
 
     def _extract_title_raw_span_text(self, note, field_priority, text_combination) -> str:
         title = note.get("title", "").strip()
@@ -229,6 +242,12 @@ class EmbeddingManager:
         if "bge" in self.model_name.lower() and query_prefix:  # tested against the *path* once loaded (:365, :558)
             queries = [query_prefix + q for q in queries]
         return self.encode_texts(queries)
+
+    def encode_queries_device(self, queries: List[str], query_prefix: str = _QUERY_PREFIX):
+        """EXTENSION: ``encode_queries`` with the embeddings left in device memory (see ``encode_texts_device``)"""
+        if "bge" in self.model_name.lower() and query_prefix:
+            queries = [query_prefix + q for q in queries]
+        return self.encode_texts_device(queries)
 
     def _preprocess_texts(self, texts: List[str]) -> List[str]:
         out = []

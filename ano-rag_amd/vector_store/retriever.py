@@ -121,17 +121,18 @@ class VectorRetriever:
                 return True
             self.atomic_notes = atomic_notes
             self._build_id_mappings()
-            self.note_embeddings = self.embedding_manager.encode_atomic_notes(atomic_notes, include_metadata=True)
-            if self.note_embeddings.size == 0:
-                logger.error("Failed to generate embeddings")
-                return False
-            if not self.vector_index.create_index():
-                logger.error("Failed to create vector index")
-                return False
-            ids = np.arange(len(atomic_notes), dtype=np.int64)
-            if not self.vector_index.add_vectors(self.note_embeddings, ids):
-                logger.error("Failed to add vectors to index")
-                return False
+            if not self._build_device_resident(atomic_notes):
+                self.note_embeddings = self.embedding_manager.encode_atomic_notes(atomic_notes, include_metadata=True)
+                if self.note_embeddings.size == 0:
+                    logger.error("Failed to generate embeddings")
+                    return False
+                if not self.vector_index.create_index():
+                    logger.error("Failed to create vector index")
+                    return False
+                ids = np.arange(len(atomic_notes), dtype=np.int64)
+                if not self.vector_index.add_vectors(self.note_embeddings, ids):
+                    logger.error("Failed to add vectors to index")
+                    return False
             if self.bm25_enabled:
                 self._build_bm25_index(atomic_notes)
             if self.enable_hybrid_search and self.hybrid_searcher:
@@ -148,6 +149,29 @@ class VectorRetriever:
             logger.error(f"Failed to build vector index: {e}")
             return False
 
+    def _build_device_resident(self, atomic_notes: List[Dict[str, Any]]) -> bool:
+        """encode -> index without the host round trip (reference flow retriever.py:140-157): the encoder writes the
+        embeddings into device memory, the index adds them from there, and ``note_embeddings`` (which callers index
+        into, query_processor.py:293) is filled by ONE device-to-host copy.  False = not applicable, nothing changed."""
+        em = self.embedding_manager
+        if not hasattr(em, "encode_texts_device") or not hasattr(getattr(em, "model", None), "encode_device"):
+            return False
+        dev = None
+        try:
+            dev = em.encode_texts_device(em._assemble_note_texts(atomic_notes))
+            if not self.vector_index.create_index():
+                return False
+            if not self.vector_index.add_vectors_device(dev, np.arange(len(atomic_notes), dtype=np.int64)):
+                return False
+            self.note_embeddings = dev.numpy()
+            return True
+        except Exception as e:
+            logger.warning(f"Device-resident index build not used: {e}")
+            return False
+        finally:
+            if dev is not None:
+                dev.free()
+
     # -- searching -------------------------------------------------------------------------------
     def search(self, queries: List[str], top_k: Optional[int] = None, similarity_threshold: Optional[float] = None,
                include_metadata: bool = True) -> List[List[Dict[str, Any]]]:
@@ -159,11 +183,13 @@ class VectorRetriever:
         top_k = top_k or self.top_k
         similarity_threshold = similarity_threshold or self.similarity_threshold
         try:
-            q_emb = self.embedding_manager.encode_queries(queries)
-            if q_emb.size == 0:
-                logger.error("Failed to generate query embeddings")
-                return [[] for _ in queries]
-            raw = self.vector_index.search(q_emb, top_k=top_k)
+            raw = self._search_device_resident(queries, top_k)
+            if raw is None:
+                q_emb = self.embedding_manager.encode_queries(queries)
+                if q_emb.size == 0:
+                    logger.error("Failed to generate query embeddings")
+                    return [[] for _ in queries]
+                raw = self.vector_index.search(q_emb, top_k=top_k)
             if len(queries) == 1 and isinstance(raw, list) and raw and isinstance(raw[0], dict):
                 raw = [raw]  # single query comes back flat (vector_index.py:255-257)
             out: List[List[Dict[str, Any]]] = []
@@ -190,6 +216,22 @@ class VectorRetriever:
         except Exception as e:
             logger.error(f"Failed to search: {e}")
             return [[] for _ in queries]
+
+    def _search_device_resident(self, queries: List[str], top_k: int):
+        """query embeddings go from the encoder to the scan in device memory (reference flow retriever.py:206-216);
+        None = not applicable"""
+        em = self.embedding_manager
+        if not hasattr(em, "encode_queries_device") or not hasattr(getattr(em, "model", None), "encode_device"):
+            return None
+        dev = None
+        try:
+            dev = em.encode_queries_device(queries)
+            return self.vector_index.search_device(dev, top_k=top_k)
+        except Exception:
+            return None
+        finally:
+            if dev is not None:
+                dev.free()
 
     def search_single(self, query: str, top_k: Optional[int] = None, similarity_threshold: Optional[float] = None,
                       include_metadata: bool = True) -> List[Dict[str, Any]]:

@@ -163,6 +163,48 @@ class VectorIndex:
             logger.error(f"Failed to add vectors to index: {e}")
             return False
 
+    def add_vectors_device(self, dev_vectors, ids: Optional[np.ndarray] = None) -> bool:
+        """EXTENSION: ``add_vectors`` for embeddings that already sit in device memory (an
+        ``anorag_hip.fusion.DeviceArray`` [n, dim] float32 on the index's device, e.g. from
+        ``EmbeddingManager.encode_texts_device``): the rows go from the encoder to the index without touching the host.
+        Single-device index with sequential ids only; returns False otherwise (the caller then uses ``add_vectors``)."""
+        if self.index is None or not isinstance(self.index, FlatIndex):
+            return False
+        n = int(dev_vectors.nq)
+        if dev_vectors.n != self.index.d or dev_vectors.dtype != np.float32 or dev_vectors.device != self.index.device:
+            return False
+        if ids is not None and not np.array_equal(np.asarray(ids).reshape(-1),
+                                                  np.arange(self.index.ntotal, self.index.ntotal + n)):
+            return False
+        if self._ids is not None:
+            return False
+        try:
+            if not self.is_trained and self.index_type in ("IVFFlat", "IVFPQ"):
+                if n < self.nlist * 2:  # the reference shrinks nlist and re-creates the index (vector_index.py:140-155)
+                    self.nlist = max(1, n // 2)
+                self.is_trained = True  # an exact scan has nothing to learn
+            self.index.add_device(dev_vectors.ptr, n)
+            self.total_vectors += n
+            logger.info(f"Added {n} vectors to index, total: {self.total_vectors}")
+            return True
+        except Exception as e:
+            logger.error(f"Failed to add vectors to index: {e}")
+            return False
+
+    def search_device(self, dev_queries, top_k: int = 10) -> List[Dict[str, Any]]:
+        """EXTENSION: ``search`` for query embeddings in device memory (``DeviceArray`` [nq, dim] float32); same return
+        value as ``search``.  Raises when the index cannot take device queries (the caller falls back)."""
+        if not isinstance(self.index, FlatIndex) or dev_queries.device != self.index.device or dev_queries.n != self.index.d:
+            raise ValueError("device queries need a single-device index on the same device")
+        if self.total_vectors == 0:
+            return []
+        scores, indices = self.index.search_device_queries(dev_queries.ptr, dev_queries.nq, int(top_k))
+        if self._ids is not None:
+            indices = np.where(indices >= 0, self._ids[np.clip(indices, 0, len(self._ids) - 1)], -1)
+        results = _shape_hits(np.ascontiguousarray(indices, dtype=np.int64),
+                              np.ascontiguousarray(scores, dtype=np.float32), self._cosine())
+        return results[0] if len(results) == 1 else results
+
     def search(self, query_vectors: np.ndarray, top_k: int = 10, return_vectors: bool = False) -> List[Dict[str, Any]]:
         if self.index is None:
             logger.error("Index not created yet")

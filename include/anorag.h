@@ -71,6 +71,8 @@ int anr_index_reconstruct(anr_index *h, int64_t i0, int64_t n, float *out_host);
  * ascending id.  Results are the exact top-k of the stored float32 rows.  k <= 1024 runs the streaming
  * pipeline; larger k (up to 2^20, synchronous calls only) computes every row's exact score and sorts on the device. */
 int anr_index_search(anr_index *h, const float *q_host, int64_t nq, int32_t k, float *D, int64_t *I);
+/* queries already in device memory (the output of anr_encoder_forward_dev), results to host buffers */
+int anr_index_search_devq(anr_index *h, const float *q_dev, int64_t nq, int32_t k, float *D, int64_t *I);
 /* same with device buffers, asynchronous on `stream` apart from one small status read-back */
 int anr_index_search_dev(anr_index *h, const float *q_dev, int64_t nq, int32_t k, float *D_dev,
                          int64_t *I_dev, void *stream);
@@ -228,6 +230,14 @@ int anr_encoder_finalize(anr_encoder *e); /* fails if a tensor is missing */
  * [B][L] or NULL; out_host [B][hidden] float32.  normalize != 0 applies F.normalize(p=2, dim=1). */
 int anr_encoder_forward(anr_encoder *e, const int32_t *ids, const int32_t *lengths, const int32_t *type_ids,
                         int32_t B, int32_t L, int32_t normalize, float *out_host);
+
+/* The same forward with the embeddings left in DEVICE memory (caller-allocated on the encoder's device, float32
+ * rows of `hidden`): sequence b goes to row out_rows[b] (host array [B]; NULL = row b), so the length-sorted batches
+ * of SentenceTransformer.encode land in input order.  Feeds anr_index_add_dev / anr_index_search_dev directly — the
+ * index build (vector_store/retriever.py:140-157) and the query path (:206-216) without the device -> host -> device
+ * round trip per batch.  out_dev is complete when the call returns. */
+int anr_encoder_forward_dev(anr_encoder *e, const int32_t *ids, const int32_t *lengths, const int32_t *type_ids,
+                            int32_t B, int32_t L, int32_t normalize, float *out_dev, const int32_t *out_rows);
 
 /* ------------------------------------------------------------------------------------------------
  * BM25 scoring: SimpleBM25.get_scores / bm25_scores of utils/bm25_search.py:43-63,

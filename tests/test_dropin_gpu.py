@@ -169,3 +169,43 @@ def test_embedding_manager_and_retriever(cfg, model_dir):
     assert vr.search(["x"]) == [[]]
     vr.cleanup()
     EmbeddingManager._reset_singleton()
+
+
+def test_device_resident_encode_to_index_handoff(cfg, model_dir):
+    """encoder -> index without the host round trip (anr_encoder_forward_dev -> anr_index_add_dev /
+    anr_index_search_devq): same embeddings and the same hits as the host-array path, rows in input order although
+    the encoder batches by length, tokenisation overlapped with the forward of the previous batch"""
+    from vector_store import EmbeddingManager, VectorRetriever
+    EmbeddingManager._reset_singleton()
+    cfg.set("embedding.model_path", model_dir)
+    cfg.set("embedding.max_length", 64)
+    cfg.set("embedding.batch_size", 8)           # 61 notes -> 8 length-sorted batches
+    cfg.set("vector_store.similarity_threshold", 0.0001)
+    em = EmbeddingManager()
+    words = oenc.synthetic_sentences(model_dir, 61, seed=21, min_words=2, max_words=30)
+    notes = [{"note_id": f"n{i}", "title": f"t{i}", "content": w} for i, w in enumerate(words)]
+    host = em.encode_atomic_notes(notes)
+    dev = em.encode_texts_device(em._assemble_note_texts(notes))
+    assert dev.nq == 61 and dev.n == em.embedding_dim
+    assert np.array_equal(dev.numpy(), host)      # same kernels, same rows, input order
+    dev.free()
+    vr = VectorRetriever()
+    assert vr._build_device_resident(notes) is True
+    assert np.array_equal(vr.note_embeddings, host) and vr.vector_index.total_vectors == 61
+    vr.atomic_notes = notes
+    vr._build_id_mappings()
+    q = words[:5]
+    a = vr._search_device_resident(q, 7)
+    b = vr.vector_index.search(em.encode_queries(q), top_k=7)
+    assert a is not None and a == b
+    assert vr.search(q, top_k=7) and len(vr.search(q, top_k=7)[0]) == 7
+    # a sharded (multi-handle) index cannot take device rows: the build falls back to the host path, same result
+    cfg.set("anorag_hip.devices", [0, 0])
+    vs = VectorRetriever()
+    assert vs.build_index(notes, force_rebuild=True, save_index=False) is True
+    assert type(vs.vector_index.index).__name__ == "ShardedFlatIndex"
+    assert np.array_equal(vs.note_embeddings, host)
+    assert [[h["note_id"] for h in r] for r in vs.search(q, top_k=7)] == [[h["note_id"] for h in r] for r in vr.search(q, top_k=7)]
+    vr.cleanup()
+    vs.cleanup()
+    EmbeddingManager._reset_singleton()
