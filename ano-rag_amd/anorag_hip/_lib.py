@@ -25,6 +25,7 @@ OPT_TIMING = 5
 OPT_ADD_RAW = 6
 OPT_STREAMS = 7
 OPT_ID_OFFSET = 8
+OPT_TINY = 9
 
 
 class AnoragError(RuntimeError):

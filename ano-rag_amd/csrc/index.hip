@@ -19,6 +19,7 @@
 
 #include "common.hpp"
 #include "index_kernels.hpp"
+#include "tiny_kernels.hpp"
 
 using namespace anr;
 
@@ -102,6 +103,13 @@ struct anr_index {
   unsigned char *out_pin = nullptr, *out_pin_dev = nullptr;  // pinned [nq*k f32 | nq*k i64] the kernels write in place
   int64_t out_pin_alloc = 0;                                  // results (nq * k)
   hipEvent_t ev_call[2] = {nullptr, nullptr};
+
+  // single-launch path for tiny corpora (tiny_kernels.hpp)
+  int tiny = 1;                                   // ANR_OPT_TINY
+  unsigned char *tiny_pin = nullptr, *tiny_pin_dev = nullptr;  // pinned: queries | D | I | completion words
+  unsigned long long *tiny_cand = nullptr;        // [kTinyMaxQ][kTinyMaxWG][kTinyMaxK]
+  unsigned *tiny_ticket = nullptr;                // [kTinyMaxQ]
+  unsigned tiny_seq = 0;
 
   anr_search_stats stats{};
 };
@@ -805,6 +813,74 @@ int search_large_k(anr_index *h, const float *q, bool q_on_host, int64_t nq, int
   return ANR_OK;
 }
 
+// Tiny corpus, host buffers, a handful of queries: ONE kernel launch, completion by a word in pinned memory
+// (tiny_kernels.hpp).  Exact by construction (f32 rows, f64 accumulation): no certificate, no fallback.
+bool tiny_applies(const anr_index *h, int64_t nq, int32_t k) {
+  if (!h->tiny || h->force_exact || nq < 1 || nq > kTinyMaxQ || k > kTinyMaxK) return false;
+  if (h->ntotal < 1 || h->ntotal * (int64_t)h->dim * 4 > ((int64_t)32 << 20)) return false;
+  const int64_t n_wg = std::max<int64_t>(1, std::min<int64_t>(kTinyMaxWG, kTinyMaxMerge / k));
+  return ceil_div(h->ntotal, n_wg) <= kTinyRowsPerWG;
+}
+
+int search_tiny(anr_index *h, const float *q, int64_t nq, int32_t k, float *D, int64_t *I) {
+  const size_t q_bytes = (size_t)kTinyMaxQ * h->dim * sizeof(float);
+  const size_t d_off = round_up((int64_t)q_bytes, 16), i_off = d_off + (size_t)kTinyMaxQ * kTinyMaxK * 4;
+  const size_t f_off = i_off + (size_t)kTinyMaxQ * kTinyMaxK * 8;
+  if (!h->tiny_pin) {
+    ANR_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->tiny_pin), f_off + 64, hipHostMallocDefault));
+    ANR_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&h->tiny_pin_dev), h->tiny_pin, 0));
+    memset(h->tiny_pin + f_off, 0, 64);
+    ANR_TRY(dev_alloc(&h->tiny_cand, (int64_t)kTinyMaxQ * kTinyMaxMerge, true));
+    ANR_TRY(dev_alloc(&h->tiny_ticket, kTinyMaxQ, true));
+  }
+  memcpy(h->tiny_pin, q, (size_t)nq * h->dim * sizeof(float));
+  TinyParams tp{};
+  tp.x32 = h->x32;
+  tp.q_host = reinterpret_cast<const float *>(h->tiny_pin_dev);
+  tp.nq = (int)nq;
+  tp.dim = h->dim;
+  tp.metric = h->metric;
+  tp.normalize = h->normalize;
+  tp.k = k;
+  tp.n_rows = h->ntotal;
+  // few enough workgroups that the last one merges <= kTinyMaxMerge entries, enough that every CU slice is short
+  int n_wg = (int)std::max<int64_t>(1, std::min<int64_t>(kTinyMaxWG, kTinyMaxMerge / k));
+  n_wg = (int)std::min<int64_t>(n_wg, ceil_div(h->ntotal, 16));
+  tp.rows_per_wg = (int)ceil_div(h->ntotal, n_wg);
+  tp.n_wg = (int)ceil_div(h->ntotal, tp.rows_per_wg);
+  tp.cand = h->tiny_cand;
+  tp.ticket = h->tiny_ticket;
+  tp.D = reinterpret_cast<float *>(h->tiny_pin_dev + d_off);
+  tp.I = reinterpret_cast<int64_t *>(h->tiny_pin_dev + i_off);
+  tp.flag = reinterpret_cast<unsigned *>(h->tiny_pin_dev + f_off);
+  if (++h->tiny_seq == 0) h->tiny_seq = 1;
+  tp.seq = h->tiny_seq;
+  tp.id_offset = h->id_offset;
+  const size_t lds = (size_t)kTinyMaxMerge * 8 + (size_t)round_up(h->dim, 4) * sizeof(float);
+  ANR_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_tiny_search), (int)lds));
+  hipLaunchKernelGGL(k_tiny_search, dim3((unsigned)tp.n_wg, (unsigned)nq), dim3(kTinyThreads), lds, h->stream, tp);
+  ANR_HIP(hipGetLastError());
+  // completion: spin on the words the last workgroups write into pinned memory (an event / stream wait costs more
+  // than the whole kernel); after ~2 s fall back to the stream so a device fault surfaces as an error
+  volatile unsigned *flag = reinterpret_cast<volatile unsigned *>(h->tiny_pin + f_off);
+  for (int64_t qi = 0; qi < nq; ++qi) {
+    uint64_t spins = 0;
+    while (__atomic_load_n(&flag[qi], __ATOMIC_ACQUIRE) != tp.seq) {
+      __builtin_ia32_pause();
+      if (++spins > (1ull << 28)) {
+        ANR_HIP(hipStreamSynchronize(h->stream));
+        if (__atomic_load_n(&flag[qi], __ATOMIC_ACQUIRE) != tp.seq)
+          return fail(ANR_EINTERNAL, "tiny search: the kernel finished without raising its completion word");
+        break;
+      }
+    }
+  }
+  memcpy(D, h->tiny_pin + d_off, (size_t)nq * k * sizeof(float));
+  memcpy(I, h->tiny_pin + i_off, (size_t)nq * k * sizeof(int64_t));
+  h->stats.n_dense_exact += nq;
+  return ANR_OK;
+}
+
 // synchronous search (host or device buffers): enqueue every batch, then retire them all
 int search_impl(anr_index *h, const float *q, bool q_on_host, int64_t nq, int32_t k, float *D, int64_t *I,
                 bool out_on_host, hipStream_t st) {
@@ -818,6 +894,7 @@ int search_impl(anr_index *h, const float *q, bool q_on_host, int64_t nq, int32_
   h->stats.n_queries = nq;
   if (nq == 0) return ANR_OK;
   if (h->ntotal == 0) return write_empty(h, nq, k, D, I, out_on_host);
+  if (q_on_host && out_on_host && tiny_applies(h, nq, k)) return search_tiny(h, q, nq, k, D, I);
   ANR_TRY(ensure_workspaces(h));
   ANR_TRY(refresh_xstat(h));
   float *Dd = D;
@@ -993,6 +1070,9 @@ int anr_index_destroy(anr_index *h) {
   dev_free(h->d_out);
   dev_free(h->i_out);
   if (h->out_pin) (void)hipHostFree(h->out_pin);
+  if (h->tiny_pin) (void)hipHostFree(h->tiny_pin);
+  dev_free(h->tiny_cand);
+  dev_free(h->tiny_ticket);
   for (auto &e : h->ev_call)
     if (e) (void)hipEventDestroy(e);
   for (hipStream_t s : {h->bstream[0], h->bstream[1], h->bstream[2], h->stream})
@@ -1306,6 +1386,7 @@ int anr_index_set_option(anr_index *h, int32_t opt, int64_t value) {
       if (value < 0) return fail(ANR_EINVAL, "id offset must be >= 0");
       h->id_offset = value;
       break;
+    case ANR_OPT_TINY: h->tiny = value != 0; break;
     case ANR_OPT_STREAMS:
       if (value < 1 || value > kWorkspaces) return fail(ANR_EINVAL, "streams must be in 1..%d", kWorkspaces);
       h->n_streams = (int)value;

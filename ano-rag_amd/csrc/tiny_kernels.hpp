@@ -1,0 +1,184 @@
+// Single-launch exact search for tiny corpora (BASELINE.json config C1: 10 k notes x 384-d, batch 1, top-10 — the
+// regime the reference actually runs per query, vector_store/retriever.py:186-216 with top_k 20).
+//
+// At this size the five-kernel pipeline (prepq, scan, select, rescore, finalize + one DMA) is pure launch
+// latency: ~58 us per query against numpy's 44 us.  Here ONE kernel does the whole search: every workgroup reads
+// the raw query straight from pinned host memory (1.5 KB over PCIe, no DMA), normalises it exactly as k_prepq
+// does, computes the EXACT scores of its slice of the stored f32 rows (f64 accumulation in k_rescore's order, so
+// the values are bit-identical to the streaming pipeline's), keeps its k best, and the last workgroup to finish
+// (agent-scope release / ticket / acquire) merges the partial lists, writes scores and ids straight into pinned
+// host memory and raises a completion word the host spins on — no event, no stream synchronisation.
+#pragma once
+#include "index_kernels.hpp"
+
+namespace anr {
+
+constexpr int kTinyThreads = 1024;
+constexpr int kTinyMaxWG = 64;
+constexpr int kTinyMaxK = 128;
+constexpr int kTinyMaxQ = 4;
+constexpr int kTinyRowsPerWG = 1024;   // rows a workgroup ranks among themselves
+constexpr int kTinyMaxMerge = 2048;    // partial-list entries the last workgroup merges
+
+struct TinyParams {
+  const float *x32;      // stored rows [n_rows][dim]
+  const float *q_host;   // pinned host memory (device-visible address): raw queries [nq][dim]
+  int nq, dim, metric, normalize, k;
+  int64_t n_rows;
+  int rows_per_wg, n_wg;
+  unsigned long long *cand;  // [nq][n_wg][k] keys, 0 = empty
+  unsigned *ticket;          // [nq], zero between calls
+  float *D;                  // pinned host [nq][k]
+  int64_t *I;                // pinned host [nq][k]
+  unsigned *flag;            // pinned host [nq]: set to seq when query q is complete
+  unsigned seq;
+  int64_t id_offset;
+};
+
+__global__ __launch_bounds__(kTinyThreads) void k_tiny_search(TinyParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tiny_smem[];
+  unsigned long long *s_keys = reinterpret_cast<unsigned long long *>(tiny_smem);             // [kTinyMaxMerge]
+  float *s_q = reinterpret_cast<float *>(tiny_smem + (size_t)kTinyMaxMerge * 8);              // [dim rounded to 4]
+  __shared__ double s_red[4];
+  __shared__ float s_scale;
+  __shared__ int s_last;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = blockIdx.y, wg = blockIdx.x;
+  const float *qin = p.q_host + (int64_t)q * p.dim;
+  // --- the query: raw copy from host memory, norm in k_prepq's order (256 threads, f64), divide -------------
+  for (int k = tid; k < p.dim; k += kTinyThreads) s_q[k] = qin[k];
+  __syncthreads();
+  if (tid < 256) {
+    double acc = 0.0;
+    for (int k = tid; k < p.dim; k += 256) {
+      const double v = (double)s_q[k];
+      acc += v * v;
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (lane == 0) s_red[wave] = acc;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const float nrm = (float)sqrt(s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+    s_scale = (p.normalize && nrm != 0.0f) ? nrm : 1.0f;
+  }
+  __syncthreads();
+  const float scale = s_scale;
+  for (int k = tid; k < p.dim; k += kTinyThreads) s_q[k] = s_q[k] / scale;
+  __syncthreads();
+  // --- exact scores of this workgroup's rows: one wave per row, 8 rows in flight per wave ---------------------
+  const int64_t row0 = (int64_t)wg * p.rows_per_wg;
+  const int rows = (int)(row0 + p.rows_per_wg <= p.n_rows ? p.rows_per_wg : (p.n_rows > row0 ? p.n_rows - row0 : 0));
+  unsigned long long *s_rowkey = s_keys;  // [rows] while ranking (rows <= kTinyRowsPerWG <= kTinyMaxMerge)
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  constexpr int NW = kTinyThreads / 64, RB = 8;
+  for (int r0 = wave * RB; r0 < rows; r0 += NW * RB) {
+    double acc[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) acc[r] = 0.0;
+    if ((p.dim & 3) == 0) {
+      const f32x4 *q4 = reinterpret_cast<const f32x4 *>(s_q);
+      const int n4 = p.dim >> 2;
+      for (int k = lane; k < n4; k += 64) {
+        const f32x4 b = q4[k];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+          const int rr = r0 + r < rows ? r0 + r : rows - 1;  // clamped: the duplicate is discarded below
+          const f32x4 a = *reinterpret_cast<const f32x4 *>(p.x32 + (row0 + rr) * p.dim + 4 * k);
+          if (p.metric == 0) {
+            acc[r] += (double)a.x * (double)b.x;
+            acc[r] += (double)a.y * (double)b.y;
+            acc[r] += (double)a.z * (double)b.z;
+            acc[r] += (double)a.w * (double)b.w;
+          } else {
+            const double d0 = (double)b.x - (double)a.x, d1 = (double)b.y - (double)a.y;
+            const double d2 = (double)b.z - (double)a.z, d3 = (double)b.w - (double)a.w;
+            acc[r] += d0 * d0;
+            acc[r] += d1 * d1;
+            acc[r] += d2 * d2;
+            acc[r] += d3 * d3;
+          }
+        }
+      }
+    } else {
+      for (int k = lane; k < p.dim; k += 64) {
+        const double b = (double)s_q[k];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+          const int rr = r0 + r < rows ? r0 + r : rows - 1;
+          const double a = (double)p.x32[(row0 + rr) * p.dim + k];
+          if (p.metric == 0) acc[r] += a * b;
+          else acc[r] += (b - a) * (b - a);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      for (int off = 32; off > 0; off >>= 1) acc[r] += __shfl_xor(acc[r], off);
+      if (lane == 0 && r0 + r < rows) {
+        const float e = (float)acc[r];
+        s_rowkey[r0 + r] = make_key(p.metric == 0 ? e : -e, (unsigned)(row0 + r0 + r));
+      }
+    }
+  }
+  __syncthreads();
+  // --- the workgroup's k best (rank counting among its rows), published as its partial list --------------------
+  unsigned long long *mine = p.cand + ((int64_t)q * p.n_wg + wg) * p.k;
+  unsigned long long mykey = 0ull;
+  int myrank = p.k;
+  if (tid < rows) {
+    mykey = s_rowkey[tid];
+    int rank = 0;
+    for (int j = 0; j < rows; ++j) rank += (s_rowkey[j] > mykey) ? 1 : 0;
+    myrank = rank;
+  }
+  if (myrank < p.k) __hip_atomic_store(mine + myrank, mykey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int i = rows + tid; i < p.k; i += kTinyThreads)
+    __hip_atomic_store(mine + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains before the ticket
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(p.ticket + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (t == (unsigned)(p.n_wg - 1)) ? 1 : 0;
+    if (s_last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+  __syncthreads();
+  if (!s_last) return;
+  // --- the last workgroup merges n_wg * k <= kTinyMaxMerge entries, ranks them, writes host memory ----------------
+  const int M = p.n_wg * p.k;
+  const unsigned long long *all = p.cand + (int64_t)q * p.n_wg * p.k;
+  for (int i = tid; i < M; i += kTinyThreads)
+    s_keys[i] = __hip_atomic_load(all + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  float *D = p.D + (int64_t)q * p.k;
+  int64_t *I = p.I + (int64_t)q * p.k;
+  const int64_t found = p.n_rows < p.k ? p.n_rows : p.k;
+  for (int i = tid; i < M; i += kTinyThreads) {
+    const unsigned long long key = s_keys[i];
+    if (key == 0ull) continue;
+    int rank = 0;
+    for (int j = 0; j < M; ++j) rank += (s_keys[j] > key) ? 1 : 0;
+    if (rank < p.k) {
+      const float v = ord2f((unsigned)(key >> 32));
+      D[rank] = p.metric == 0 ? v : -v;
+      I[rank] = (int64_t)(0xffffffffu - (unsigned)(key & 0xffffffffu)) + p.id_offset;
+    }
+  }
+  for (int i = (int)found + tid; i < p.k; i += kTinyThreads) {  // fewer rows than k: faiss padding
+    D[i] = p.metric == 0 ? -3.402823466e+38f : 3.402823466e+38f;
+    I[i] = -1;
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (tid == 0) {
+    __hip_atomic_store(p.ticket + q, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next call
+    __hip_atomic_store(p.flag + q, p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+}  // namespace anr

@@ -504,3 +504,39 @@ def test_candidate_list_overflow_falls_back_to_the_dense_exact_path():
     st = idx.last_stats()
     assert st["n_overflow"] > 0 and st["n_dense_exact"] > 0, st
     idx.close()
+
+
+def test_tiny_corpus_single_launch_path_equals_the_pipeline_and_the_oracle():
+    """C1's regime (a few queries, host buffers, a corpus of a few MB): ONE kernel per call (tiny_kernels.hpp).  Same
+    bits as the five-kernel pipeline (ANR_OPT_TINY = 0) and the oracle's ids — cosine and L2, a dimension that is not
+    a multiple of 4, k larger than the corpus, an id offset, 1 to 4 queries, repeated calls (completion words)."""
+    from anorag_hip import FlatIndex, METRIC_IP, METRIC_L2
+    from anorag_hip._lib import OPT_ID_OFFSET, OPT_TINY
+    for (n, d, k, metric, name, norm) in ((10_000, 384, 10, METRIC_IP, "ip", True), (7_777, 130, 100, METRIC_L2, "l2", False),
+                                          (37, 64, 50, METRIC_IP, "ip", True), (16_001, 96, 128, METRIC_IP, "ip", False)):
+        x, q = _data(n, d, 4, seed=n, qseed=n + 1)
+        idx = FlatIndex(d, metric, normalize=norm)
+        idx.add(x)
+        for nq in (1, 3, 4):
+            for rep in range(3):
+                D, I = idx.search(q[:nq], k)
+                st = idx.last_stats()
+                assert st["n_dense_exact"] == nq and st["n_candidates"] == 0, st   # the single-launch path ran
+            idx.set_option(OPT_TINY, 0)
+            D0, I0 = idx.search(q[:nq], k)
+            idx.set_option(OPT_TINY, 1)
+            assert np.array_equal(I, I0) and np.array_equal(D, D0)
+            _check(idx, x, q[:nq], k, name, norm)
+        idx.set_option(OPT_ID_OFFSET, 5_000_000)
+        D1, I1 = idx.search(q[:1], k)
+        assert np.array_equal(np.where(I1 >= 0, I1 - 5_000_000, -1), I[:1]) and np.array_equal(D1, D[:1])
+        idx.close()
+    # beyond the path's limits the pipeline answers (5 queries; a 40 MB corpus)
+    x, q = _data(30_000, 384, 5)
+    idx = FlatIndex(384, METRIC_IP, normalize=True)
+    idx.add(x)
+    idx.search(q, 10)
+    assert idx.last_stats()["n_dense_exact"] == 0
+    idx.search(q[:1], 10)
+    assert idx.last_stats()["n_dense_exact"] == 0
+    idx.close()
