@@ -135,7 +135,14 @@ SIGNATURES = {
         [C.c_int32, C.c_int32, C.c_int64, C.POINTER(FuseSource), C.c_void_p, C.c_double, C.c_int32, C.c_void_p,
          C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(FuseDenseStats)],
     ),
+    "anr_fuse_candidates": (
+        C.c_int,
+        [C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+         C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p],
+    ),
     "anr_bm25_scores_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "anr_bm25_combine_fields": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32,
+                                          C.c_void_p]),
     "anr_bm25_create": (C.c_int, [C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.POINTER(C.c_void_p)]),
     "anr_bm25_destroy": (C.c_int, [C.c_void_p]),

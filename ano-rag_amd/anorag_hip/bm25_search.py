@@ -143,6 +143,90 @@ class DeviceBM25:
             pass
 
 
+class DeviceFieldWeightedBM25:
+    """FieldWeightedBM25 (reference utils/bm25_search.py:66-146): one BM25 per field (title / entities / content by
+    default) with its own document lengths, average length and IDF, combined as sum_f weight_f * score_f.  Each field
+    is a ``DeviceBM25`` (same posting-weight expression, same addition order); the fields are added up on the device
+    in the order of ``field_weights`` — float64, bit-identical to the reference's ``get_scores``."""
+
+    def __init__(self, corpus: List[Dict[str, List[str]]], field_weights: Dict[str, float] = None, k1: float = 1.5,
+                 b: float = 0.75, device: int = 0):
+        self.corpus = corpus
+        self.field_weights = field_weights or {"title": 2.0, "entities": 1.5, "content": 1.0}
+        self.k1, self.b = k1, b
+        self.doc_count = len(corpus)
+        self.device = int(device)
+        self.fields: Dict[str, DeviceBM25] = {}
+        for field in self.field_weights:
+            self.fields[field] = DeviceBM25([doc.get(field, []) for doc in corpus], k1, b, device)
+
+    def scores_device(self, queries: Sequence[Sequence[str]], normalize: bool = False):
+        """[nq, n_docs] float64 in device memory (``DeviceArray``): feeds ``anr_fuse_dense`` as is"""
+        from .fusion import DeviceArray
+        nq = len(queries)
+        parts = [bm.scores_device(queries, normalize=False) for bm in self.fields.values()]
+        out = DeviceArray(nq, self.doc_count, np.float64, self.device)
+        ptrs = (C.c_void_p * len(parts))(*[p.ptr for p in parts])
+        w = np.asarray([float(v) for v in self.field_weights.values()], dtype=np.float64)
+        try:
+            _lib.check(_lib.load().anr_bm25_combine_fields(self.device, len(parts), ptrs, w.ctypes.data_as(C.c_void_p), nq,
+                                                           self.doc_count, int(bool(normalize)), C.c_void_p(out.ptr)),
+                       "anr_bm25_combine_fields")
+        finally:
+            for p in parts:
+                p.free()
+        return out
+
+    def scores_batch(self, queries: Sequence[Sequence[str]], normalize: bool = False) -> np.ndarray:
+        if self.doc_count == 0 or not queries:
+            return np.zeros((len(queries), self.doc_count), dtype=np.float64)
+        d = self.scores_device(queries, normalize)
+        try:
+            return d.numpy()
+        finally:
+            d.free()
+
+    def get_scores(self, query: List[str]) -> List[float]:
+        return self.scores_batch([query], normalize=False)[0].tolist()
+
+    def close(self):
+        for bm in self.fields.values():
+            bm.close()
+
+
+def build_field_weighted_bm25_corpus(notes: List[Dict[str, Any]], field_weights: Dict[str, float] = None) -> DeviceFieldWeightedBM25:
+    """reference utils/bm25_search.py:149-187: title / entities / content token lists per note"""
+    if field_weights is None:
+        field_weights = {"title": 2.0, "entities": 1.5, "content": 1.0}
+    field_corpus = []
+    for note in notes:
+        entities = note.get("entities", []) or []
+        entities_text = " ".join(entities) if isinstance(entities, list) else str(entities)
+        field_corpus.append({"title": tokenize_text(note.get("title", "") or ""),
+                             "entities": tokenize_text(entities_text),
+                             "content": tokenize_text(note.get("content", "") or "")})
+    return DeviceFieldWeightedBM25(field_corpus, field_weights)
+
+
+def field_weighted_bm25_scores(corpus: DeviceFieldWeightedBM25, docs: List[Dict[str, Any]], query: str) -> List[float]:
+    """reference utils/bm25_search.py:190-234"""
+    try:
+        tokens = tokenize_text(query)
+        if not tokens:
+            return [0.0] * len(docs)
+        scores = corpus.scores_batch([tokens], normalize=False)[0].tolist()
+        if len(scores) != len(docs):
+            scores = scores + [0.0] * (len(docs) - len(scores)) if len(scores) < len(docs) else scores[:len(docs)]
+        if scores:
+            m = max(scores)
+            if m > 0:
+                scores = [s / m for s in scores]
+        return scores
+    except Exception as e:
+        logger.error(f"Error calculating field-weighted BM25 scores: {e}")
+        return [0.0] * len(docs)
+
+
 def build_bm25_corpus(notes: List[Dict[str, Any]], text_fn: Callable[[Dict[str, Any]], str]) -> DeviceBM25:
     tokenized = []
     for note in notes:

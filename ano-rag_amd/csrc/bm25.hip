@@ -95,6 +95,45 @@ __global__ __launch_bounds__(1024) void k_bm25_nonzero(NzParams p) {
   if (tid == 0) p.out_count[q] = s_cnt;
 }
 
+// FieldWeightedBM25.get_scores (utils/bm25_search.py:116-146): total = sum over the fields, in field order, of
+// weight_f * field_score_f — elementwise over the documents, then the max-normalisation of
+// field_weighted_bm25_scores (:222-226).  One workgroup per query.
+struct CombineParams {
+  const double *f[8];
+  double w[8];
+  int n_fields;
+  int64_t n_docs;
+  int normalize;
+  double *out;  // [nq][n_docs]
+};
+
+__global__ __launch_bounds__(1024) void k_bm25_combine(CombineParams p) {
+  __shared__ double s_red[16];
+  __shared__ double s_max;
+  const int q = blockIdx.x, tid = threadIdx.x;
+  double *o = p.out + (int64_t)q * p.n_docs;
+  double m = -__builtin_inf();
+  for (int64_t d = tid; d < p.n_docs; d += 1024) {
+    double t = 0.0;
+    for (int f = 0; f < p.n_fields; ++f) t += p.w[f] * p.f[f][(int64_t)q * p.n_docs + d];
+    o[d] = t;
+    m = fmax(m, t);
+  }
+  if (!p.normalize) return;
+  for (int s = 32; s > 0; s >>= 1) m = fmax(m, __shfl_xor(m, s));
+  if ((tid & 63) == 0) s_red[tid >> 6] = m;
+  __syncthreads();
+  if (tid == 0) {
+    double mm = s_red[0];
+    for (int w = 1; w < 16; ++w) mm = fmax(mm, s_red[w]);
+    s_max = mm;
+  }
+  __syncthreads();
+  const double mx = s_max;
+  if (mx > 0.0)
+    for (int64_t d = tid; d < p.n_docs; d += 1024) o[d] = o[d] / mx;
+}
+
 }  // namespace anr
 
 using namespace anr;
@@ -254,6 +293,29 @@ int anr_bm25_scores_dev(anr_bm25 *h, int64_t nq, const int64_t *q_indptr, const 
   std::lock_guard<std::mutex> lk(h->mu);
   double *d = nullptr;
   return score_chunk(h, nq, q_indptr, q_terms, normalize, &d, out_dev);
+}
+
+int anr_bm25_combine_fields(int32_t device, int32_t n_fields, const double *const *field_scores_dev, const double *weights,
+                            int64_t nq, int64_t n_docs, int32_t normalize, double *out_dev) {
+  if (n_fields < 1 || n_fields > 8 || !field_scores_dev || !weights || nq < 0 || n_docs < 0 || !out_dev)
+    return fail(ANR_EINVAL, "bad argument (1..8 fields)");
+  if (nq == 0 || n_docs == 0) return ANR_OK;
+  DeviceGuard g(device);
+  if (!g.ok) return fail(ANR_EHIP, "hipSetDevice(%d) failed", device);
+  CombineParams p{};
+  for (int f = 0; f < n_fields; ++f) {
+    if (!field_scores_dev[f]) return fail(ANR_EINVAL, "field %d: null score array", f);
+    p.f[f] = field_scores_dev[f];
+    p.w[f] = weights[f];
+  }
+  p.n_fields = n_fields;
+  p.n_docs = n_docs;
+  p.normalize = normalize;
+  p.out = out_dev;
+  hipLaunchKernelGGL(k_bm25_combine, dim3((unsigned)nq), dim3(1024), 0, 0, p);
+  ANR_HIP(hipGetLastError());
+  ANR_HIP(hipStreamSynchronize(nullptr));
+  return ANR_OK;
 }
 
 int anr_bm25_nonzero(anr_bm25 *h, int64_t nq, const int64_t *q_indptr, const int32_t *q_terms, int32_t normalize,

@@ -203,6 +203,22 @@ int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const anr_fuse_so
                    const double *weights /*[4]*/, double rrf_k, int32_t pool, int64_t *out_ids, double *out_final,
                    double *out_src, int32_t *out_count, anr_fuse_dense_stats *stats /* may be NULL */);
 
+/* Candidate-level fusion of QueryProcessor (opt-in, the reference's own call path re-encodes
+ * candidates instead): the scoring loops of _hybrid_search (query/query_processor.py:3703-3760) and of
+ * _enhanced_hybrid_search_v2 (:1104-1143) for nq queries at once, candidates of query q = entries [offs[q], offs[q+1]).
+ *   mode 0 linear: v = a; s = b; s *= 0.1 if flags&1 (misses the must-have terms); v *= 1.2 per boost entity found
+ *                  (n_ent); s *= 1.3 per boost predicate found (n_pred); score = wa*v + wb*s
+ *   mode 1 rrf:    0-based ranks of stable descending sorts of a and of b; score = wa/(rrf_k+ra) + wb/(rrf_k+rb);
+ *                  score *= 0.1 if flags&1
+ *   mode 2 v2:     f = 1.0*a + 0.6*b; f *= mult[0] (section); f *= mult[1] (lexical); if f < noise and flags&1 (must-have
+ *                  terms NOT satisfied): f = 0; f *= mult[2] (entity boost); f *= mult[3] (predicate boost)
+ * score[] per candidate (float64, the reference's order of operations) and order[] = the candidate indices of each
+ * query (relative to its range) in the stable descending order the reference sorts into.  All arrays host memory;
+ * flags / n_ent / n_pred may be NULL (= 0), mult is [total][4] and required for mode 2. */
+int anr_fuse_candidates(int32_t device, int32_t mode, int64_t nq, const int64_t *offs, const double *a, const double *b,
+                        const int32_t *flags, const int32_t *n_ent, const int32_t *n_pred, const double *mult,
+                        double wa, double wb, double rrf_k, double noise, double *score, int32_t *order);
+
 /* ------------------------------------------------------------------------------------------------
  * Sentence encoder: replaces SentenceTransformer.encode as called at
  * vector_store/embedding_manager.py:392-399 (and :357) — transformer forward + pooling + optional L2
@@ -260,6 +276,13 @@ int anr_bm25_scores(anr_bm25 *h, int64_t nq, const int64_t *q_indptr, const int3
  * source anr_fuse_dense takes — the N-vector never crosses PCIe */
 int anr_bm25_scores_dev(anr_bm25 *h, int64_t nq, const int64_t *q_indptr, const int32_t *q_terms, int32_t normalize,
                         double *out_dev);
+/* FieldWeightedBM25 (utils/bm25_search.py:66-146, :190-234): per field one anr_bm25 handle scores the queries
+ * (anr_bm25_scores_dev, normalize = 0); this adds the fields up — total = sum_f weights[f] * field_scores[f], in field
+ * order, float64, bit-identical to get_scores — and, with normalize != 0, divides by the per-query maximum when it is
+ * > 0 (field_weighted_bm25_scores).  field_scores_dev: host array of n_fields (<= 8) device pointers [nq][n_docs];
+ * out_dev [nq][n_docs] on the same device (it may be one of the inputs). */
+int anr_bm25_combine_fields(int32_t device, int32_t n_fields, const double *const *field_scores_dev,
+                            const double *weights, int64_t nq, int64_t n_docs, int32_t normalize, double *out_dev);
 /* sparse form for the fusion: the documents with a non-zero score, unordered; out_count may exceed cap
  * (the lists are then truncated) */
 int anr_bm25_nonzero(anr_bm25 *h, int64_t nq, const int64_t *q_indptr, const int32_t *q_terms, int32_t normalize,

@@ -13,6 +13,10 @@ stub, the same sys.modules technique the reference's own tests use for GPUtil). 
       ids; the long lists are stored sparsely (non-zero entries + the value every other entry has)
   tests/golden/embedding_candidates_cases.json   GraphRetriever._find_embedding_candidates
       (graph/graph_retriever.py:153-170), with `graph.graph_index` / `config` satisfied by stand-in modules
+  tests/golden/candidate_fusion_cases.json   QueryProcessor._hybrid_search / _enhanced_hybrid_search_v2
+      (query/query_processor.py:3680-3768, :1088-1143): query_processor.py cannot be imported here (LLM clients,
+      rerankers, ...), so the two METHODS are taken from its source with `ast`, compiled as they stand and run on a
+      stand-in `self` whose collaborators (vector / bm25 similarities, penalties, boosts) return the case's inputs
   tests/golden/similarity_relation_cases.json   embeddings + the reference's semantic-similarity relations
       (graph/relation_extractor.py:591-629, 769-791).  That file's module-level imports (`utils`, `config`) pull
       in packages that are absent here; the three methods used are pure numpy, so the two names are satisfied by
@@ -205,6 +209,95 @@ def load_graph_retriever():
     return load_by_path("graph.graph_retriever", os.path.join(REF, "graph", "graph_retriever.py"))
 
 
+def candidate_fusion_cases():
+    """runs the reference's own _hybrid_search / _enhanced_hybrid_search_v2 bodies on synthetic candidates"""
+    import ast
+    import numpy as np
+    path = os.path.join(REF, "query", "query_processor.py")
+    src = open(path, encoding="utf-8").read()
+    tree = ast.parse(src)
+    wanted = {}
+    for node in ast.walk(tree):
+        if isinstance(node, ast.ClassDef) and node.name == "QueryProcessor":
+            for fn in node.body:
+                if isinstance(fn, ast.FunctionDef) and fn.name in ("_hybrid_search", "_enhanced_hybrid_search_v2"):
+                    fn.decorator_list = []
+                    wanted[fn.name] = fn
+
+    class _Log:
+        def __getattr__(self, _):
+            return lambda *a, **k: None
+
+    from typing import Any, Dict, List
+    ns = {"List": List, "Dict": Dict, "Any": Any, "logger": _Log(), "config": types.SimpleNamespace(get=lambda k, d=None: d)}
+    mod = ast.Module(body=list(wanted.values()), type_ignores=[])
+    exec(compile(ast.fix_missing_locations(mod), path, "exec"), ns)
+    bm_stub = types.ModuleType("utils.bm25_search")
+    sys.modules.setdefault("utils", types.ModuleType("utils"))
+    sys.modules["utils.bm25_search"] = bm_stub
+    rng = np.random.default_rng(20261006)
+    vocab = [f"w{i}" for i in range(40)]
+    cases = []
+
+    def cands(n, ties=False):
+        out = []
+        for i in range(n):
+            out.append({"note_id": f"n{i}", "content": " ".join(rng.choice(vocab, size=int(rng.integers(3, 12)))),
+                        "title": f"t{i % 5}"})
+        vs = rng.uniform(0.05, 0.95, n)
+        bs = np.abs(rng.standard_normal(n))
+        bs = bs / bs.max() if n else bs
+        bs[rng.random(n) < 0.4] = 0.0
+        if ties:
+            vs, bs = np.round(vs, 1), np.round(bs, 1)
+        return out, [float(v) for v in vs], [float(v) for v in bs]
+
+    for method in ("linear", "rrf"):
+        for t, (n, ties) in enumerate([(30, False), (120, False), (60, True), (1, False), (7, True)]):
+            c, vs, bs = cands(n, ties)
+            must = [str(w) for w in rng.choice(vocab, 2)] if t != 3 else None
+            ents = [str(w) for w in rng.choice(vocab, 3)] if t % 2 == 0 else None
+            preds = [str(w) for w in rng.choice(vocab, 3)] if t % 2 == 1 or t == 0 else None
+            self = types.SimpleNamespace(structured_logger=_Log(), hybrid_search_enabled=True, bm25_corpus=True,
+                                         fusion_method=method, vector_weight=0.7, bm25_weight=0.3, rrf_k=60,
+                                         _calculate_vector_similarities=lambda q, cc, vs=vs: list(vs),
+                                         _fallback_vector_search=lambda q, cc: (_ for _ in ()).throw(RuntimeError("fallback")))
+            bm_stub.bm25_scores = lambda corpus, docs, query, bs=bs: list(bs)
+            inp = [dict(x) for x in c]
+            out = ns["_hybrid_search"](self, "query", [dict(x) for x in c], must, ents, preds)
+            cases.append({"name": f"hybrid_{method}_{t}", "kind": method, "vector_weight": 0.7, "bm25_weight": 0.3, "rrf_k": 60,
+                          "candidates": inp, "vector_scores": vs, "bm25_scores": bs, "must_have_terms": must,
+                          "boost_entities": ents, "boost_predicates": preds,
+                          "expected": [{"note_id": x["note_id"], "hybrid_score": x["hybrid_score"]} for x in out]})
+    for t, n in enumerate([25, 90, 40, 3]):
+        c, vs, bs = cands(n, ties=(t == 2))
+        sec = [float(rng.choice([1.0, 0.5, 0.8])) for _ in range(n)]
+        lex = [float(rng.choice([1.0, 0.3])) for _ in range(n)]
+        ok = [bool(rng.random() < 0.5) for _ in range(n)]
+        eb = [float(rng.choice([1.0, 1.2, 1.44])) for _ in range(n)]
+        pb = [float(rng.choice([1.0, 1.15])) for _ in range(n)]
+        for x, a1, a2, a3, a4, a5 in zip(c, sec, lex, ok, eb, pb):
+            x.update(_sec=a1, _lex=a2, _ok=a3, _eb=a4, _pb=a5)
+        must = ["x"] if t != 3 else None
+        self = types.SimpleNamespace(_calculate_vector_similarities=lambda q, cc, vs=vs: list(vs),
+                                     _calculate_bm25_similarities=lambda q, cc, bs=bs: list(bs),
+                                     section_filtering_enabled=(t != 1), lexical_fallback_enabled=True,
+                                     noise_threshold=0.35, listt5=None,
+                                     _apply_section_filtering=lambda cand, q: cand["_sec"],
+                                     _apply_lexical_fallback=lambda cand, terms: cand["_lex"],
+                                     _satisfies_must_have_terms=lambda cand, terms: cand["_ok"],
+                                     _calculate_entity_boost=lambda cand, e: cand["_eb"],
+                                     _calculate_predicate_boost=lambda cand, pr: cand["_pb"])
+        ents = ["e"] if t % 2 == 0 else None
+        preds = ["p"] if t < 3 else None
+        out = ns["_enhanced_hybrid_search_v2"](self, "query", [dict(x) for x in c], must, ents, preds)
+        cases.append({"name": f"v2_{t}", "kind": "v2", "noise_threshold": 0.35, "section_filtering_enabled": t != 1,
+                      "candidates": c, "vector_scores": vs, "bm25_scores": bs, "must_have_terms": must,
+                      "boost_entities": ents, "boost_predicates": preds,
+                      "expected": [{"note_id": x["note_id"], "final_base_score": x["final_base_score"]} for x in out]})
+    return cases
+
+
 def bm25_cases(bm):
     rng = random.Random(7)
     vocab = [f"w{i}" for i in range(300)] + ["natural", "language", "processing", "machine", "learning", "AI"]
@@ -237,6 +330,30 @@ def bm25_cases(bm):
         add(f"random_{t}", nn, qs)
     add("empty_docs", [{"title": "", "content": ""}, {"title": "a b", "content": "c"}, {"title": "", "content": ""}],
         ["a", "c b", "q"])
+    return cases
+
+
+def bm25_field_cases(bm):
+    """FieldWeightedBM25 (utils/bm25_search.py:66-234): title / entities / content with weights"""
+    rng = random.Random(11)
+    vocab = [f"w{i}" for i in range(120)]
+    cases = []
+
+    def add(name, notes, queries, weights=None):
+        corpus = bm.build_field_weighted_bm25_corpus(notes, weights)
+        cases.append({"name": name, "notes": notes, "queries": queries, "field_weights": weights,
+                      "raw": [corpus.get_scores(bm.tokenize_text(q)) for q in queries if bm.tokenize_text(q)],
+                      "expected": [bm.field_weighted_bm25_scores(corpus, notes, q) for q in queries]})
+
+    for t in range(4):
+        nn = []
+        for i in range(rng.randint(5, 50)):
+            nn.append({"title": " ".join(rng.choices(vocab, k=rng.randint(0, 4))),
+                       "entities": rng.choices(vocab, k=rng.randint(0, 3)) if rng.random() < 0.8 else "w1 w2",
+                       "content": " ".join(rng.choices(vocab, k=rng.randint(0, 30)))})
+        qs = [" ".join(rng.choices(vocab, k=rng.randint(1, 6))) for _ in range(5)] + ["", "w3 w3 w4"]
+        add(f"random_{t}", nn, qs, None if t % 2 == 0 else {"content": 1.0, "title": 3.0})
+    add("no_entities_anywhere", [{"title": "a b", "content": "c d a"}, {"title": "", "content": "a"}], ["a", "d q"])
     return cases
 
 
@@ -297,9 +414,18 @@ def main():
     with open(os.path.join(HERE, "bm25_cases.json"), "w") as f:
         json.dump({"source": "reference utils/bm25_search.py build_bm25_corpus + bm25_scores (SimpleBM25)",
                    "cases": bm25_cases(bm)}, f)
+    with open(os.path.join(HERE, "bm25_field_cases.json"), "w") as f:
+        json.dump({"source": "reference utils/bm25_search.py FieldWeightedBM25 / field_weighted_bm25_scores",
+                   "cases": bm25_field_cases(bm)}, f)
     with open(os.path.join(HERE, "fusion_long_cases.json"), "w") as f:
         json.dump({"source": "reference retrieval/hybrid_search.py HybridSearcher.fuse, full-corpus bm25 lists",
                    "cases": fusion_long_cases(hs)}, f)
+    with open(os.path.join(HERE, "candidate_fusion_cases.json"), "w") as f:
+        json.dump({"source": "reference query/query_processor.py QueryProcessor._hybrid_search / _enhanced_hybrid_search_v2 "
+                             "(method bodies compiled from the reference source as they stand)",
+                   "cases": candidate_fusion_cases()}, f)
+    sys.modules.pop("utils.bm25_search", None)
+    sys.modules.pop("utils", None)
     stub_utils_and_config()
     gr = load_graph_retriever()
     with open(os.path.join(HERE, "embedding_candidates_cases.json"), "w") as f:
@@ -309,7 +435,7 @@ def main():
     with open(os.path.join(HERE, "similarity_relation_cases.json"), "w") as f:
         json.dump({"source": "reference graph/relation_extractor.py extract_semantic_similarity_relations",
                    "cases": similarity_cases(rx)}, f)
-    print("wrote fusion_cases.json, fusion_long_cases.json, bm25_cases.json, embedding_candidates_cases.json, "
+    print("wrote candidate_fusion_cases.json, fusion_cases.json, fusion_long_cases.json, bm25_cases.json, embedding_candidates_cases.json, "
           "similarity_relation_cases.json")
 
 

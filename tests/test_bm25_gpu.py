@@ -56,3 +56,50 @@ def test_bm25_random_corpus_vs_oracle_and_sparse_form():
         assert np.array_equal(sc, norm[i][ids]) and np.all(np.diff(sc) <= 0)
     assert dev.get_scores(["zzz"]) == [0.0] * len(notes)
     dev.close()
+
+
+def _field_cases():
+    with open(os.path.join(GOLD, "bm25_field_cases.json")) as f:
+        return json.load(f)["cases"]
+
+
+@pytest.mark.parametrize("case", _field_cases(), ids=lambda c: c["name"])
+def test_field_weighted_bm25_matches_reference_golden(case):
+    """FieldWeightedBM25 (utils/bm25_search.py:66-234): per-field device scoring + the device combine, bit-exact"""
+    from anorag_hip import bm25_search as dbm
+    corpus = dbm.build_field_weighted_bm25_corpus(case["notes"], case["field_weights"])
+    raw = iter(case["raw"])
+    for q, exp in zip(case["queries"], case["expected"]):
+        assert dbm.field_weighted_bm25_scores(corpus, case["notes"], q) == exp
+        if dbm.tokenize_text(q):
+            assert corpus.get_scores(dbm.tokenize_text(q)) == next(raw)
+    corpus.close()
+
+
+def test_field_weighted_bm25_feeds_the_fusion_without_leaving_the_device():
+    """DeviceFieldWeightedBM25.scores_device -> HybridSearcher.fuse_arrays: the N-vector stays on the device"""
+    from anorag_hip import bm25_search as dbm
+    from oracle import fusion as ofu
+    from retrieval.hybrid_search import HybridSearcher
+    rng = np.random.default_rng(8)
+    vocab = [f"w{i}" for i in range(400)]
+    notes = [{"title": " ".join(rng.choice(vocab, 3)), "entities": list(rng.choice(vocab, 2)),
+              "content": " ".join(rng.choice(vocab, size=rng.integers(5, 40)))} for _ in range(9000)]
+    queries = [" ".join(rng.choice(vocab, size=4)) for _ in range(6)]
+    dev = dbm.build_field_weighted_bm25_corpus(notes)
+    ref = obm.build_field_weighted_bm25_corpus(notes)
+    arr = dev.scores_device([dbm.tokenize_text(q) for q in queries], normalize=True)
+    host = arr.numpy()
+    dense = [(rng.choice(9000, 50, replace=False).astype(np.int64), np.sort(rng.uniform(0.3, 0.9, 50))[::-1].copy())
+             for _ in queries]
+    w = {"dense": 1.0, "bm25": 0.5, "graph": 0.5, "path": 0.1}
+    hs = HybridSearcher({"retrieval": {"candidate_pool": 40, "hybrid": {"fusion_method": "rrf", "rrf_k": 60, "weights": w}}})
+    got = hs.fuse_arrays(len(queries), dense=dense, bm25=arr)
+    arr.free()
+    full = np.arange(9000, dtype=np.int64)
+    for i, q in enumerate(queries):
+        exp_scores = obm.field_weighted_bm25_scores(ref, notes, q)
+        assert host[i].tolist() == exp_scores
+        ids, fin = ofu.fuse_arrays(9000, (dense[i], (full, np.asarray(exp_scores)), None, None), [1.0, 0.5, 0.5, 0.1], "rrf", 60, 40)
+        assert [r["note_id"] for r in got[i]] == ids.tolist() and [r["final_similarity"] for r in got[i]] == fin.tolist()
+    dev.close()

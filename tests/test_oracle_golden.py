@@ -163,3 +163,13 @@ def test_embedding_candidates_oracle_matches_reference_golden(case):
     q = np.asarray(case["query"], dtype=np.float32)
     got = og.find_embedding_candidates(emb, q, case["top_k"])
     assert [f"note_{int(i):04d}" for i in got] == case["expected"]
+
+
+@pytest.mark.parametrize("case", _load("bm25_field_cases.json"), ids=lambda c: c["name"])
+def test_field_weighted_bm25_oracle_matches_reference(case):
+    corpus = obm.build_field_weighted_bm25_corpus(case["notes"], case["field_weights"])
+    raw = iter(case["raw"])
+    for q, exp in zip(case["queries"], case["expected"]):
+        assert obm.field_weighted_bm25_scores(corpus, case["notes"], q) == exp
+        if obm.tokenize_text(q):
+            assert corpus.get_scores(obm.tokenize_text(q)) == next(raw)
