@@ -26,6 +26,7 @@ OPT_ADD_RAW = 6
 OPT_STREAMS = 7
 OPT_ID_OFFSET = 8
 OPT_TINY = 9
+OPT_FUSED_POST = 10
 
 
 class AnoragError(RuntimeError):

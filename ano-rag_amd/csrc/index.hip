@@ -105,11 +105,13 @@ struct anr_index {
   hipEvent_t ev_call[2] = {nullptr, nullptr};
 
   // single-launch path for tiny corpora (tiny_kernels.hpp)
+  int fused_post = 1;                             // ANR_OPT_FUSED_POST
   int tiny = 1;                                   // ANR_OPT_TINY
   unsigned char *tiny_pin = nullptr, *tiny_pin_dev = nullptr;  // pinned: queries | D | I | completion words
   unsigned long long *tiny_cand = nullptr;        // [kTinyMaxQ][kTinyMaxWG][kTinyMaxK]
   unsigned *tiny_ticket = nullptr;                // [kTinyMaxQ]
   unsigned tiny_seq = 0;
+  unsigned long long *tiny_stamps = nullptr;      // developer aid: ANORAG_TINY_STAMPS=1 prints the kernel's phase times
 
   anr_search_stats stats{};
 };
@@ -243,6 +245,14 @@ int launch_select(int nblocks, const SelParams &sp, hipStream_t st) {
   const int nt = 1024;
   (void)n_hint;
   hipLaunchKernelGGL(k_select, dim3(nblocks), dim3(nt), sizeof(SelShared), st, sp);
+  ANR_HIP(hipGetLastError());
+  return ANR_OK;
+}
+
+int launch_post(int nblocks, const SelParams &sp, const PostParams &pp, hipStream_t st) {
+  ANR_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_post), (int)sizeof(SelShared)));
+  if (sp.G > kSelMaxLists) return fail(ANR_EINTERNAL, "select: too many candidate lists (%d)", sp.G);
+  hipLaunchKernelGGL(k_post, dim3(nblocks), dim3(1024), sizeof(SelShared), st, sp, pp);
   ANR_HIP(hipGetLastError());
   return ANR_OK;
 }
@@ -621,7 +631,7 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
     sp.n = h->ntotal;
     sp.row0 = 0;
     sp.row_tile_stride = 1;
-    ANR_TRY(launch_select(nq, sp, bs));
+    if (!h->fused_post) ANR_TRY(launch_select(nq, sp, bs));
   } else {
     ANR_TRY(ensure_dense(w, sample_tiles * kTileRows));
     ANR_TRY(ensure_cand(h, w));
@@ -679,7 +689,38 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
     sp.capb = (unsigned)h->cand_cap;
     sp.overflow = w.ncand + kQB;
     sp.ncand = w.ncand;
-    ANR_TRY(launch_select(nq, sp, bs));
+    if (!h->fused_post) ANR_TRY(launch_select(nq, sp, bs));
+  }
+
+  if (h->fused_post) {
+    // select + exact re-score + finalize in one launch per batch (k_post)
+    PostParams pp{};
+    pp.x32 = h->x32;
+    pp.q32 = w.q32;
+    pp.dim = h->dim;
+    pp.dimp = h->dimp;
+    pp.metric = h->metric;
+    pp.qstat = w.qstat;
+    pp.xstat = h->xstat;
+    pp.overflow = sparse ? w.ncand + kQB : nullptr;
+    pp.ncand = sparse ? w.ncand : nullptr;
+    pp.n_rows = h->ntotal;
+    pp.Mreq = M;
+    pp.k = k;
+    pp.nq = nq;
+    pp.out_off = out_off;
+    pp.D = D_dev;
+    pp.I = I_dev;
+    pp.flags = reinterpret_cast<int *>(w.ncand + 2 * kQB);
+    pp.theta = reinterpret_cast<float *>(w.ncand + 3 * kQB);
+    pp.id_offset = h->id_offset;
+    pp.status_host = w.cnt_dev;
+    pp.host_out = host_out ? 1 : 0;
+    ANR_TRY(launch_post(nq, sp, pp, bs));
+    ANR_HIP(hipEventRecord(w.ev_done, bs));
+    w.in_flight = true;
+    ANR_HIP(hipStreamWaitEvent(user, w.ev_done, 0));
+    return ANR_OK;
   }
 
   RescoreParams rp{};
@@ -832,6 +873,7 @@ int search_tiny(anr_index *h, const float *q, int64_t nq, int32_t k, float *D, i
     memset(h->tiny_pin + f_off, 0, 64);
     ANR_TRY(dev_alloc(&h->tiny_cand, (int64_t)kTinyMaxQ * kTinyMaxMerge, true));
     ANR_TRY(dev_alloc(&h->tiny_ticket, kTinyMaxQ, true));
+    if (getenv("ANORAG_TINY_STAMPS")) ANR_TRY(dev_alloc(&h->tiny_stamps, 16, true));
   }
   memcpy(h->tiny_pin, q, (size_t)nq * h->dim * sizeof(float));
   TinyParams tp{};
@@ -856,9 +898,22 @@ int search_tiny(anr_index *h, const float *q, int64_t nq, int32_t k, float *D, i
   if (++h->tiny_seq == 0) h->tiny_seq = 1;
   tp.seq = h->tiny_seq;
   tp.id_offset = h->id_offset;
+  tp.stamps = h->tiny_stamps;
   const size_t lds = (size_t)kTinyMaxMerge * 8 + (size_t)round_up(h->dim, 4) * sizeof(float);
-  ANR_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_tiny_search), (int)lds));
-  hipLaunchKernelGGL(k_tiny_search, dim3((unsigned)tp.n_wg, (unsigned)nq), dim3(kTinyThreads), lds, h->stream, tp);
+  const int kc = (h->dim % 4 == 0 && h->dim <= 1024) ? (int)ceil_div(h->dim / 4, 64) : 0;
+#define ANR_TINY_LAUNCH(KC)                                                                                   \
+  {                                                                                                           \
+    ANR_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_tiny_search<KC>), (int)lds));                 \
+    hipLaunchKernelGGL(k_tiny_search<KC>, dim3((unsigned)tp.n_wg, (unsigned)nq), dim3(kTinyThreads), lds, h->stream, tp); \
+  }
+  switch (kc) {
+    case 1: ANR_TINY_LAUNCH(1) break;
+    case 2: ANR_TINY_LAUNCH(2) break;
+    case 3: ANR_TINY_LAUNCH(3) break;
+    case 4: ANR_TINY_LAUNCH(4) break;
+    default: ANR_TINY_LAUNCH(0) break;
+  }
+#undef ANR_TINY_LAUNCH
   ANR_HIP(hipGetLastError());
   // completion: spin on the words the last workgroups write into pinned memory (an event / stream wait costs more
   // than the whole kernel); after ~2 s fall back to the stream so a device fault surfaces as an error
@@ -874,6 +929,14 @@ int search_tiny(anr_index *h, const float *q, int64_t nq, int32_t k, float *D, i
         break;
       }
     }
+  }
+  if (h->tiny_stamps && (h->tiny_seq & 127) == 0) {
+    unsigned long long st[16];
+    ANR_HIP(hipStreamSynchronize(h->stream));
+    ANR_HIP(hipMemcpy(st, h->tiny_stamps, sizeof st, hipMemcpyDeviceToHost));
+    auto us = [&](int a, int b) { return (double)((long long)st[b] - (long long)st[a]) / 100.0; };  // 100 MHz clock
+    fprintf(stderr, "[tiny] wg0: query %.2f norm %.2f score %.2f rank+publish %.2f ticket %.2f | last: start+%.2f load %.2f "
+                    "merge %.2f fence %.2f us\n", us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5), us(0, 8), us(8, 9), us(9, 10), us(10, 11));
   }
   memcpy(D, h->tiny_pin + d_off, (size_t)nq * k * sizeof(float));
   memcpy(I, h->tiny_pin + i_off, (size_t)nq * k * sizeof(int64_t));
@@ -1073,6 +1136,7 @@ int anr_index_destroy(anr_index *h) {
   if (h->tiny_pin) (void)hipHostFree(h->tiny_pin);
   dev_free(h->tiny_cand);
   dev_free(h->tiny_ticket);
+  dev_free(h->tiny_stamps);
   for (auto &e : h->ev_call)
     if (e) (void)hipEventDestroy(e);
   for (hipStream_t s : {h->bstream[0], h->bstream[1], h->bstream[2], h->stream})
@@ -1387,6 +1451,7 @@ int anr_index_set_option(anr_index *h, int32_t opt, int64_t value) {
       h->id_offset = value;
       break;
     case ANR_OPT_TINY: h->tiny = value != 0; break;
+    case ANR_OPT_FUSED_POST: h->fused_post = value != 0; break;
     case ANR_OPT_STREAMS:
       if (value < 1 || value > kWorkspaces) return fail(ANR_EINVAL, "streams must be in 1..%d", kWorkspaces);
       h->n_streams = (int)value;

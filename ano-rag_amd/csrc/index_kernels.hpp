@@ -536,18 +536,11 @@ __device__ __forceinline__ unsigned long long sel_key(const SelParams &p, const 
   return make_key(__uint_as_float(c.x), c.y);
 }
 
-__global__ __launch_bounds__(1024) void k_select(SelParams p) {
-  extern __shared__ unsigned char sel_smem[];
-  SelShared &sh = *reinterpret_cast<SelShared *>(sel_smem);
+// The selection itself: leaves the M best keys, ordered best first, in sh.srt[0, M) and returns M (the same value in
+// every thread; 0 when the query has no entry).  All threads of the workgroup call it.
+__device__ __forceinline__ int sel_run(const SelParams &p, SelShared &sh, const int q) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int NT = blockDim.x, NW = NT >> 6;
-  const int q = p.qslots ? p.qslots[blockIdx.x] : blockIdx.x;
-  if (p.ladder && p.live_q > 0 && q >= p.live_q) {
-    if (tid == 0) p.out_m[q] = 0;
-    if (tid < kLadder) p.ladder[q * kLadder + tid] = __builtin_inff();
-    if (p.lvl_init && tid == 0) p.lvl_init[q] = p.lvl_init_value;
-    return;
-  }
   int64_t n;
   if (p.dense) {
     n = p.n;
@@ -587,12 +580,7 @@ __global__ __launch_bounds__(1024) void k_select(SelParams p) {
     }
   }
   int M = (int)((int64_t)p.M < n ? (int64_t)p.M : n);
-  if (M == 0) {
-    if (tid == 0) p.out_m[q] = 0;
-    if (p.ladder && tid < kLadder) p.ladder[q * kLadder + tid] = -__builtin_inff();
-    if (p.lvl_init && tid == 0) p.lvl_init[q] = p.lvl_init_value;
-    return;
-  }
+  if (M == 0) return 0;
   const bool staged = n <= kSelLds;
   if (tid == 0) sh.cnt = 0;
   __syncthreads();
@@ -641,8 +629,6 @@ __global__ __launch_bounds__(1024) void k_select(SelParams p) {
   }
   __syncthreads();
   int koff = 0;
-  if (tid == 0) p.out_m[q] = M;
-  if (M == 0) return;
   kmin = sh.red[0][0];
   kmax = sh.red[0][1];
   for (int w = 1; w < NW; ++w) {
@@ -774,6 +760,13 @@ __global__ __launch_bounds__(1024) void k_select(SelParams p) {
   }
   __syncthreads();
   }
+  return M;
+}
+
+// write a selection out: (rank value, row) pairs, their count, and (ladder mode) the threshold ladder
+__device__ __forceinline__ void sel_write(const SelParams &p, const SelShared &sh, const int q, const int M) {
+  const int tid = threadIdx.x, NT = blockDim.x;
+  if (tid == 0) p.out_m[q] = M;
   for (int i = tid; i < M; i += NT) {
     const unsigned long long k = sh.srt[i];
     float v = ord2f((unsigned)(k >> 32));
@@ -782,12 +775,185 @@ __global__ __launch_bounds__(1024) void k_select(SelParams p) {
   }
   if (p.lvl_init && tid == 0) p.lvl_init[q] = p.lvl_init_value;
   if (p.ladder && tid < kLadder) {
-    // level j = value of rank max(1, M >> j) (1-based) of the sample: ascending in j
-    int rk = M >> tid;
-    if (rk < 1 || tid == kLadder - 1) rk = 1;
-    p.ladder[q * kLadder + tid] = ord2f((unsigned)(sh.srt[rk - 1] >> 32));
+    if (M == 0) {
+      p.ladder[q * kLadder + tid] = -__builtin_inff();
+    } else {
+      // level j = value of rank max(1, M >> j) (1-based) of the sample: ascending in j
+      int rk = M >> tid;
+      if (rk < 1 || tid == kLadder - 1) rk = 1;
+      p.ladder[q * kLadder + tid] = ord2f((unsigned)(sh.srt[rk - 1] >> 32));
+    }
   }
 }
+
+__global__ __launch_bounds__(1024) void k_select(SelParams p) {
+  extern __shared__ unsigned char sel_smem[];
+  SelShared &sh = *reinterpret_cast<SelShared *>(sel_smem);
+  const int tid = threadIdx.x;
+  const int q = p.qslots ? p.qslots[blockIdx.x] : blockIdx.x;
+  if (p.ladder && p.live_q > 0 && q >= p.live_q) {
+    if (tid == 0) p.out_m[q] = 0;
+    if (tid < kLadder) p.ladder[q * kLadder + tid] = __builtin_inff();
+    if (p.lvl_init && tid == 0) p.lvl_init[q] = p.lvl_init_value;
+    return;
+  }
+  const int M = sel_run(p, sh, q);
+  sel_write(p, sh, q, M);
+}
+
+// ------------------------------------------------------------------------------------------------
+// post: select + exact re-score + finalize of one query in ONE workgroup (the three launches k_select, k_rescore,
+// k_finalize of the pipeline fused: two launch gaps and two round trips through HBM less per batch).  After the
+// selection the M candidate rows are re-scored exactly by the workgroup's 16 waves (f32 rows, f64 accumulation in
+// k_rescore's order: bit-identical values), ranked by (exact, id), written out as the top-k, and thread 0 decides the
+// certificate exactly as k_finalize does.
+// ------------------------------------------------------------------------------------------------
+struct PostParams {
+  const float *x32;
+  const float *q32;          // [64][dimp]
+  int dim, dimp, metric;
+  const float *qstat;        // [64][4]
+  const unsigned *xstat;
+  const unsigned *overflow;  // may be null: [64] set by the selection when a candidate list overflowed
+  const unsigned *ncand;     // may be null
+  int64_t n_rows;
+  int Mreq, k, nq;
+  int64_t out_off;
+  float *D;
+  int64_t *I;
+  int *flags;
+  float *theta;
+  int64_t id_offset;
+  unsigned *status_host;
+  int host_out;
+};
+
+__global__ __launch_bounds__(1024) void k_post(SelParams p, PostParams pp) {
+  extern __shared__ unsigned char sel_smem[];
+  SelShared &sh = *reinterpret_cast<SelShared *>(sel_smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = blockIdx.x;
+  const int m = sel_run(p, sh, q);  // sh.srt[0, m): (approximate rank score, row) best first
+  __syncthreads();
+  float approx_last = 0.f;
+  if (m > 0) {
+    const float v = ord2f((unsigned)(sh.srt[m - 1] >> 32));
+    approx_last = p.negate ? -v : v;
+  }
+  // ---- exact value of every candidate row: one wave per row, four rows in flight per wave --------------------
+  const float *qv = pp.q32 + (int64_t)q * pp.dimp;
+  constexpr int RB = 4, NW = 16;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  for (int j0 = wave; j0 < m; j0 += NW * RB) {
+    double acc[RB];
+    unsigned row[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      acc[r] = 0.0;
+      const int j = j0 + r * NW < m ? j0 + r * NW : j0;
+      row[r] = 0xffffffffu - (unsigned)(sh.srt[j] & 0xffffffffu);
+    }
+    if ((pp.dim & 3) == 0) {
+      const f32x4 *q4 = reinterpret_cast<const f32x4 *>(qv);
+      const int n4 = pp.dim >> 2;
+      for (int k = lane; k < n4; k += 64) {
+        const f32x4 b = q4[k];
+        f32x4 a[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+          a[r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(pp.x32 + (int64_t)row[r] * pp.dim) + k);
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+          if (pp.metric == 0) {
+            acc[r] += (double)a[r].x * (double)b.x;
+            acc[r] += (double)a[r].y * (double)b.y;
+            acc[r] += (double)a[r].z * (double)b.z;
+            acc[r] += (double)a[r].w * (double)b.w;
+          } else {
+            const double d0 = (double)b.x - (double)a[r].x, d1 = (double)b.y - (double)a[r].y;
+            const double d2 = (double)b.z - (double)a[r].z, d3 = (double)b.w - (double)a[r].w;
+            acc[r] += d0 * d0;
+            acc[r] += d1 * d1;
+            acc[r] += d2 * d2;
+            acc[r] += d3 * d3;
+          }
+        }
+      }
+    } else {
+      for (int k = lane; k < pp.dim; k += 64) {
+        const double b = (double)qv[k];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+          const double a = (double)pp.x32[(int64_t)row[r] * pp.dim + k];
+          if (pp.metric == 0) acc[r] += a * b;
+          else acc[r] += (b - a) * (b - a);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      for (int off = 32; off > 0; off >>= 1) acc[r] += __shfl_xor(acc[r], off);
+      if (lane == 0 && j0 + r * NW < m) {
+        const float e = (float)acc[r];
+        sh.sel[j0 + r * NW] = make_key(pp.metric == 0 ? e : -e, row[r]);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- order by (exact, id): rank counting into the (now free) key staging area --------------------------------
+  unsigned long long *sorted = sh.keys;
+  for (int i = tid; i < m; i += 1024) {
+    const unsigned long long k = sh.sel[i];
+    int rank = 0;
+#pragma unroll 16
+    for (int j = 0; j < m; ++j) rank += (sh.sel[j] > k) ? 1 : 0;
+    sorted[rank] = k;
+  }
+  __syncthreads();
+  const int kk = pp.k < m ? pp.k : m;
+  float *D = pp.D + (pp.out_off + q) * (int64_t)pp.k;
+  int64_t *I = pp.I + (pp.out_off + q) * (int64_t)pp.k;
+  for (int i = tid; i < pp.k; i += 1024) {
+    if (i < kk) {
+      const unsigned long long k = sorted[i];
+      const float v = ord2f((unsigned)(k >> 32));
+      D[i] = pp.metric == 0 ? v : -v;
+      I[i] = (int64_t)(0xffffffffu - (unsigned)(k & 0xffffffffu)) + pp.id_offset;
+    } else {
+      D[i] = pp.metric == 0 ? -3.402823466e+38f : 3.402823466e+38f;
+      I[i] = -1;
+    }
+  }
+  if (pp.host_out) __threadfence_system();
+  if (tid == 0) {  // the certificate: identical to k_finalize
+    int flag = 0;
+    float theta = -__builtin_inff();
+    const bool ovf = pp.overflow && pp.overflow[q];
+    if (ovf) flag = 1;
+    if (kk > 0 && (int64_t)m < pp.n_rows) {
+      const float xmax = __uint_as_float(pp.xstat[0]), xerr = __uint_as_float(pp.xstat[1]);
+      const float qn = pp.qstat[q * 4 + 0], qh = pp.qstat[q * 4 + 1], qe = pp.qstat[q * 4 + 2];
+      double eps = (double)xerr * qh + (double)xmax * qe + 2.0 * pp.dimp * 5.9604645e-8 * (double)xmax * qn;
+      if (pp.metric != 0) eps += 1e-6 * (double)xmax * (double)xmax;
+      const double bound = (double)approx_last + eps;
+      double kth = (double)ord2f((unsigned)(sorted[kk - 1] >> 32));
+      if (pp.metric != 0) kth = 0.5 * (kth + (double)pp.qstat[q * 4 + 3]);
+      if (m < pp.Mreq || !(bound < kth)) flag = 1;
+      if (m >= pp.Mreq && kk < pp.k) flag = 1;
+      if (kk >= pp.k && !ovf) theta = (float)(kth - eps - 1e-6 * (fabs(kth) + 1.0));
+    }
+    pp.flags[q] = flag;
+    if (pp.theta) pp.theta[q] = theta;
+    if (pp.status_host) {
+      pp.status_host[q] = pp.ncand ? pp.ncand[q] : 0u;
+      pp.status_host[kQB + q] = ovf ? 1u : 0u;
+      pp.status_host[2 * kQB + q] = (unsigned)flag;
+      pp.status_host[3 * kQB + q] = __float_as_uint(theta);
+      __threadfence_system();
+    }
+  }
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // rescore: one wave per (query, candidate): exact value from the f32 rows, f64 accumulation

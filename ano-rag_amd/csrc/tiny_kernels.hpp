@@ -14,7 +14,7 @@
 namespace anr {
 
 constexpr int kTinyThreads = 1024;
-constexpr int kTinyMaxWG = 64;
+constexpr int kTinyMaxWG = 128;
 constexpr int kTinyMaxK = 128;
 constexpr int kTinyMaxQ = 4;
 constexpr int kTinyRowsPerWG = 1024;   // rows a workgroup ranks among themselves
@@ -33,8 +33,13 @@ struct TinyParams {
   unsigned *flag;            // pinned host [nq]: set to seq when query q is complete
   unsigned seq;
   int64_t id_offset;
+  unsigned long long *stamps;  // developer aid (ANORAG_TINY_STAMPS): [16] wall-clock stamps of workgroup 0 / the last one
 };
 
+#define TINY_STAMP(slot, cond) do { if (p.stamps && (cond) && threadIdx.x == 0) p.stamps[slot] = wall_clock64(); } while (0)
+
+// KC: 16-byte chunks per lane of one row (dim / 4 <= 64 KC), 0 = generic path (dim not a multiple of 4, or > 1024)
+template <int KC>
 __global__ __launch_bounds__(kTinyThreads) void k_tiny_search(TinyParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tiny_smem[];
   unsigned long long *s_keys = reinterpret_cast<unsigned long long *>(tiny_smem);             // [kTinyMaxMerge]
@@ -42,12 +47,37 @@ __global__ __launch_bounds__(kTinyThreads) void k_tiny_search(TinyParams p) {
   __shared__ double s_red[4];
   __shared__ float s_scale;
   __shared__ int s_last;
+  __shared__ unsigned long long s_rank[kTinyMaxK];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = blockIdx.y, wg = blockIdx.x;
   const float *qin = p.q_host + (int64_t)q * p.dim;
+  const bool w0 = wg == 0 && q == 0;
+  TINY_STAMP(0, w0);
+  const int64_t row0 = (int64_t)wg * p.rows_per_wg;
+  const int rows = (int)(row0 + p.rows_per_wg <= p.n_rows ? p.rows_per_wg : (p.n_rows > row0 ? p.n_rows - row0 : 0));
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  // rows in flight per wave: a 1024-thread workgroup leaves 128 VGPRs per lane (RB x KC x 4 of them hold row chunks)
+  constexpr int NW = kTinyThreads / 64, RB = KC <= 1 ? 8 : (KC == 2 ? 6 : (KC == 3 ? 4 : 3)), KCA = KC > 0 ? KC : 1;
+  const int n4 = p.dim >> 2;
+  f32x4 a[RB][KCA];
+  auto load_rows = [&](int r0) {  // all RB x KC row chunks of this wave's next rows in flight at once
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const int rr = r0 + r < rows ? r0 + r : rows - 1;  // clamped: the duplicate is discarded below
+      const f32x4 *x4 = reinterpret_cast<const f32x4 *>(p.x32 + (row0 + rr) * p.dim);
+#pragma unroll
+      for (int c = 0; c < KCA; ++c) {
+        const int k = lane + 64 * c;
+        a[r][c] = x4[k < n4 ? k : n4 - 1];  // out-of-range chunks re-read the last one and are skipped below
+      }
+    }
+  };
+  // the first rows are requested BEFORE the query is fetched from host memory and normalised: the two latencies overlap
+  if (KC > 0 && wave * RB < rows) load_rows(wave * RB);
   // --- the query: raw copy from host memory, norm in k_prepq's order (256 threads, f64), divide -------------
   for (int k = tid; k < p.dim; k += kTinyThreads) s_q[k] = qin[k];
   __syncthreads();
+  TINY_STAMP(1, w0);
   if (tid < 256) {
     double acc = 0.0;
     for (int k = tid; k < p.dim; k += 256) {
@@ -66,37 +96,38 @@ __global__ __launch_bounds__(kTinyThreads) void k_tiny_search(TinyParams p) {
   const float scale = s_scale;
   for (int k = tid; k < p.dim; k += kTinyThreads) s_q[k] = s_q[k] / scale;
   __syncthreads();
-  // --- exact scores of this workgroup's rows: one wave per row, 8 rows in flight per wave ---------------------
-  const int64_t row0 = (int64_t)wg * p.rows_per_wg;
-  const int rows = (int)(row0 + p.rows_per_wg <= p.n_rows ? p.rows_per_wg : (p.n_rows > row0 ? p.n_rows - row0 : 0));
+  TINY_STAMP(2, w0);
+  // --- exact scores of this workgroup's rows: one wave per row, RB rows in flight per wave, every row load issued
+  //     before the first use (the loop over a row's chunks is unrolled by the template: a data-dependent trip count
+  //     would serialise the loads behind each other's latency) -----------------------------------------------------
   unsigned long long *s_rowkey = s_keys;  // [rows] while ranking (rows <= kTinyRowsPerWG <= kTinyMaxMerge)
-  typedef float f32x4 __attribute__((ext_vector_type(4)));
-  constexpr int NW = kTinyThreads / 64, RB = 8;
   for (int r0 = wave * RB; r0 < rows; r0 += NW * RB) {
     double acc[RB];
 #pragma unroll
     for (int r = 0; r < RB; ++r) acc[r] = 0.0;
-    if ((p.dim & 3) == 0) {
+    if (KC > 0) {
       const f32x4 *q4 = reinterpret_cast<const f32x4 *>(s_q);
-      const int n4 = p.dim >> 2;
-      for (int k = lane; k < n4; k += 64) {
-        const f32x4 b = q4[k];
+      if (r0 != wave * RB) load_rows(r0);
 #pragma unroll
-        for (int r = 0; r < RB; ++r) {
-          const int rr = r0 + r < rows ? r0 + r : rows - 1;  // clamped: the duplicate is discarded below
-          const f32x4 a = *reinterpret_cast<const f32x4 *>(p.x32 + (row0 + rr) * p.dim + 4 * k);
-          if (p.metric == 0) {
-            acc[r] += (double)a.x * (double)b.x;
-            acc[r] += (double)a.y * (double)b.y;
-            acc[r] += (double)a.z * (double)b.z;
-            acc[r] += (double)a.w * (double)b.w;
-          } else {
-            const double d0 = (double)b.x - (double)a.x, d1 = (double)b.y - (double)a.y;
-            const double d2 = (double)b.z - (double)a.z, d3 = (double)b.w - (double)a.w;
-            acc[r] += d0 * d0;
-            acc[r] += d1 * d1;
-            acc[r] += d2 * d2;
-            acc[r] += d3 * d3;
+      for (int c = 0; c < KC; ++c) {
+        const int k = lane + 64 * c;
+        if (k < n4) {
+          const f32x4 b = q4[k];
+#pragma unroll
+          for (int r = 0; r < RB; ++r) {
+            if (p.metric == 0) {
+              acc[r] += (double)a[r][c].x * (double)b.x;
+              acc[r] += (double)a[r][c].y * (double)b.y;
+              acc[r] += (double)a[r][c].z * (double)b.z;
+              acc[r] += (double)a[r][c].w * (double)b.w;
+            } else {
+              const double d0 = (double)b.x - (double)a[r][c].x, d1 = (double)b.y - (double)a[r][c].y;
+              const double d2 = (double)b.z - (double)a[r][c].z, d3 = (double)b.w - (double)a[r][c].w;
+              acc[r] += d0 * d0;
+              acc[r] += d1 * d1;
+              acc[r] += d2 * d2;
+              acc[r] += d3 * d3;
+            }
           }
         }
       }
@@ -122,6 +153,7 @@ __global__ __launch_bounds__(kTinyThreads) void k_tiny_search(TinyParams p) {
     }
   }
   __syncthreads();
+  TINY_STAMP(3, w0);
   // --- the workgroup's k best (rank counting among its rows), published as its partial list --------------------
   unsigned long long *mine = p.cand + ((int64_t)q * p.n_wg + wg) * p.k;
   unsigned long long mykey = 0ull;
@@ -137,44 +169,68 @@ __global__ __launch_bounds__(kTinyThreads) void k_tiny_search(TinyParams p) {
     __hip_atomic_store(mine + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains before the ticket
   __syncthreads();
+  TINY_STAMP(4, w0);
   if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the partial lists were stored write-through (agent-scope atomic stores, drained above) and are read back with
+    // agent-scope atomic loads only, so neither a release nor an acquire fence is needed around the ticket
+    // (cdna_hip_programming.md, Guideline 16, R1)
     const unsigned t = __hip_atomic_fetch_add(p.ticket + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = (t == (unsigned)(p.n_wg - 1)) ? 1 : 0;
-    if (s_last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
   }
   __syncthreads();
+  TINY_STAMP(5, w0);
   if (!s_last) return;
+  TINY_STAMP(8, q == 0);
   // --- the last workgroup merges n_wg * k <= kTinyMaxMerge entries, ranks them, writes host memory ----------------
   const int M = p.n_wg * p.k;
   const unsigned long long *all = p.cand + (int64_t)q * p.n_wg * p.k;
   for (int i = tid; i < M; i += kTinyThreads)
     s_keys[i] = __hip_atomic_load(all + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
+  TINY_STAMP(9, q == 0);
   float *D = p.D + (int64_t)q * p.k;
   int64_t *I = p.I + (int64_t)q * p.k;
   const int64_t found = p.n_rows < p.k ? p.n_rows : p.k;
+  // every partial list is sorted (best first, empty slots = 0 at its end): the global rank of an entry is its own
+  // position plus, for every other list, the number of entries ahead of it there — a binary search per list
   for (int i = tid; i < M; i += kTinyThreads) {
     const unsigned long long key = s_keys[i];
     if (key == 0ull) continue;
-    int rank = 0;
-    for (int j = 0; j < M; ++j) rank += (s_keys[j] > key) ? 1 : 0;
-    if (rank < p.k) {
-      const float v = ord2f((unsigned)(key >> 32));
-      D[rank] = p.metric == 0 ? v : -v;
-      I[rank] = (int64_t)(0xffffffffu - (unsigned)(key & 0xffffffffu)) + p.id_offset;
+    const int li = i / p.k;
+    int rank = i - li * p.k;
+    for (int l = 0; l < p.n_wg && rank < p.k; ++l) {
+      if (l == li) continue;
+      const unsigned long long *L = s_keys + l * p.k;
+      int lo = 0, hi = p.k;  // entries [0, lo) are greater than key
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (L[mid] > key) lo = mid + 1;
+        else hi = mid;
+      }
+      rank += lo;
     }
+    if (rank < p.k) s_rank[rank] = key;  // ranks are distinct: one writer per slot
   }
-  for (int i = (int)found + tid; i < p.k; i += kTinyThreads) {  // fewer rows than k: faiss padding
-    D[i] = p.metric == 0 ? -3.402823466e+38f : 3.402823466e+38f;
-    I[i] = -1;
-  }
-  __threadfence_system();
   __syncthreads();
+  // one wave writes the k results into pinned host memory and fences them ONCE at system scope (a fence per writing
+  // thread, or system-scope atomic stores, cost 5-10 us apiece here)
+  if (wave == 0) {
+    for (int i = lane; i < p.k; i += 64) {
+      if (i < (int)found) {
+        const unsigned long long key = s_rank[i];
+        const float v = ord2f((unsigned)(key >> 32));
+        D[i] = p.metric == 0 ? v : -v;
+        I[i] = (int64_t)(0xffffffffu - (unsigned)(key & 0xffffffffu)) + p.id_offset;
+      } else {  // fewer rows than k: faiss padding
+        D[i] = p.metric == 0 ? -3.402823466e+38f : 3.402823466e+38f;
+        I[i] = -1;
+      }
+    }
+    __threadfence_system();
+  }
+  TINY_STAMP(10, q == 0);
+  __syncthreads();
+  TINY_STAMP(11, q == 0);
   if (tid == 0) {
     __hip_atomic_store(p.ticket + q, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next call
     __hip_atomic_store(p.flag + q, p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -121,6 +121,8 @@ int anr_index_self_join(anr_index *h, float threshold, int64_t cap, int64_t *I_h
 #define ANR_OPT_ID_OFFSET 8       /* added to every returned id: the first global row of this shard (default 0) */
 #define ANR_OPT_TINY 9            /* 1 (default): host-buffer searches of <= 4 queries, k <= 128, over a corpus of <= 32 MB run as ONE
                                      kernel launch (exact f32 rows / f64 accumulate; completion by a word in pinned memory) */
+#define ANR_OPT_FUSED_POST 10     /* 1 (default): candidate select + exact re-score + finalize run as ONE kernel per batch; 0: the
+                                     three separate launches (developer A/B switch, identical results) */
 int anr_index_set_option(anr_index *h, int32_t opt, int64_t value);
 
 typedef struct anr_search_stats {

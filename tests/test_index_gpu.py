@@ -540,3 +540,31 @@ def test_tiny_corpus_single_launch_path_equals_the_pipeline_and_the_oracle():
     idx.search(q[:1], 10)
     assert idx.last_stats()["n_dense_exact"] == 0
     idx.close()
+
+
+def test_fused_post_kernel_equals_the_three_launch_pipeline():
+    """k_post (select + exact re-score + finalize in one launch) against the separate k_select / k_rescore / k_finalize
+    launches (ANR_OPT_FUSED_POST = 0): identical bits — threshold-gated scan, dense small-corpus scan, L2, and tight
+    clusters whose certificates fail (so flags / theta feed the recovery pass)"""
+    from anorag_hip import FlatIndex, METRIC_IP, METRIC_L2
+    from anorag_hip._lib import OPT_FUSED_POST, OPT_TINY
+    rng = np.random.default_rng(3)
+    cent = rng.standard_normal((200, 256)).astype(np.float32)
+    cl = (cent[rng.integers(0, 200, 120_000)] + 0.02 * rng.standard_normal((120_000, 256))).astype(np.float32)
+    clq = (cent[rng.integers(0, 200, 64)] + 0.02 * rng.standard_normal((64, 256))).astype(np.float32)
+    cases = [(_data(150_000, 768, 64), METRIC_IP, True, 100), (_data(3_000, 384, 17), METRIC_IP, True, 10),
+             (_data(90_000, 130, 33), METRIC_L2, False, 50), ((cl, clq), METRIC_IP, True, 50)]
+    for (x, q), metric, norm, k in cases:
+        res = []
+        for fused in (1, 0):
+            idx = FlatIndex(x.shape[1], metric, normalize=norm)
+            idx.set_option(OPT_TINY, 0)
+            idx.set_option(OPT_FUSED_POST, fused)
+            idx.add(x)
+            D, I = idx.search(q, k)
+            res.append((D, I, idx.last_stats()))
+            idx.close()
+        assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][0], res[1][0])
+        for key in ("n_fallback", "n_candidates", "n_from_lists", "n_dense_exact"):
+            assert res[0][2][key] == res[1][2][key], (key, res[0][2], res[1][2])
+    assert res[0][2]["n_fallback"] > 0     # the clustered case exercised the failed-certificate hand-off
