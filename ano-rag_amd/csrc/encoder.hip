@@ -16,6 +16,7 @@
 // consume them as is.  GEMMs run "token on lane" (C^T = W * act^T); V is projected with the operands
 // swapped so that it lands "feature on lane, keys in k" — the A operand P*V needs.
 // f16 operands, f32 accumulation, f32 residual stream and LayerNorm.
+#include <algorithm>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -347,6 +348,26 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + copysignf(erf_abs, x));
 }
 
+// The epilogue's form: Phi(x) - 0.5 = x Q(x^2) with Q a degree-8 polynomial in t = 2 x^2 / 4.5^2 - 1 (weighted minimax
+// fit on |x| <= 4.5, beyond which Phi is held at its edge value), |gelu_poly - gelu| <= 6e-5 for every float32 x in
+// [-14, 14] — a sixteenth of an f16 ulp at 1.0, the format the value is stored in.  13 plain VALU operations and no
+// transcendental: the erf form's reciprocal (compiled to the IEEE division sequence), exponential and select made the
+// GELU epilogue cost as many cycles as the tile's MFMAs (2900 VALU instructions per lane and tile).
+__device__ __forceinline__ float gelu_poly(float x) {
+  const float xc = __builtin_amdgcn_fmed3f(x, -4.5f, 4.5f);
+  const float t = fmaf(xc * xc, 0.09876543209876543f, -1.0f);
+  float q = 0.00335475942119956f;
+  q = fmaf(q, t, -0.009329607710242271f);
+  q = fmaf(q, t, 0.012207310646772385f);
+  q = fmaf(q, t, -0.016742795705795288f);
+  q = fmaf(q, t, 0.027629755437374115f);
+  q = fmaf(q, t, -0.0405561588704586f);
+  q = fmaf(q, t, 0.05481854826211929f);
+  q = fmaf(q, t, -0.0771719291806221f);
+  q = fmaf(q, t, 0.15690211951732635f);
+  return x * fmaf(xc, q, 0.5f);
+}
+
 // epilogue of one 32 x 32 accumulator tile (token block tb, feature block nb)
 template <int EPI>
 __device__ __forceinline__ void gemm_store_tile(const GemmParams &p, const floatx16 &c, int64_t tb, int nb, int lane) {
@@ -376,7 +397,7 @@ __device__ __forceinline__ void gemm_store_tile(const GemmParams &p, const float
       } else {
         half8 hv;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) hv[j] = (_Float16)(EPI == EPI_GELU ? gelu_erf(o[j]) : o[j]);
+        for (int j = 0; j < 8; ++j) hv[j] = (_Float16)(EPI == EPI_GELU ? gelu_poly(o[j]) : o[j]);
         *reinterpret_cast<half8 *>(p.out + e) = hv;
       }
     }
@@ -605,6 +626,10 @@ __global__ __launch_bounds__(256) void k_gemm_lds(GemmParams p) {
 // When 3 x (8 + TN) fragments do not divide over the 8 waves, the surplus copies repeat the first fragments
 // (same bytes to the same LDS address).
 __device__ __forceinline__ void gemm_glds16(const uint4 *g, uint4 *l) { __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0); }
+// keep a value alive in an ablated build (plain __device__ functions: an asm with a "v" constraint written directly in
+// a __global__ template breaks the host-side instantiation, like the builtin above)
+__device__ __forceinline__ void gemm_keep(const half8 &x) { asm volatile("" ::"v"(x)); }
+__device__ __forceinline__ void gemm_keep(const floatx16 &x) { asm volatile("" ::"v"(x)); }
 
 template <int EPI, int TN, int S>
 __global__ __launch_bounds__(512) void k_gemm_lds8(GemmParams p) {
@@ -686,6 +711,133 @@ __global__ __launch_bounds__(512) void k_gemm_lds8(GemmParams p) {
       const int nb = nb0 + NW * wn + n;
       if (tb < p.TB && nb < p.NB) gemm_store_tile<EPI>(p, acc[m][n], tb, nb, lane);
     }
+}
+
+// ---- ping-pong form of the 8-wave GEMM --------------------------------------------------------------------
+// Same tile (256 tokens x 32 TN features, 4 x 2 waves, 64 x (16 TN) per wave), same operand layouts; what changes
+// is the schedule.  A k-step (K = 16) is one PHASE per wave:
+//     load segment : 6 ds_read_b128 (its 2 + TN/2 operand fragments of this k-step), 2 global_load_lds (its share
+//                    of the k-step PF ahead), counted s_waitcnt vmcnt   -> s_barrier
+//     MFMA segment : s_waitcnt lgkmcnt(0), s_setprio 1, 2 x TN/2 MFMAs (256 cycles at TN = 8), s_setprio 0 -> s_barrier
+// and the two waves that share a SIMD (wave w and w + 4) run ONE BARRIER APART (waves 4-7 pass one extra s_barrier
+// before the loop, waves 0-3 one after it): at every workgroup barrier one of them turns from loading to multiplying
+// and the other from multiplying to loading, so the matrix pipe of every SIMD always has a wave whose operands are
+// already in registers (cdna_hip_programming.md: T3+T4 counted vmcnt / raw s_barrier, T5 s_setprio).
+// LDS: a ring of R = 8 k-step slots of (8 + TN) KiB; the copy of k-step ks + PF is issued in phase ks.
+//   RAW: every wave has waited (vmcnt) for its copies of k-step ks + 1 before its first barrier of phase ks, and a
+//        wave starts reading k-step ks + 1 only after its second barrier of phase ks, which lies behind the first
+//        barrier of phase ks of both groups;
+//   WAR: slot (ks + PF) % R last held k-step ks + PF - R, whose fragment reads completed (lgkmcnt(0)) at least
+//        R - PF - 1 >= 1 full phases earlier for both groups (R >= PF + 2).
+// Persistent: a workgroup per CU walks the tiles in XCD-aware patches (common.hpp: the 32 workgroups of an XCD share
+// the operand panels of a 4 x 8 patch through its L2), and it requests the first PF k-steps of its NEXT tile before the
+// epilogue of the current one, so the epilogue's VALU work and stores overlap the next tile's operand traffic instead
+// of every CU writing, then every CU reading, in lockstep (measured on the separate-launch form: the epilogues were
+// 23-48 % of the four encoder GEMMs' time).
+template <int EPI, int TN, int ABL = 0>  // ABL: developer ablations (1 no copies in the loop, 2 no MFMAs, 3 no epilogue)
+__global__ __launch_bounds__(512) void k_gemm_pp(GemmParams p, PatchGrid pg, int64_t n_slots) {
+  constexpr int TM = 8, F = TM + TN, NW = TN / 2, R = 8, PF = 5;
+  static_assert(R >= PF + 2, "ring too small for the prefetch distance");
+  extern __shared__ uint4 g_lds[];  // ring [R][F][64]
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int grp = wave >> 2, wq = wave & 3;          // the two waves of a SIMD are (wq, grp 0) and (wq, grp 1)
+  const int wm = wq, wn = grp;                       // token pair wm, feature half wn
+  const int fb = wave < TN ? wave : wave - TN;       // TN = 6: waves 6, 7 repeat fragments 0, 1 (same bytes, same address)
+  const int dstA = wave * 64, dstB = (TM + fb) * 64;
+  constexpr int SLOT = F * 64;  // uint4 per ring slot
+  const int KB = p.KB;
+  const uint4 *srcA = nullptr, *srcB = nullptr;
+  auto find_tile = [&](int64_t &slot, int &bm, int &bn) -> bool {
+    for (; slot < n_slots; slot += gridDim.x)
+      if (patch_tile(pg, slot, bm, bn)) return true;
+    return false;
+  };
+  auto request = [&](int bm, int bn) {  // this wave copies token fragment `wave` and feature fragment `fb` of every k-step
+    const int64_t tb_c = (int64_t)bm * TM + wave < p.TB ? (int64_t)bm * TM + wave : p.TB - 1;
+    const int nb_c = bn * TN + fb < p.NB ? bn * TN + fb : p.NB - 1;
+    srcA = p.act + (tb_c * KB) * 64 + lane;
+    srcB = p.w + ((int64_t)nb_c * KB) * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < PF; ++i)
+      if (i < KB) {
+        gemm_glds16(srcA + (int64_t)i * 64, g_lds + i * SLOT + dstA);
+        gemm_glds16(srcB + (int64_t)i * 64, g_lds + i * SLOT + dstB);
+      }
+  };
+  int64_t slot = blockIdx.x;
+  int bm = 0, bn = 0;
+  bool have = find_tile(slot, bm, bn);
+  if (have) request(bm, bn);
+  while (have) {
+    floatx16 acc[2][NW];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < NW; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    if (KB >= PF) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // 2 (PF - 1): k-step 0 has landed
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();  // the stagger
+    __builtin_amdgcn_sched_barrier(0);
+    for (int ks = 0; ks < KB; ++ks) {
+      const uint4 *L = g_lds + (ks & (R - 1)) * SLOT + lane;
+      half8 a[2], b[NW];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) a[m] = __builtin_bit_cast(half8, L[(2 * wm + m) * 64]);
+#pragma unroll
+      for (int n = 0; n < NW; ++n) b[n] = __builtin_bit_cast(half8, L[(TM + NW * wn + n) * 64]);
+      if (ABL != 1 && ks + PF < KB) {
+        uint4 *dst = g_lds + ((ks + PF) & (R - 1)) * SLOT;
+        gemm_glds16(srcA + (int64_t)(ks + PF) * 64, dst + dstA);
+        gemm_glds16(srcB + (int64_t)(ks + PF) * 64, dst + dstB);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // k-step ks + 1 is complete, ks + 2 .. ks + PF stay in flight
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < NW; ++n) {
+          if (ABL == 2) {
+            gemm_keep(a[m]);
+            gemm_keep(b[n]);
+          } else if (EPI == EPI_VT) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m], b[n], acc[m][n], 0, 0, 0);
+          else acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[n], a[m], acc[m][n], 0, 0, 0);
+        }
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();  // pairs with the last barrier of the staggered group: every read is done
+    __builtin_amdgcn_sched_barrier(0);
+    // the next tile's first k-steps are requested now and land during the epilogue
+    const int cm = bm, cn = bn;
+    slot += gridDim.x;
+    have = find_tile(slot, bm, bn);
+    if (have) request(bm, bn);
+    __builtin_amdgcn_sched_barrier(0);
+    if (ABL == 3) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < NW; ++n) gemm_keep(acc[m][n]);
+    } else {
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < NW; ++n) {
+          const int64_t tb = (int64_t)cm * TM + 2 * wm + m;
+          const int nb = cn * TN + NW * wn + n;
+          if (tb < p.TB && nb < p.NB) gemm_store_tile<EPI>(p, acc[m][n], tb, nb, lane);
+        }
+    }
+  }
 }
 
 // ---- attention: one wave per (sequence, head, 32-query block), online softmax, all in registers --------
@@ -917,6 +1069,30 @@ int plain_copy(const float *host, int64_t n, float **dst) {
 
 template <int EPI, int TN>
 void launch_gemm8(anr_encoder *e, GemmParams &g, int64_t blocks) {
+  static const bool pp = getenv("ANORAG_GEMM_LDS8") == nullptr;  // developer switch: set to run the older k_gemm_lds8 instead
+  if (pp) {
+    constexpr int lds_pp = 8 * (8 + TN) * 1024;
+#ifdef ANR_GEMM_ABLATIONS
+    static const int abl = getenv("ANORAG_GEMM_ABL") ? atoi(getenv("ANORAG_GEMM_ABL")) : 0;  // developer ablations (wrong results)
+#else
+    constexpr int abl = 0;
+#endif
+    const PatchGrid pg = make_patch_grid(ceil_div(g.TB, 8), ceil_div(g.NB, TN));
+    const int64_t n_slots = pg.grid();
+    const int64_t grid = std::min<int64_t>(n_slots, std::max(8, e->n_cu / 8 * 8));  // a multiple of 8: slot % 8 = XCD
+#define ANR_PP(A)                                                                                          \
+  {                                                                                                        \
+    (void)ensure_dynamic_lds(reinterpret_cast<const void *>(&k_gemm_pp<EPI, TN, A>), lds_pp);              \
+    hipLaunchKernelGGL((k_gemm_pp<EPI, TN, A>), dim3((unsigned)grid), dim3(512), lds_pp, e->stream, g, pg, n_slots); \
+  }
+#ifdef ANR_GEMM_ABLATIONS
+    if (abl == 1) ANR_PP(1) else if (abl == 2) ANR_PP(2) else if (abl == 3) ANR_PP(3) else
+#endif
+    ANR_PP(0)
+    (void)abl;
+#undef ANR_PP
+    return;
+  }
   if (g.KB % 3 == 0) {
     constexpr int lds8 = 3 * 3 * (8 + TN) * 1024;
     (void)ensure_dynamic_lds(reinterpret_cast<const void *>(&k_gemm_lds8<EPI, TN, 3>), lds8);

@@ -899,7 +899,7 @@ int search_tiny(anr_index *h, const float *q, int64_t nq, int32_t k, float *D, i
   tp.seq = h->tiny_seq;
   tp.id_offset = h->id_offset;
   tp.stamps = h->tiny_stamps;
-  const size_t lds = (size_t)kTinyMaxMerge * 8 + (size_t)round_up(h->dim, 4) * sizeof(float);
+  const size_t lds = (size_t)kTinyMaxMerge * 8 + (size_t)16 * kTinyMaxK * 8 + (size_t)round_up(h->dim, 4) * sizeof(float);
   const int kc = (h->dim % 4 == 0 && h->dim <= 1024) ? (int)ceil_div(h->dim / 4, 64) : 0;
 #define ANR_TINY_LAUNCH(KC)                                                                                   \
   {                                                                                                           \

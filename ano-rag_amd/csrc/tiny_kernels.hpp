@@ -43,7 +43,7 @@ template <int KC>
 __global__ __launch_bounds__(kTinyThreads) void k_tiny_search(TinyParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tiny_smem[];
   unsigned long long *s_keys = reinterpret_cast<unsigned long long *>(tiny_smem);             // [kTinyMaxMerge]
-  float *s_q = reinterpret_cast<float *>(tiny_smem + (size_t)kTinyMaxMerge * 8);              // [dim rounded to 4]
+  float *s_q = reinterpret_cast<float *>(tiny_smem + (size_t)kTinyMaxMerge * 8 + (size_t)16 * kTinyMaxK * 8);  // [dim rounded to 4]
   __shared__ double s_red[4];
   __shared__ float s_scale;
   __shared__ int s_last;
@@ -191,24 +191,30 @@ __global__ __launch_bounds__(kTinyThreads) void k_tiny_search(TinyParams p) {
   float *D = p.D + (int64_t)q * p.k;
   int64_t *I = p.I + (int64_t)q * p.k;
   const int64_t found = p.n_rows < p.k ? p.n_rows : p.k;
-  // every partial list is sorted (best first, empty slots = 0 at its end): the global rank of an entry is its own
-  // position plus, for every other list, the number of entries ahead of it there — a binary search per list
+  // two-level merge with INDEPENDENT LDS reads (binary searches across the sorted lists were tried: ~1000 dependent LDS
+  // round trips per entry, 100 us): level 1 — each of the 16 waves ranks the entries of its share of the lists among
+  // themselves and keeps the k best; level 2 — the 16 k survivors are ranked among themselves
+  unsigned long long *s_l2 = s_keys + kTinyMaxMerge;  // [16][k]
+  const int G = (p.n_wg + 15) / 16;                    // lists per level-1 group
+  const int GE = G * p.k;                              // entries per group
+  for (int i = tid; i < 16 * p.k; i += kTinyThreads) s_l2[i] = 0ull;
+  __syncthreads();
   for (int i = tid; i < M; i += kTinyThreads) {
     const unsigned long long key = s_keys[i];
     if (key == 0ull) continue;
-    const int li = i / p.k;
-    int rank = i - li * p.k;
-    for (int l = 0; l < p.n_wg && rank < p.k; ++l) {
-      if (l == li) continue;
-      const unsigned long long *L = s_keys + l * p.k;
-      int lo = 0, hi = p.k;  // entries [0, lo) are greater than key
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (L[mid] > key) lo = mid + 1;
-        else hi = mid;
-      }
-      rank += lo;
-    }
+    const int g = i / GE;
+    const int e0 = g * GE, e1 = e0 + GE < M ? e0 + GE : M;
+    int rank = 0;
+    for (int j = e0; j < e1; ++j) rank += (s_keys[j] > key) ? 1 : 0;
+    if (rank < p.k) s_l2[g * p.k + rank] = key;
+  }
+  __syncthreads();
+  const int M2 = 16 * p.k;
+  for (int i = tid; i < M2; i += kTinyThreads) {
+    const unsigned long long key = s_l2[i];
+    if (key == 0ull) continue;
+    int rank = 0;
+    for (int j = 0; j < M2; ++j) rank += (s_l2[j] > key) ? 1 : 0;
     if (rank < p.k) s_rank[rank] = key;  // ranks are distinct: one writer per slot
   }
   __syncthreads();
