@@ -74,8 +74,12 @@ struct PatchGrid {
   int MB, NB, P, Q;
   int patches_n;      // patches along N
   int64_t n_patches;
+  int contig;         // 1: XCD x takes the CONSECUTIVE patches [x * per_xcd, (x + 1) * per_xcd) — with patches numbered
+                      // N-fastest an XCD then keeps the same M panels in its L2 while it walks the N panels (GEMM: every
+                      // activation panel is fetched by ONE XCD only); 0: patches dealt round-robin over the XCDs
   // workgroups to launch: whole patches, a multiple of 8 of them
-  int64_t grid() const { return (n_patches + 7) / 8 * 8 * (int64_t)(P * Q); }
+  __host__ __device__ int64_t per_xcd() const { return (n_patches + 7) / 8; }
+  __host__ __device__ int64_t grid() const { return per_xcd() * 8 * (int64_t)(P * Q); }
 };
 
 static inline PatchGrid make_patch_grid(int64_t MB, int64_t NB) {
@@ -88,7 +92,7 @@ static inline PatchGrid make_patch_grid(int64_t MB, int64_t NB) {
     const int64_t slots = (pm * pn + 7) / 8 * 8 * 32;
     if (best_slots < 0 || slots < best_slots) {
       best_slots = slots;
-      best = PatchGrid{(int)MB, (int)NB, sh[0], sh[1], (int)pn, pm * pn};
+      best = PatchGrid{(int)MB, (int)NB, sh[0], sh[1], (int)pn, pm * pn, 0};
     }
   }
   return best;
@@ -100,7 +104,7 @@ __device__ __forceinline__ bool patch_tile(const PatchGrid &g, int64_t wg, int &
   const int xcd = (int)(wg & 7);
   const int64_t local = wg >> 3;
   const int within = (int)(local % (g.P * g.Q));
-  const int64_t patch = (local / (g.P * g.Q)) * 8 + xcd;
+  const int64_t patch = g.contig ? xcd * g.per_xcd() + local / (g.P * g.Q) : (local / (g.P * g.Q)) * 8 + xcd;
   if (patch >= g.n_patches) return false;
   bm = (int)(patch / g.patches_n) * g.P + within / g.Q;
   bn = (int)(patch % g.patches_n) * g.Q + within % g.Q;

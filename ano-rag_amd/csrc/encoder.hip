@@ -724,6 +724,7 @@ __global__ __launch_bounds__(512) void k_gemm_lds8(GemmParams p) {
 // and the other from multiplying to loading, so the matrix pipe of every SIMD always has a wave whose operands are
 // already in registers (cdna_hip_programming.md: T3+T4 counted vmcnt / raw s_barrier, T5 s_setprio).
 // LDS: a ring of R = 8 k-step slots of (8 + TN) KiB; the copy of k-step ks + PF is issued in phase ks.
+//   (the two copies a wave owes per k-step are issued between its MFMAs, see the loop)
 //   RAW: every wave has waited (vmcnt) for its copies of k-step ks + 1 before its first barrier of phase ks, and a
 //        wave starts reading k-step ks + 1 only after its second barrier of phase ks, which lies behind the first
 //        barrier of phase ks of both groups;
@@ -734,10 +735,17 @@ __global__ __launch_bounds__(512) void k_gemm_lds8(GemmParams p) {
 // epilogue of the current one, so the epilogue's VALU work and stores overlap the next tile's operand traffic instead
 // of every CU writing, then every CU reading, in lockstep (measured on the separate-launch form: the epilogues were
 // 23-48 % of the four encoder GEMMs' time).
+// Ring: 8 slots, copies requested 5 k-steps ahead.  Tried and dropped (tools/gemm_abl.sh, PMC SQ_VALU_MFMA_BUSY_CYCLES):
+// 11 slots / 8 k-steps ahead on the 192-wide tile (slower: 103 vs 94 us on the FFN-up GEMM — latency is not what the
+// loop waits for); two workgroups per CU on a 5-slot ring (the epilogue of one beside the k-loop of the other: +5 % on
+// the GEMMs that ran 2 rounds, nothing overall); XCD-contiguous instead of round-robin patch assignment (no change in
+// TCC misses, which are mostly the output stores).  MFMA pipes: 54 % busy at the 1.66 GHz the chip holds under this load.
 template <int EPI, int TN, int ABL = 0>  // ABL: developer ablations (1 no copies in the loop, 2 no MFMAs, 3 no epilogue)
 __global__ __launch_bounds__(512) void k_gemm_pp(GemmParams p, PatchGrid pg, int64_t n_slots) {
-  constexpr int TM = 8, F = TM + TN, NW = TN / 2, R = 8, PF = 5;
+  constexpr int TM = 8, F = TM + TN, NW = TN / 2;
+  constexpr int R = 8, PF = 5;
   static_assert(R >= PF + 2, "ring too small for the prefetch distance");
+  static_assert(R * F <= 160, "ring exceeds the LDS");
   extern __shared__ uint4 g_lds[];  // ring [R][F][64]
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int grp = wave >> 2, wq = wave & 3;          // the two waves of a SIMD are (wq, grp 0) and (wq, grp 1)
@@ -776,23 +784,27 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmParams p, PatchGrid pg, int
       for (int n = 0; n < NW; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-    if (KB >= PF) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // 2 (PF - 1): k-step 0 has landed
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (KB >= PF) {  // 2 (PF - 1) copies may stay in flight: k-step 0 has landed
+      if (PF == 8) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();  // the stagger
     __builtin_amdgcn_sched_barrier(0);
+    int rd = 0, wr = PF % R;  // ring slots of k-step ks and of k-step ks + PF
     for (int ks = 0; ks < KB; ++ks) {
-      const uint4 *L = g_lds + (ks & (R - 1)) * SLOT + lane;
+      const uint4 *L = g_lds + rd * SLOT + lane;
       half8 a[2], b[NW];
 #pragma unroll
       for (int m = 0; m < 2; ++m) a[m] = __builtin_bit_cast(half8, L[(2 * wm + m) * 64]);
 #pragma unroll
       for (int n = 0; n < NW; ++n) b[n] = __builtin_bit_cast(half8, L[(TM + NW * wn + n) * 64]);
-      if (ABL != 1 && ks + PF < KB) {
-        uint4 *dst = g_lds + ((ks + PF) & (R - 1)) * SLOT;
-        gemm_glds16(srcA + (int64_t)(ks + PF) * 64, dst + dstA);
-        gemm_glds16(srcB + (int64_t)(ks + PF) * 64, dst + dstB);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // k-step ks + 1 is complete, ks + 2 .. ks + PF stay in flight
+      // this wave's copies of k-step ks + 1 have landed; ks + 2 .. ks + PF - 1 (issued in earlier MFMA segments) stay in flight
+      if (ks + PF - 1 < KB) {
+        if (PF == 8) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
@@ -800,6 +812,10 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmParams p, PatchGrid pg, int
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
+      // the two copies of k-step ks + PF are issued BETWEEN the MFMAs: an LDS-DMA piece costs the wave 60-180 cycles of
+      // issue, which hides behind the 32 cycles each MFMA keeps the pipe busy instead of lengthening the load segment
+      const bool more = ABL != 1 && ks + PF < KB;
+      uint4 *dst = g_lds + wr * SLOT;
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -809,10 +825,14 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmParams p, PatchGrid pg, int
             gemm_keep(b[n]);
           } else if (EPI == EPI_VT) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m], b[n], acc[m][n], 0, 0, 0);
           else acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[n], a[m], acc[m][n], 0, 0, 0);
+          if (m == 0 && n == 1 && more) gemm_glds16(srcA + (int64_t)(ks + PF) * 64, dst + dstA);
+          if (m == 1 && n == 0 && more) gemm_glds16(srcB + (int64_t)(ks + PF) * 64, dst + dstB);
         }
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
+      rd = rd + 1 == R ? 0 : rd + 1;
+      wr = wr + 1 == R ? 0 : wr + 1;
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();  // pairs with the last barrier of the staggered group: every read is done
     __builtin_amdgcn_sched_barrier(0);
@@ -1077,7 +1097,8 @@ void launch_gemm8(anr_encoder *e, GemmParams &g, int64_t blocks) {
 #else
     constexpr int abl = 0;
 #endif
-    const PatchGrid pg = make_patch_grid(ceil_div(g.TB, 8), ceil_div(g.NB, TN));
+    PatchGrid pg = make_patch_grid(ceil_div(g.TB, 8), ceil_div(g.NB, TN));
+    pg.contig = getenv("ANORAG_GEMM_CONTIG") ? 1 : 0;  // developer switch: XCD-contiguous patch assignment
     const int64_t n_slots = pg.grid();
     const int64_t grid = std::min<int64_t>(n_slots, std::max(8, e->n_cu / 8 * 8));  // a multiple of 8: slot % 8 = XCD
 #define ANR_PP(A)                                                                                          \
@@ -1125,7 +1146,10 @@ void launch_gemm(anr_encoder *e, GemmParams &g) {
   if (wide && g.KB % 2 == 0 && g.TB >= 8 * 16) {
     // tile width by grid shape: fewest rounds of workgroups over the CUs, weighted by the work per workgroup
     const int64_t b8 = ceil_div(g.TB, 8) * ceil_div(g.NB, 8), b6 = ceil_div(g.TB, 8) * ceil_div(g.NB, 6);
+    // rounds of workgroups over the CUs x tile width; at equal cost the 192-wide tile (deeper ring: 8 k-steps in flight)
+    static const bool lds8 = getenv("ANORAG_GEMM_LDS8") != nullptr;
     const int64_t cost8 = ceil_div(b8, e->n_cu) * 8, cost6 = ceil_div(b6, e->n_cu) * 6;
+    (void)lds8;
     if (cost6 < cost8) launch_gemm8<EPI, 6>(e, g, b6);
     else launch_gemm8<EPI, 8>(e, g, b8);
     return;
