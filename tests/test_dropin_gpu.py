@@ -209,3 +209,103 @@ def test_device_resident_encode_to_index_handoff(cfg, model_dir):
     vr.cleanup()
     vs.cleanup()
     EmbeddingManager._reset_singleton()
+
+
+def test_update_note_optimize_params_and_tfidf_namespace_fallback(cfg, model_dir, monkeypatch):
+    """rows c6 / b9 / c10 of SURVEY.md §8a: update_note (re-encode + rebuild), optimize_search_params (the nprobe sweep
+    of an exact scan: recall 1.0 at the first value), the TF-IDF "BM25 fallback" and search_with_namespace_fallback
+    (reference retriever.py:924-1062; the reference's utils.dataset_guard helper is stood in for by a stub with its
+    filtering rule: a note belongs when its dataset / qid fields match)"""
+    import sys
+    import types
+    from vector_store import EmbeddingManager, VectorIndex, VectorRetriever
+    EmbeddingManager._reset_singleton()
+    cfg.set("embedding.model_path", model_dir)
+    cfg.set("embedding.max_length", 64)
+    cfg.set("embedding.batch_size", 16)
+    cfg.set("vector_store.similarity_threshold", 0.0001)
+    words = oenc.synthetic_sentences(model_dir, 30, seed=31, min_words=4, max_words=10)
+    notes = [{"note_id": f"n{i}", "title": f"t{i}", "content": w, "dataset": "ds", "qid": "q1" if i < 15 else "q2"}
+             for i, w in enumerate(words)]
+    vr = VectorRetriever()
+    assert vr.build_index(notes, save_index=False)
+    # update_note: the row's embedding changes, the index is rebuilt and finds the new text
+    before = vr.note_embeddings[4].copy()
+    new_note = dict(notes[4], content=words[20] + " " + words[21])
+    assert vr.update_note("n4", new_note) is True
+    assert not np.allclose(vr.note_embeddings[4], before) and vr.get_note_by_id("n4")["content"] == new_note["content"]
+    assert vr.update_note("missing", new_note) is False
+    hit = vr.search_single(new_note["content"], top_k=1)
+    assert hit and hit[0]["note_id"] == "n4"
+    # TF-IDF fallback ("BM25" in the reference): built with the index, cosine over TF-IDF rows
+    vr.bm25_enabled = True
+    vr._build_bm25_index(vr.atomic_notes)
+    tf = vr._bm25_search(words[7], top_k=3)
+    assert tf and tf[0]["note_id"] == "n7" and tf[0]["retrieval_info"]["retrieval_method"] == "bm25_fallback"
+    assert [h["retrieval_info"]["rank"] for h in tf] == list(range(1, len(tf) + 1))
+    # namespace fallback: dense hits outside the namespace are dropped; an empty result falls back to TF-IDF
+    guard = types.ModuleType("utils.dataset_guard")
+    guard.filter_notes_by_namespace = lambda hits, dataset, qid: [h for h in hits if h.get("dataset") == dataset and h.get("qid") == qid]
+    monkeypatch.setitem(sys.modules, "utils", types.ModuleType("utils"))
+    monkeypatch.setitem(sys.modules, "utils.dataset_guard", guard)
+    res = vr.search_with_namespace_fallback([words[2], words[25]], "ds", "q2", top_k=30)
+    assert all(h["qid"] == "q2" for r in res for h in r) and res[1] and res[1][0]["note_id"] == "n25"
+    orig_search = vr.search
+    vr.search = lambda q, *a, **k: [[] for _ in q]        # dense search finds nothing in the namespace
+    res = vr.search_with_namespace_fallback([words[25]], "ds", "q2", top_k=5)
+    vr.search = orig_search
+    assert res[0] and res[0][0]["retrieval_info"]["retrieval_method"] == "bm25_fallback" and res[0][0]["note_id"] == "n25"
+    vr.cleanup()
+    EmbeddingManager._reset_singleton()
+    # optimize_search_params: only for the IVF types; the exact scan reaches recall 1.0 at the first nprobe tried
+    x = np.random.default_rng(0).standard_normal((3000, 64)).astype(np.float32)
+    q = np.random.default_rng(1).standard_normal((6, 64)).astype(np.float32)
+    vi = VectorIndex(64)
+    assert vi.create_index("Flat") and vi.add_vectors(x)
+    assert vi.optimize_search_params(q, np.zeros((6, 5), dtype=np.int64)) == {}
+    vj = VectorIndex(64)
+    assert vj.create_index("IVFFlat") and vj.add_vectors(x)
+    _, truth = orc.flat_search(orc.preprocess_vectors(q), orc.preprocess_vectors(x), 10, "ip")
+    best = vj.optimize_search_params(q, truth, target_recall=0.9)
+    assert best == {"nprobe": 1, "recall": 1.0} and vj.nprobe == 1
+    vi.cleanup()
+    vj.cleanup()
+
+
+def test_streamed_and_sharded_builds_equal_the_one_shot_build(cfg, model_dir, tmp_path):
+    """anorag_hip.offline_build: chunked device-resident encode -> add (with the embeddings.npy side file), and the
+    per-rank shard builds (two ranks played one after the other on this device) whose merged search equals the single
+    index"""
+    from anorag_hip import FlatIndex, METRIC_IP
+    from anorag_hip.offline_build import sharded_build, stream_build
+    from anorag_hip.sharded import merge_topk_host_c
+    from vector_store import EmbeddingManager
+    EmbeddingManager._reset_singleton()
+    cfg.set("embedding.model_path", model_dir)
+    cfg.set("embedding.max_length", 64)
+    cfg.set("embedding.batch_size", 16)
+    em = EmbeddingManager()
+    words = oenc.synthetic_sentences(model_dir, 150, seed=41, min_words=3, max_words=20)
+    notes = [{"note_id": f"n{i}", "title": f"t{i}", "content": w} for i, w in enumerate(words)]
+    ref = em.encode_atomic_notes(notes)
+    one = FlatIndex(em.embedding_dim, METRIC_IP, normalize=True)
+    one.add(ref)
+    idx = FlatIndex(em.embedding_dim, METRIC_IP, normalize=True)
+    npy = str(tmp_path / "embeddings.npy")
+    assert stream_build(idx, em, notes, chunk_notes=64, embeddings_npy=npy) == 150 and idx.ntotal == 150
+    assert np.array_equal(np.load(npy), ref)
+    q = em.encode_queries(words[:9])
+    D1, I1 = one.search(q, 12)
+    D2, I2 = idx.search(q, 12)
+    assert np.array_equal(I1, I2) and np.array_equal(D1, D2)
+    parts = []
+    for rank in range(2):
+        searcher, shard, (lo, hi) = sharded_build(em, notes, world=2, rank=rank, chunk_notes=50)
+        assert shard.ntotal == hi - lo and searcher.row_offset == lo
+        parts.append(shard.search(q, 12))          # global ids (ANR_OPT_ID_OFFSET set by the searcher)
+        shard.close()
+    Dm, Im = merge_topk_host_c(np.stack([p[0] for p in parts]), np.stack([p[1] for p in parts]), True)
+    assert np.array_equal(Im, I1) and np.array_equal(Dm, D1)
+    one.close()
+    idx.close()
+    EmbeddingManager._reset_singleton()

@@ -1,23 +1,66 @@
 #!/bin/bash
-# Run on the GPU box: headline bench + rocprofv3 kernel stats of the same command + PMC traffic of k_scan.
-# Outputs land in gpurun_out/; copy the summaries into profiles/ afterwards (tools/collect_profiles.py).
+# Run on the GPU box (gpurun): regenerates every measured artefact of profiles/ for this round into gpurun_out/prof/.
+# Copy the files from gpurun_out/prof/ into profiles/ afterwards (rN_ prefix is added here).
+#   1 headline bench + rocprofv3 --kernel-trace --stats of the same command
+#   2 HBM traffic of k_scan from the PMC counters (separate --pmc passes, MI355X_MICROARCH.md §HBM) + the sha256 of the
+#     kernel source it was measured on (bench.py refuses a stale file)
+#   3 shard-size lines (1 M and 1.25 M rows), the other BASELINE.json configs (tools/bench_configs.py), C1 timing
+#   4 encoder: kernel stats of one bge-base 256 x 64 forward loop + MFMA-busy PMC of the FFN-up GEMM
+#   5 N-array fusion (C5) kernel stats
 set -e
 R=$GRAFT_REPO_ROOT
-python3 $R/bench.py > $R/gpurun_out/bench_final.json 2> $R/gpurun_out/bench_final.err
+ROUND=${ROUND:-r02}
+O=$R/gpurun_out/prof
+rm -rf $O && mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/kstats -- python3 $R/bench.py --no-cpu --recall-queries 0 > $R/gpurun_out/bench_prof.json 2> $R/gpurun_out/bench_prof.err
-ROWS=10000000 bash $R/tools/pmc_traffic.sh > $R/gpurun_out/pmc_summary.txt 2>&1
-cd $R
-cp $(ls gpurun_out/kstats/*/*kernel_stats.csv | head -1) gpurun_out/kernel_stats.csv
+echo "[1] bench" >&2
+python3 $R/bench.py > $O/${ROUND}_bench_1gpu.json 2> $O/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats -- python3 $R/bench.py --no-cpu --recall-queries 0 --no-facade > $O/bench_prof.json 2> $O/bench_prof.err
+cp $(ls $O/kstats/*/*kernel_stats.csv | head -1) $O/${ROUND}_bench_10m_1gpu_kernel_stats.csv
+rm -rf $O/kstats
+echo "[2] pmc traffic" >&2
 for c in FETCH_SIZE WRITE_SIZE; do
-  python3 - "$c" <<'PY'
-import csv, glob, sys
-c = sys.argv[1]
-f = glob.glob("gpurun_out/pmc_%s/*/*counter_collection.csv" % c)[0]
-rows = [r for r in csv.DictReader(open(f)) if "k_scan<false" in r["Kernel_Name"] and r["Counter_Name"] == c]
-with open("gpurun_out/pmc_%s_k_scan.csv" % c, "w", newline="") as o:
-    w = csv.DictWriter(o, fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(rows)
-PY
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- python3 $R/tools/scan_perf.py --rows 10000000 --steps 4 --mode sync > $O/pmc_$c.log 2>&1
 done
-rm -rf gpurun_out/kstats gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE
-tail -3 gpurun_out/pmc_summary.txt
+python3 - "$R" "$O" "$ROUND" <<'PY'
+import csv, glob, hashlib, json, sys
+R, O, ROUND = sys.argv[1:4]
+out = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = glob.glob(f"{O}/pmc_{c}/*/*counter_collection.csv")[0]
+    rows = [r for r in csv.DictReader(open(f)) if "k_scan<false" in r["Kernel_Name"] and r["Counter_Name"] == c]
+    out[c] = [float(r["Counter_Value"]) for r in rows]
+    kernel = rows[0]["Kernel_Name"]
+    with open(f"{O}/{ROUND}_pmc_{c}_k_scan.csv", "w", newline="") as o:
+        w = csv.DictWriter(o, fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(rows)
+fetch = sum(out["FETCH_SIZE"]) / len(out["FETCH_SIZE"]); write = sum(out["WRITE_SIZE"]) / len(out["WRITE_SIZE"])
+rows_n, dim = 10_000_000, 768
+traffic = (2 * fetch + write) * 1024
+src = open(f"{R}/ano-rag_amd/csrc/index_kernels.hpp", "rb").read()
+json.dump({"kernel": kernel.replace("void anr::", "").split("(")[0], "rows": rows_n, "dim": dim,
+           "algorithmic_bytes_per_launch": rows_n * dim * 2, "FETCH_SIZE_KiB_per_launch": fetch,
+           "WRITE_SIZE_KiB_per_launch": write,
+           "correction": "gfx950: FETCH_SIZE counts half of a wide coalesced stream -> doubled (MI355X_MICROARCH.md HBM section); WRITE_SIZE exact; unit KiB",
+           "traffic_bytes_per_launch": traffic, "traffic_over_algorithmic": traffic / (rows_n * dim * 2),
+           "kernel_source_sha256": hashlib.sha256(src).hexdigest(),
+           "command": "rocprofv3 --pmc <counter> --kernel-trace --output-format csv -- python3 tools/scan_perf.py --rows 10000000 --steps 4 --mode sync (one pass per counter; tools/refresh_profiles.sh)"},
+          open(f"{O}/{ROUND}_pmc_traffic_k_scan.json", "w"), indent=1)
+print("traffic/algorithmic", traffic / (rows_n * dim * 2))
+PY
+rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
+echo "[3] shard sizes + configs" >&2
+{ python3 $R/tools/scan_perf.py --rows 1000000 --steps 60; python3 $R/tools/scan_perf.py --rows 1250000 --steps 60; python3 $R/tools/scan_perf.py --rows 1250000 --steps 60 --clustered; } 2>&1 | grep -v amdgpu > $O/${ROUND}_shard_size_lines.txt
+python3 $R/tools/bench_configs.py > $O/configs.log 2>&1 && cp $R/gpurun_out/configs.json $O/${ROUND}_configs_c1_c2_c4_c5.json
+python3 $R/tools/tiny_perf.py 2>&1 | grep -v amdgpu > $O/${ROUND}_c1_tiny_path.txt
+echo "[4] encoder" >&2
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/enc -- python3 $R/tools/enc_perf.py 256 64 > $O/enc_perf.log 2>&1
+cp $(ls $O/enc/*/*kernel_stats.csv | head -1) $O/${ROUND}_encoder_bge_base_256x64_kernel_stats.csv
+rm -rf $O/enc
+{ python3 $R/tools/enc_perf.py 256 64; python3 $R/tools/enc_perf.py 64 512; SHAPE=bge-m3 python3 $R/tools/enc_perf.py 256 64; } 2>&1 | grep TFLOP > $O/${ROUND}_encoder_forward_lines.txt
+bash $R/tools/pmc_kernel.sh "k_gemm_pp<1" SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY TCC_HIT_sum TCC_MISS_sum -- $R/tools/enc_perf.py 256 64 > $O/${ROUND}_pmc_k_gemm_pp_ffn_up.txt 2>&1
+echo "[5] fusion" >&2
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/fd -- python3 $R/tools/fuse_dense_perf.py > $O/${ROUND}_fuse_dense_c5.txt 2>&1
+cp $(ls $O/fd/*/*kernel_stats.csv | head -1) $O/${ROUND}_fuse_dense_c5_kernel_stats.csv
+rm -rf $O/fd
+ls -la $O >&2
