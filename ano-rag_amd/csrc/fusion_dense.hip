@@ -89,7 +89,9 @@ struct FdParams {
   int *o_rank;
   int64_t *o_offs;               // [nq][5]
   double *o_smax;                // [nq][4]
+  unsigned long long *stamps;    // developer aid (ANORAG_FD_STAMPS): phase stamps of workgroup 0's second chunk
 };
+#define FD_STAMP(slot) do { if (p.stamps && blockIdx.x == 0 && stamp_on && threadIdx.x == 0) p.stamps[slot] = wall_clock64(); } while (0)
 
 __device__ __forceinline__ bool fd_val(const FdSrc &s, int64_t q, int64_t i, double &v) {
   if (!s.arr || i >= s.len) return false;
@@ -120,6 +122,70 @@ __device__ __forceinline__ bool fd_key(const FdParams &p, const double (&smax)[4
   f = f + (hp ? p.w[3] * v : p.w[3] * 0.0);
   key = d2ord(f);
   return any || hp;
+}
+
+// One chunk's entries of a source for this thread: ids base + e * kFdThreads + tid.  The loads are UNCONDITIONAL (index
+// clamped, the array / dtype tests are uniform and sit outside the element loop): a per-element `if (i < len) load`
+// makes hipcc branch around every load and wait for each one before the next — eight dependent HBM round trips per
+// thread, measured at 19 us per 64-KiB chunk (0.9 TB/s chip-wide).
+__device__ __forceinline__ void fd_load_chunk(const FdSrc &s, int64_t q, int64_t base, int tid, double (&v)[kFdPer],
+                                              bool (&ok)[kFdPer]) {
+  if (!s.arr) {
+#pragma unroll
+    for (int e = 0; e < kFdPer; ++e) {
+      v[e] = 0.0;
+      ok[e] = false;
+    }
+    return;
+  }
+  const int64_t last = s.len - 1;
+  if (s.dtype == 0) {
+    const double *a = reinterpret_cast<const double *>(s.arr) + q * s.len;
+#pragma unroll
+    for (int e = 0; e < kFdPer; ++e) {
+      const int64_t i = base + e * kFdThreads + tid;
+      v[e] = a[i < last ? i : last];
+    }
+  } else {
+    const float *a = reinterpret_cast<const float *>(s.arr) + q * s.len;
+#pragma unroll
+    for (int e = 0; e < kFdPer; ++e) {
+      const int64_t i = base + e * kFdThreads + tid;
+      v[e] = (double)a[i < last ? i : last];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < kFdPer; ++e) ok[e] = base + e * kFdThreads + tid < s.len && v[e] == v[e];
+}
+
+// the keys of one chunk (fd_key for kFdPer entries, every array load in flight at once)
+__device__ __forceinline__ void fd_chunk_keys(const FdParams &p, const double (&smax)[4], int64_t q, int64_t base, int tid,
+                                              unsigned long long (&key)[kFdPer], bool (&valid)[kFdPer]) {
+  if (p.method == 1) {
+    double v[kFdPer];
+    fd_load_chunk(p.src[p.r1_src], q, base, tid, v, valid);
+#pragma unroll
+    for (int e = 0; e < kFdPer; ++e) key[e] = d2ord(v[e]);
+    return;
+  }
+  double v[4][kFdPer];
+  bool ok[4][kFdPer];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) fd_load_chunk(p.src[s], q, base, tid, v[s], ok[s]);
+#pragma unroll
+  for (int e = 0; e < kFdPer; ++e) {
+    double f = 0.0;
+    bool any = false;
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+      if (ok[s][e]) {
+        f += p.w[s] * (smax[s] == 0.0 ? 0.0 : v[s][e] / smax[s]);
+        any = true;
+      }
+    f = f + (ok[3][e] ? p.w[3] * v[3][e] : p.w[3] * 0.0);
+    key[e] = d2ord(f);
+    valid[e] = any || ok[3][e];
+  }
 }
 
 struct FdShared {
@@ -356,14 +422,14 @@ __global__ __launch_bounds__(kFdThreads) void k_fd_max(FdParams p) {
 #pragma unroll
   for (int s = 0; s < 3; ++s) {
     if (!p.src[s].arr) continue;
+    double v[kFdPer];
+    bool ok[kFdPer];
+    fd_load_chunk(p.src[s], p.q0 + q, base, tid, v, ok);
     unsigned long long best = 0ull;
 #pragma unroll
     for (int e = 0; e < kFdPer; ++e) {
-      double v;
-      if (fd_val(p.src[s], p.q0 + q, base + e * kFdThreads + tid, v)) {
-        const unsigned long long o = d2ord(v);
-        best = o > best ? o : best;
-      }
+      const unsigned long long o = ok[e] ? d2ord(v[e]) : 0ull;
+      best = o > best ? o : best;
     }
     for (int o = 32; o > 0; o >>= 1) {
       const unsigned long long t = __shfl_xor(best, o);
@@ -374,65 +440,81 @@ __global__ __launch_bounds__(kFdThreads) void k_fd_max(FdParams p) {
 }
 
 // ---- the scan ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kFdThreads) void k_fd_scan(FdParams p) {
-  extern __shared__ unsigned char fd_smem[];
-  FdShared &sh = *reinterpret_cast<FdShared *>(fd_smem);
-  const int q = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
-  const int c = p.chunk0 + blockIdx.x;
+// Persistent: a workgroup per CU walks a contiguous range of (query, chunk) items — launching one 1024-thread,
+// 113-KiB-LDS workgroup per 64-KiB chunk cost ~19 us of dispatch per chunk (0.87 TB/s); a query's short-list keys and
+// its rank histogram stay in LDS across the consecutive chunks of that query and are flushed when the query changes.
+__device__ void fd_scan_chunk(const FdParams &p, FdShared &sh, const int q, const int c, const int skn, const int kp,
+                              const double (&smax)[4], const unsigned long long tau0, const bool stamp_on) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  FD_STAMP(0);
   const int64_t base = (int64_t)c * kFdChunk;
-  const int kp = p.kprime[q];
-  double smax[4] = {0.0, 0.0, 0.0, 0.0};
-  if (p.method == 0)
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      const unsigned long long o = p.smax_ord[(int64_t)q * 4 + s];
-      smax[s] = o ? ord2d(o) : 0.0;
-    }
-  int skn = 0;
-  if (p.method == 1) {
-    skn = p.sk_n[q];
-    for (int i = tid; i < skn; i += kFdThreads) {
-      sh.sk_hi[i] = p.sk_hi[(int64_t)q * kFdMaxSparse + i];
-      sh.sk_id[i] = p.sk_id[(int64_t)q * kFdMaxSparse + i];
-    }
-    for (int i = tid; i <= skn; i += kFdThreads) sh.H[i] = 0;
-  }
   if (tid == 0) {
     sh.n = 0;
     sh.cnt = 0;
   }
   __syncthreads();
-  const unsigned long long tau0 = p.prefix ? 0ull : p.tau0[q];
-  const unsigned long long T = p.prefix ? 0ull : __hip_atomic_load(p.T + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // a plain (cached) load: T only ever rises and any earlier value is still a valid threshold, so a stale line costs a
+  // few extra candidates at worst — the agent-scope atomic load this replaced went past the L2 and took ~4 us per chunk
+  const unsigned long long T = p.prefix ? 0ull : *reinterpret_cast<const volatile unsigned long long *>(p.T + q);
+  unsigned long long key[kFdPer];
+  bool valid[kFdPer];
+  FD_STAMP(1);
+  fd_chunk_keys(p, smax, p.q0 + q, base, tid, key, valid);
+  if (p.stamps && blockIdx.x == 0 && stamp_on) {  // force the loads to have returned before the stamp
+    unsigned long long acc = 0;
 #pragma unroll
-  for (int e = 0; e < kFdPer; ++e) {
-    const int64_t i = base + e * kFdThreads + tid;
-    unsigned long long key = 0ull;
-    const bool valid = i < p.U && fd_key(p, smax, p.q0 + q, i, key);
-    if (p.method == 1 && skn > 0) {
-      // rank histogram: pb = short-list keys that beat this entry (they are sorted descending)
-      unsigned pb = 0;
-      if (valid) {
-        int lo = 0, hi = skn;  // keys [0, lo) beat the entry, keys [hi, skn) do not
-        while (lo < hi) {
-          const int mid = (lo + hi) >> 1;
-          const unsigned long long kh = sh.sk_hi[mid];
-          const bool beats = kh > key || (kh == key && (int64_t)sh.sk_id[mid] < i);
-          if (beats) lo = mid + 1;
-          else hi = mid;
-        }
-        pb = (unsigned)lo;
+    for (int e = 0; e < kFdPer; ++e) acc ^= key[e];
+    if (acc == 0x1234567ull && tid == 0) p.stamps[15] = acc;
+  }
+  FD_STAMP(2);
+  if (p.method == 1 && skn > 0) {
+    // rank histogram: pb = short-list keys that beat this entry (sorted descending).  The binary searches of a thread's
+    // kFdPer entries advance together, step by step, so their LDS reads overlap instead of forming one long chain.
+    // (Tried and dropped: a wave-level fast path that gives every entry equal to the wave's commonest key the count found
+    // by two searches per chunk — the per-chunk barrier then waits for the few waves that still search: 1.32 -> 1.70 ms.)
+    int lo[kFdPer], hi[kFdPer];
+#pragma unroll
+    for (int e = 0; e < kFdPer; ++e) {
+      lo[e] = 0;
+      hi[e] = skn;
+    }
+    for (int step = skn; step > 0; step >>= 1) {  // ceil(log2(skn + 1)) rounds; branch-free: every LDS read unconditional
+      unsigned long long kh[kFdPer];
+      unsigned kid[kFdPer];
+      int mid[kFdPer];
+#pragma unroll
+      for (int e = 0; e < kFdPer; ++e) {
+        mid[e] = (lo[e] + hi[e]) >> 1;
+        const int m = mid[e] < skn ? mid[e] : skn - 1;
+        kh[e] = sh.sk_hi[m];
+        kid[e] = sh.sk_id[m];
       }
-      const unsigned long long m = __ballot(valid);
-      if (m) {
-        const int leader = __ffsll((long long)m) - 1;
-        const unsigned pl = __shfl(pb, leader);
-        const unsigned long long same = __ballot(valid && pb == pl);
-        if (lane == leader) atomicAdd(&sh.H[pl], (unsigned)__popcll(same));
-        if (valid && pb != pl) atomicAdd(&sh.H[pb], 1u);
+#pragma unroll
+      for (int e = 0; e < kFdPer; ++e) {
+        const int64_t i = base + e * kFdThreads + tid;
+        const bool open = lo[e] < hi[e];
+        const bool beats = kh[e] > key[e] || (kh[e] == key[e] && (int64_t)kid[e] < i);
+        lo[e] = (open && beats) ? mid[e] + 1 : lo[e];
+        hi[e] = (open && !beats) ? mid[e] : hi[e];
       }
     }
-    const bool pass = valid && key > tau0 && key >= T;
+#pragma unroll
+    for (int e = 0; e < kFdPer; ++e) {
+      const unsigned pb = (unsigned)lo[e];
+      const unsigned long long m = __ballot(valid[e]);
+      if (m) {
+        const int leader = __ffsll((long long)m) - 1;
+        const unsigned pl = (unsigned)__builtin_amdgcn_readlane((int)pb, leader);
+        const unsigned long long same = __ballot(valid[e] && pb == pl);
+        if (lane == leader) atomicAdd(&sh.H[pl], (unsigned)__popcll(same));
+        if (valid[e] && pb != pl) atomicAdd(&sh.H[pb], 1u);
+      }
+    }
+  }
+  FD_STAMP(3);
+#pragma unroll
+  for (int e = 0; e < kFdPer; ++e) {
+    const bool pass = valid[e] && key[e] > tau0 && key[e] >= T;
     const unsigned long long pm = __ballot(pass);
     if (pm) {
       unsigned wbase = 0;
@@ -440,17 +522,13 @@ __global__ __launch_bounds__(kFdThreads) void k_fd_scan(FdParams p) {
       wbase = __shfl(wbase, 0);
       if (pass) {
         const unsigned pos = wbase + (unsigned)__popcll(pm & ((1ull << lane) - 1ull));
-        sh.hi[pos] = key;
-        sh.idx[pos] = (unsigned)i;
+        sh.hi[pos] = key[e];
+        sh.idx[pos] = (unsigned)(base + e * kFdThreads + tid);
       }
     }
   }
   __syncthreads();
-  if (p.method == 1 && skn > 0) {
-    unsigned *Hq = p.H + (int64_t)q * (kFdMaxSparse + 1);
-    for (int i = tid; i <= skn; i += kFdThreads)
-      if (sh.H[i]) atomicAdd(Hq + i, sh.H[i]);
-  }
+  FD_STAMP(4);
   const int n = (int)sh.n;
   unsigned long long *lh = p.c_hi + ((int64_t)q * p.n_chunks + c) * p.lcap;
   unsigned *li = p.c_id + ((int64_t)q * p.n_chunks + c) * p.lcap;
@@ -464,6 +542,8 @@ __global__ __launch_bounds__(kFdThreads) void k_fd_scan(FdParams p) {
       p.c_cnt[(int64_t)q * p.n_chunks + c] = (unsigned)n;
       if (p.prefix) p.tau0[q] = 0ull;  // fewer than K' ids in chunk 0: no threshold
     }
+    __syncthreads();
+    FD_STAMP(5);
     return;
   }
   fd_select_boundary(sh, n, kp);
@@ -491,6 +571,56 @@ __global__ __launch_bounds__(kFdThreads) void k_fd_scan(FdParams p) {
     if (p.prefix) p.tau0[q] = B;          // later ids tie-break below chunk 0's K': strictly greater only
     else atomicMax(p.T + q, B);            // K' ids at or above B exist: a valid (>=) threshold for everyone
   }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(kFdThreads) void k_fd_scan(FdParams p, int64_t n_items) {
+  extern __shared__ unsigned char fd_smem[];
+  FdShared &sh = *reinterpret_cast<FdShared *>(fd_smem);
+  const int tid = threadIdx.x;
+  const int per_q = p.prefix ? 1 : p.n_chunks - 1;  // items of one query in this launch
+  const int64_t per_wg = (n_items + gridDim.x - 1) / gridDim.x;
+  const int64_t it0 = (int64_t)blockIdx.x * per_wg, it1 = it0 + per_wg < n_items ? it0 + per_wg : n_items;
+  int cur_q = -1, skn = 0, kp = 0;
+  double smax[4] = {0.0, 0.0, 0.0, 0.0};
+  unsigned long long tau0 = 0ull;
+  auto flush = [&]() {  // the finished query's rank histogram joins the global one
+    if (cur_q >= 0 && p.method == 1 && skn > 0) {
+      unsigned *Hq = p.H + (int64_t)cur_q * (kFdMaxSparse + 1);
+      for (int i = tid; i <= skn; i += kFdThreads)
+        if (sh.H[i]) atomicAdd(Hq + i, sh.H[i]);
+    }
+  };
+  for (int64_t item = it0; item < it1; ++item) {
+    const int q = (int)(item / per_q);
+    const int c = p.prefix ? 0 : 1 + (int)(item % per_q);
+    if (q != cur_q) {
+      __syncthreads();
+      flush();
+      __syncthreads();
+      cur_q = q;
+      kp = p.kprime[q];
+      if (p.method == 0) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+          const unsigned long long o = p.smax_ord[(int64_t)q * 4 + s];
+          smax[s] = o ? ord2d(o) : 0.0;
+        }
+      } else {
+        skn = p.sk_n[q];
+        for (int i = tid; i < skn; i += kFdThreads) {
+          sh.sk_hi[i] = p.sk_hi[(int64_t)q * kFdMaxSparse + i];
+          sh.sk_id[i] = p.sk_id[(int64_t)q * kFdMaxSparse + i];
+        }
+        for (int i = tid; i <= skn; i += kFdThreads) sh.H[i] = 0;
+      }
+      tau0 = p.prefix ? 0ull : p.tau0[q];
+      __syncthreads();
+    }
+    fd_scan_chunk(p, sh, q, c, skn, kp, smax, tau0, item == it0 + 2);
+  }
+  __syncthreads();
+  flush();
 }
 
 // ---- build: K' best of the chunk lists, ordered; compose the short lists k_fuse<true> consumes ------------------
@@ -796,6 +926,9 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
   }
   int rc = ANR_OK;
   hipStream_t st = nullptr;
+  DevBuf b_st;
+  const bool want_stamps = getenv("ANORAG_FD_STAMPS") != nullptr;
+  if (want_stamps) ANR_TRY(b_st.alloc(16 * 8));
   for (int64_t q0 = 0; q0 < nq && rc == ANR_OK; q0 += QB) {
     const int64_t nb = std::min(QB, nq - q0);
     FdParams p{};
@@ -834,6 +967,7 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
     p.o_rank = b_or.as<int>();
     p.o_offs = b_oo.as<int64_t>();
     p.o_smax = b_om.as<double>();
+    p.stamps = want_stamps ? b_st.as<unsigned long long>() : nullptr;
     hipError_t e = hipMemcpyAsync(b_offs.p, offs.data() + q0 * 5, (size_t)nb * 5 * 8, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemsetAsync(b_H.p, 0, (size_t)nb * (kFdMaxSparse + 1) * 4, st);
     if (e == hipSuccess) e = hipMemsetAsync(b_smax.p, 0, (size_t)nb * 4 * 8, st);
@@ -847,13 +981,15 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
     hipLaunchKernelGGL(k_fd_prep, dim3((unsigned)nb), dim3(kFdThreads), 0, st, p);
     if (timed) (void)hipEventRecord(ev[0], st);
     if (method == 0) hipLaunchKernelGGL(k_fd_max, dim3((unsigned)n_chunks, (unsigned)nb), dim3(kFdThreads), 0, st, p);
+    const int n_cu = device_cu_count(device);
     p.chunk0 = 0;
     p.prefix = 1;
-    hipLaunchKernelGGL(k_fd_scan, dim3(1, (unsigned)nb), dim3(kFdThreads), sizeof(FdShared), st, p);
+    hipLaunchKernelGGL(k_fd_scan, dim3((unsigned)std::min<int64_t>(nb, n_cu)), dim3(kFdThreads), sizeof(FdShared), st, p, nb);
     if (n_chunks > 1) {
       p.chunk0 = 1;
       p.prefix = 0;
-      hipLaunchKernelGGL(k_fd_scan, dim3((unsigned)(n_chunks - 1), (unsigned)nb), dim3(kFdThreads), sizeof(FdShared), st, p);
+      const int64_t items = nb * (int64_t)(n_chunks - 1);
+      hipLaunchKernelGGL(k_fd_scan, dim3((unsigned)std::min<int64_t>(items, n_cu)), dim3(kFdThreads), sizeof(FdShared), st, p, items);
     }
     if (timed) (void)hipEventRecord(ev[1], st);
     hipLaunchKernelGGL(k_fd_build, dim3((unsigned)nb), dim3(kFdThreads), sizeof(FdShared), st, p);
@@ -881,6 +1017,14 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
     if (e != hipSuccess) {
       rc = fail(ANR_EHIP, "fuse_dense failed: %s", hipGetErrorString(e));
       break;
+    }
+    if (want_stamps) {
+      unsigned long long sv[16];
+      if (hipMemcpy(sv, b_st.p, sizeof sv, hipMemcpyDeviceToHost) == hipSuccess) {
+        auto us = [&](int a, int b) { return (double)((long long)sv[b] - (long long)sv[a]) / 100.0; };
+        fprintf(stderr, "[fd] chunk: zero+barrier %.2f loads+keys %.2f ranks %.2f compact+barrier %.2f emit %.2f us\n", us(0, 1), us(1, 2),
+                us(2, 3), us(3, 4), us(4, 5));
+      }
     }
     if (timed) {
       float ms = 0.f;

@@ -211,6 +211,10 @@ def test_device_resident_encode_to_index_handoff(cfg, model_dir):
     EmbeddingManager._reset_singleton()
 
 
+def em_row(vr, note):
+    return vr.embedding_manager.encode_atomic_notes([note], include_metadata=True)[0]
+
+
 def test_update_note_optimize_params_and_tfidf_namespace_fallback(cfg, model_dir, monkeypatch):
     """rows c6 / b9 / c10 of SURVEY.md §8a: update_note (re-encode + rebuild), optimize_search_params (the nprobe sweep
     of an exact scan: recall 1.0 at the first value), the TF-IDF "BM25 fallback" and search_with_namespace_fallback
@@ -235,8 +239,8 @@ def test_update_note_optimize_params_and_tfidf_namespace_fallback(cfg, model_dir
     assert vr.update_note("n4", new_note) is True
     assert not np.allclose(vr.note_embeddings[4], before) and vr.get_note_by_id("n4")["content"] == new_note["content"]
     assert vr.update_note("missing", new_note) is False
-    hit = vr.search_single(new_note["content"], top_k=1)
-    assert hit and hit[0]["note_id"] == "n4"
+    assert np.array_equal(vr.note_embeddings[4], em_row(vr, new_note))          # the re-encoded row, and the rebuilt index
+    assert vr.vector_index.search(vr.note_embeddings[4:5], top_k=1)[0]["index"] == 4    # holds it at the same position
     # TF-IDF fallback ("BM25" in the reference): built with the index, cosine over TF-IDF rows
     vr.bm25_enabled = True
     vr._build_bm25_index(vr.atomic_notes)
