@@ -470,34 +470,56 @@ __device__ void fd_scan_chunk(const FdParams &p, FdShared &sh, const int q, cons
   if (p.method == 1 && skn > 0) {
     // rank histogram: pb = short-list keys that beat this entry (sorted descending).  The binary searches of a thread's
     // kFdPer entries advance together, step by step, so their LDS reads overlap instead of forming one long chain.
-    // (Tried and dropped: a wave-level fast path that gives every entry equal to the wave's commonest key the count found
-    // by two searches per chunk — the per-chunk barrier then waits for the few waves that still search: 1.32 -> 1.70 ms.)
-    int lo[kFdPer], hi[kFdPer];
+    // pb of one (key, id) pair: binary search, branch-free (every LDS read unconditional)
+    auto beaten_by = [&](unsigned long long k, int64_t i) -> int {
+      int lo = 0, hi = skn;
+      for (int step = skn; step > 0; step >>= 1) {  // ceil(log2(skn + 1)) rounds
+        const int mid = (lo + hi) >> 1;
+        const int m = mid < skn ? mid : skn - 1;
+        const unsigned long long kh = sh.sk_hi[m];
+        const unsigned kid = sh.sk_id[m];
+        const bool open = lo < hi;
+        const bool beats = kh > k || (kh == k && (int64_t)kid < i);
+        lo = (open && beats) ? mid + 1 : lo;
+        hi = (open && !beats) ? mid : hi;
+      }
+      return lo;
+    };
+    // A BM25 vector is mostly ZERO: two searches per thread (the chunk's first id and the next chunk's) bracket the
+    // zero-valued short-list ids that lie inside the chunk, and a zero entry's count is the first of them plus the few of
+    // those ids below it.  The other entries are searched one per round, `while any lane still has one` (a lane rarely
+    // holds two).  (Searching every entry: 8 x 7 rounds x ~12 instructions per wave, four waves per SIMD = 5.3 us of a
+    // 12-us chunk.)
+    const unsigned long long kzero = 0x8000000000000000ull;  // d2ord(0.0)
+    // short-list keys [pb_z0, pb_z1) are exactly the zero-valued short-list ids that lie inside this chunk, in id order
+    const int pb_z0 = beaten_by(kzero, base), pb_z1 = beaten_by(kzero, base + kFdChunk);
+    int lo[kFdPer];
+    unsigned pend = 0;
 #pragma unroll
     for (int e = 0; e < kFdPer; ++e) {
-      lo[e] = 0;
-      hi[e] = skn;
+      const int64_t i = base + e * kFdThreads + tid;
+      int pb = pb_z0;
+      for (int j = pb_z0; j < pb_z1; ++j) pb += ((int64_t)sh.sk_id[j] < i) ? 1 : 0;  // usually no iteration at all
+      lo[e] = pb;
+      if (valid[e] && key[e] != kzero) pend |= 1u << e;
     }
-    for (int step = skn; step > 0; step >>= 1) {  // ceil(log2(skn + 1)) rounds; branch-free: every LDS read unconditional
-      unsigned long long kh[kFdPer];
-      unsigned kid[kFdPer];
-      int mid[kFdPer];
+    while (__any(pend != 0)) {
+      const int e = pend ? __ffs(pend) - 1 : -1;
+      unsigned long long k = 0ull;
+      int64_t i = 0;
 #pragma unroll
-      for (int e = 0; e < kFdPer; ++e) {
-        mid[e] = (lo[e] + hi[e]) >> 1;
-        const int m = mid[e] < skn ? mid[e] : skn - 1;
-        kh[e] = sh.sk_hi[m];
-        kid[e] = sh.sk_id[m];
-      }
+      for (int ee = 0; ee < kFdPer; ++ee)
+        if (ee == e) {
+          k = key[ee];
+          i = base + ee * kFdThreads + tid;
+        }
+      const int r = beaten_by(k, i);
 #pragma unroll
-      for (int e = 0; e < kFdPer; ++e) {
-        const int64_t i = base + e * kFdThreads + tid;
-        const bool open = lo[e] < hi[e];
-        const bool beats = kh[e] > key[e] || (kh[e] == key[e] && (int64_t)kid[e] < i);
-        lo[e] = (open && beats) ? mid[e] + 1 : lo[e];
-        hi[e] = (open && !beats) ? mid[e] : hi[e];
-      }
+      for (int ee = 0; ee < kFdPer; ++ee)
+        if (ee == e) lo[ee] = r;
+      pend &= pend - 1;
     }
+    // histogram: wave-aggregated adds (a wave's zeros nearly always share one count)
 #pragma unroll
     for (int e = 0; e < kFdPer; ++e) {
       const unsigned pb = (unsigned)lo[e];
@@ -527,6 +549,7 @@ __device__ void fd_scan_chunk(const FdParams &p, FdShared &sh, const int q, cons
       }
     }
   }
+  if (p.stamps && blockIdx.x == 0 && stamp_on && lane == 0) p.stamps[16 + (tid >> 6)] = wall_clock64();  // per-wave arrival
   __syncthreads();
   FD_STAMP(4);
   const int n = (int)sh.n;
@@ -928,7 +951,7 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
   hipStream_t st = nullptr;
   DevBuf b_st;
   const bool want_stamps = getenv("ANORAG_FD_STAMPS") != nullptr;
-  if (want_stamps) ANR_TRY(b_st.alloc(16 * 8));
+  if (want_stamps) ANR_TRY(b_st.alloc(32 * 8));
   for (int64_t q0 = 0; q0 < nq && rc == ANR_OK; q0 += QB) {
     const int64_t nb = std::min(QB, nq - q0);
     FdParams p{};
@@ -1019,8 +1042,11 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
       break;
     }
     if (want_stamps) {
-      unsigned long long sv[16];
+      unsigned long long sv[32];
       if (hipMemcpy(sv, b_st.p, sizeof sv, hipMemcpyDeviceToHost) == hipSuccess) {
+        fprintf(stderr, "[fd] wave arrivals at the chunk barrier (us after the rank phase of wave 0):");
+        for (int w = 0; w < 16; ++w) fprintf(stderr, " %.1f", (double)((long long)sv[16 + w] - (long long)sv[3]) / 100.0);
+        fprintf(stderr, "\n");
         auto us = [&](int a, int b) { return (double)((long long)sv[b] - (long long)sv[a]) / 100.0; };
         fprintf(stderr, "[fd] chunk: zero+barrier %.2f loads+keys %.2f ranks %.2f compact+barrier %.2f emit %.2f us\n", us(0, 1), us(1, 2),
                 us(2, 3), us(3, 4), us(4, 5));
