@@ -33,6 +33,11 @@ namespace anr {
 constexpr int kFdChunk = 8192;      // ids per scan workgroup
 constexpr int kFdThreads = 1024;
 constexpr int kFdPer = kFdChunk / kFdThreads;
+// the streaming scan runs TWO 512-thread workgroups per CU on 4096-id chunks (one fat workgroup per CU spent its time
+// at its own barriers: its 16 waves arrive 4 us apart, and nothing overlapped the load latency of the next chunk)
+constexpr int kFsChunk = 4096;
+constexpr int kFsThreads = 512;
+static_assert(kFsChunk / kFsThreads == kFdPer, "same ids per thread in both chunkings");
 constexpr int kFdMaxSparse = 1024;  // unique short-list ids per query
 constexpr int kFdMaxK = 2048;       // K' = pool + unique short-list ids
 
@@ -89,9 +94,7 @@ struct FdParams {
   int *o_rank;
   int64_t *o_offs;               // [nq][5]
   double *o_smax;                // [nq][4]
-  unsigned long long *stamps;    // developer aid (ANORAG_FD_STAMPS): phase stamps of workgroup 0's second chunk
 };
-#define FD_STAMP(slot) do { if (p.stamps && blockIdx.x == 0 && stamp_on && threadIdx.x == 0) p.stamps[slot] = wall_clock64(); } while (0)
 
 __device__ __forceinline__ bool fd_val(const FdSrc &s, int64_t q, int64_t i, double &v) {
   if (!s.arr || i >= s.len) return false;
@@ -128,6 +131,7 @@ __device__ __forceinline__ bool fd_key(const FdParams &p, const double (&smax)[4
 // clamped, the array / dtype tests are uniform and sit outside the element loop): a per-element `if (i < len) load`
 // makes hipcc branch around every load and wait for each one before the next — eight dependent HBM round trips per
 // thread, measured at 19 us per 64-KiB chunk (0.9 TB/s chip-wide).
+template <int TH>
 __device__ __forceinline__ void fd_load_chunk(const FdSrc &s, int64_t q, int64_t base, int tid, double (&v)[kFdPer],
                                               bool (&ok)[kFdPer]) {
   if (!s.arr) {
@@ -143,54 +147,25 @@ __device__ __forceinline__ void fd_load_chunk(const FdSrc &s, int64_t q, int64_t
     const double *a = reinterpret_cast<const double *>(s.arr) + q * s.len;
 #pragma unroll
     for (int e = 0; e < kFdPer; ++e) {
-      const int64_t i = base + e * kFdThreads + tid;
+      const int64_t i = base + e * TH + tid;
       v[e] = a[i < last ? i : last];
     }
   } else {
     const float *a = reinterpret_cast<const float *>(s.arr) + q * s.len;
 #pragma unroll
     for (int e = 0; e < kFdPer; ++e) {
-      const int64_t i = base + e * kFdThreads + tid;
+      const int64_t i = base + e * TH + tid;
       v[e] = (double)a[i < last ? i : last];
     }
   }
 #pragma unroll
-  for (int e = 0; e < kFdPer; ++e) ok[e] = base + e * kFdThreads + tid < s.len && v[e] == v[e];
+  for (int e = 0; e < kFdPer; ++e) ok[e] = base + e * TH + tid < s.len && v[e] == v[e];
 }
 
-// the keys of one chunk (fd_key for kFdPer entries, every array load in flight at once)
-__device__ __forceinline__ void fd_chunk_keys(const FdParams &p, const double (&smax)[4], int64_t q, int64_t base, int tid,
-                                              unsigned long long (&key)[kFdPer], bool (&valid)[kFdPer]) {
-  if (p.method == 1) {
-    double v[kFdPer];
-    fd_load_chunk(p.src[p.r1_src], q, base, tid, v, valid);
-#pragma unroll
-    for (int e = 0; e < kFdPer; ++e) key[e] = d2ord(v[e]);
-    return;
-  }
-  double v[4][kFdPer];
-  bool ok[4][kFdPer];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) fd_load_chunk(p.src[s], q, base, tid, v[s], ok[s]);
-#pragma unroll
-  for (int e = 0; e < kFdPer; ++e) {
-    double f = 0.0;
-    bool any = false;
-#pragma unroll
-    for (int s = 0; s < 3; ++s)
-      if (ok[s][e]) {
-        f += p.w[s] * (smax[s] == 0.0 ? 0.0 : v[s][e] / smax[s]);
-        any = true;
-      }
-    f = f + (ok[3][e] ? p.w[3] * v[3][e] : p.w[3] * 0.0);
-    key[e] = d2ord(f);
-    valid[e] = any || ok[3][e];
-  }
-}
-
-struct FdShared {
-  unsigned long long hi[kFdChunk];
-  unsigned idx[kFdChunk];
+template <int CH>
+struct FdSharedT {
+  unsigned long long hi[CH];
+  unsigned idx[CH];
   unsigned long long sk_hi[kFdMaxSparse];
   unsigned sk_id[kFdMaxSparse];
   unsigned H[kFdMaxSparse + 1];
@@ -199,17 +174,20 @@ struct FdShared {
   unsigned long long bnd;  // select boundary
   unsigned cut;
   unsigned n, cnt, above, d, hd;
+  int pbz[2];  // rrf: short-list keys beating a zero entry at the chunk's first id / the next chunk's
 };
+using FdShared = FdSharedT<kFdChunk>;   // prep / build
+
 
 // The need-th largest key among the participating entries i < n (8-bit radix passes, common leading bytes skipped);
 // on return *eq = entries equal to it, *need_eq = how many of those belong to the `need` largest.  All threads call.
-template <typename KeyFn, typename PartFn>
-__device__ unsigned long long fd_radix_kth(FdShared &sh, int n, unsigned need, int total_bits, KeyFn key, PartFn part,
+template <typename SH, typename KeyFn, typename PartFn>
+__device__ __forceinline__ unsigned long long fd_radix_kth(SH &sh, int n, unsigned need, int total_bits, KeyFn key, PartFn part,
                                            unsigned *eq, unsigned *need_eq) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
   unsigned long long kmin = ~0ull, kmax = 0ull;
   unsigned np = 0;
-  for (int i = tid; i < n; i += kFdThreads)
+  for (int i = tid; i < n; i += nthr)
     if (part(i)) {
       const unsigned long long k = key(i);
       kmin = k < kmin ? k : kmin;
@@ -232,7 +210,7 @@ __device__ unsigned long long fd_radix_kth(FdShared &sh, int n, unsigned need, i
   kmin = sh.red[0][0];
   kmax = sh.red[1][0];
   unsigned total = sh.hist[0];
-  for (int w = 1; w < kFdThreads / 64; ++w) {
+  for (int w = 1; w < nthr / 64; ++w) {
     kmin = sh.red[0][w] < kmin ? sh.red[0][w] : kmin;
     kmax = sh.red[1][w] > kmax ? sh.red[1][w] : kmax;
     total += sh.hist[w];
@@ -243,10 +221,10 @@ __device__ unsigned long long fd_radix_kth(FdShared &sh, int n, unsigned need, i
   unsigned long long prefix = bits ? (kmax >> (total_bits - bits)) : 0ull;
   unsigned count_eq = total;  // entries matching the current prefix
   while (bits < total_bits) {
-    for (int i = tid; i < 256; i += kFdThreads) sh.hist[i] = 0;
+    for (int i = tid; i < 256; i += nthr) sh.hist[i] = 0;
     __syncthreads();
     const int sh_d = total_bits - 8 - bits;
-    for (int i0 = 0; i0 < n; i0 += kFdThreads) {
+    for (int i0 = 0; i0 < n; i0 += nthr) {
       const int i = i0 + tid;
       bool act = false;
       unsigned dg = 0;
@@ -305,7 +283,8 @@ __device__ unsigned long long fd_radix_kth(FdShared &sh, int n, unsigned need, i
 
 // boundary of the K largest (hi desc, idx asc) of the n staged pairs (n > K): selected <=> hi > bnd || (hi == bnd &&
 // idx <= cut).  All threads call; result in sh.bnd / sh.cut.
-__device__ void fd_select_boundary(FdShared &sh, int n, int K) {
+template <typename SH>
+__device__ __forceinline__ void fd_select_boundary(SH &sh, int n, int K) {
   unsigned eq, need_eq;
   const unsigned long long B = fd_radix_kth(
       sh, n, (unsigned)K, 64, [&](int i) { return sh.hi[i]; }, [](int) { return true; }, &eq, &need_eq);
@@ -417,162 +396,322 @@ __global__ __launch_bounds__(kFdThreads) void k_fd_prep(FdParams p) {
 
 // ---- linear: per-source maximum over the arrays ----------------------------------------------------------
 __global__ __launch_bounds__(kFdThreads) void k_fd_max(FdParams p) {
-  const int q = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
-  const int64_t base = (int64_t)blockIdx.x * kFdChunk;
+  // grid (x, query): workgroup x strides over the 8192-id chunks; maxima are taken as doubles (NaN never wins a `>`),
+  // one d2ord and one atomic per workgroup and source
+  __shared__ double s_best[kFdThreads / 64];
+  __shared__ int s_any[kFdThreads / 64];
+  const int q = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t n8 = (p.U + kFdChunk - 1) / kFdChunk;
 #pragma unroll
   for (int s = 0; s < 3; ++s) {
     if (!p.src[s].arr) continue;
-    double v[kFdPer];
-    bool ok[kFdPer];
-    fd_load_chunk(p.src[s], p.q0 + q, base, tid, v, ok);
-    unsigned long long best = 0ull;
+    double best = 0.0;
+    bool any = false;
+    for (int64_t c = blockIdx.x; c < n8; c += gridDim.x) {
+      double v[kFdPer];
+      bool ok[kFdPer];
+      fd_load_chunk<kFdThreads>(p.src[s], p.q0 + q, c * kFdChunk, tid, v, ok);
 #pragma unroll
-    for (int e = 0; e < kFdPer; ++e) {
-      const unsigned long long o = ok[e] ? d2ord(v[e]) : 0ull;
-      best = o > best ? o : best;
+      for (int e = 0; e < kFdPer; ++e)
+        if (ok[e]) {
+          best = (!any || v[e] > best) ? v[e] : best;
+          any = true;
+        }
     }
     for (int o = 32; o > 0; o >>= 1) {
-      const unsigned long long t = __shfl_xor(best, o);
-      best = t > best ? t : best;
+      const double t = __shfl_xor(best, o);
+      const bool ta = __shfl_xor((int)any, o) != 0;
+      best = (ta && (!any || t > best)) ? t : best;
+      any = any || ta;
     }
-    if (lane == 0 && best) atomicMax(p.smax_ord + (int64_t)q * 4 + s, best);
+    __syncthreads();
+    if (lane == 0) {
+      s_best[wave] = best;
+      s_any[wave] = any ? 1 : 0;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < kFdThreads / 64; ++w)
+        if (s_any[w] && (!any || s_best[w] > best)) {
+          best = s_best[w];
+          any = true;
+        }
+      if (any) atomicMax(p.smax_ord + (int64_t)q * 4 + s, d2ord(best));
+    }
   }
 }
 
 // ---- the scan ---------------------------------------------------------------------------------------------
-// Persistent: a workgroup per CU walks a contiguous range of (query, chunk) items — launching one 1024-thread,
-// 113-KiB-LDS workgroup per 64-KiB chunk cost ~19 us of dispatch per chunk (0.87 TB/s); a query's short-list keys and
-// its rank histogram stay in LDS across the consecutive chunks of that query and are flushed when the query changes.
-__device__ void fd_scan_chunk(const FdParams &p, FdShared &sh, const int q, const int c, const int skn, const int kp,
-                              const double (&smax)[4], const unsigned long long tau0, const bool stamp_on) {
+// Persistent: two 512-thread workgroups per CU, each walking a contiguous range of (query, chunk) items; a query's
+// short-list keys and its rank histogram stay in LDS across the consecutive chunks of that query and are flushed when
+// the query changes.  The scan was issue- and latency-bound, not HBM-bound, so the per-chunk work is kept short and
+// uniform (measured steps in DESIGN.md 5a):
+//   * the NEXT chunk's values (and the running threshold) are loaded into registers before the current chunk is
+//     processed; the chunk barrier waits for LDS only, so those loads stay in flight across it;
+//   * ONE barrier per chunk in the steady state: the staging counter and the drain flag rotate through three slots
+//     (slot c + 2 is cleared after the barrier of chunk c), and a second barrier is passed only when something was staged;
+//   * values are compared as doubles; d2ord only for the rare entry that is kept or searched;
+//   * rrf: zero entries (a BM25 vector is ~99.9 % zeros) are counted per wave without a search — the zero-valued
+//     short-list ids inside the chunk are tracked by a pointer that advances with the chunks; the few non-zero entries of
+//     a sparse wave are DEFERRED to an LDS list that all threads search together every ~100 chunks (a 7-round
+//     dependent-LDS binary search inside the chunk made one wave late for the barrier every time); a wave with many
+//     non-zero entries (a dense vector) searches in place.
+constexpr int kFsPend = 768;     // deferred rank searches held in LDS
+constexpr int kFsPushMax = 8;    // a wave defers at most this many entries per chunk (more: it searches in place)
+constexpr unsigned kFsDrainAt = kFsPend - 3 * (kFsThreads / 64) * kFsPushMax;
+struct FsShared : FdSharedT<kFsChunk> {
+  unsigned long long pk[kFsPend];
+  unsigned pi[kFsPend];
+  unsigned pn;
+  unsigned n3[3];      // staged entries of chunk c in slot c % 3
+  unsigned drain3[3];  // "search the deferred list after this chunk's barrier"
+};
+
+// workgroup barrier that waits for this wave's LDS traffic only (global loads of the next chunk stay in flight)
+__device__ __forceinline__ void fs_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int TH>
+__device__ __forceinline__ void fd_load_raw(const FdSrc &s, int64_t q, int64_t base, int tid, double (&v)[kFdPer]) {
+  const int64_t last = s.len - 1;
+  if (s.dtype == 0) {
+    const double *a = reinterpret_cast<const double *>(s.arr) + q * s.len;
+#pragma unroll
+    for (int e = 0; e < kFdPer; ++e) {
+      const int64_t i = base + e * TH + tid;
+      v[e] = a[i < last ? i : last];
+    }
+  } else {
+    const float *a = reinterpret_cast<const float *>(s.arr) + q * s.len;
+#pragma unroll
+    for (int e = 0; e < kFdPer; ++e) {
+      const int64_t i = base + e * TH + tid;
+      v[e] = (double)a[i < last ? i : last];
+    }
+  }
+}
+
+struct FsState {
+  int cur_q, skn, kp;
+  double smax[4];
+  unsigned long long tau0;
+  int z_hi;   // rrf: short-list keys at or above zero (the zero-valued ones end here)
+  int zp, zc; // rrf: short-list keys beating a zero entry at the first id of chunk zc
+  int par;    // chunk counter mod 3
+};
+
+// one chunk; `raw` = the prefetched values of array source s0, T = the running threshold read with them
+template <int METHOD>
+__device__ __forceinline__ void fd_scan_chunk(const FdParams &p, FsShared &sh, FsState &st, const int q, const int c,
+                                              const int s0, const double (&raw)[kFdPer], const unsigned long long T) {
   const int tid = threadIdx.x, lane = tid & 63;
-  FD_STAMP(0);
-  const int64_t base = (int64_t)c * kFdChunk;
-  if (tid == 0) {
-    sh.n = 0;
-    sh.cnt = 0;
-  }
-  __syncthreads();
-  // a plain (cached) load: T only ever rises and any earlier value is still a valid threshold, so a stale line costs a
-  // few extra candidates at worst — the agent-scope atomic load this replaced went past the L2 and took ~4 us per chunk
-  const unsigned long long T = p.prefix ? 0ull : *reinterpret_cast<const volatile unsigned long long *>(p.T + q);
-  unsigned long long key[kFdPer];
+  const int64_t base = (int64_t)c * kFsChunk;
+  const int skn = st.skn;
+  const bool ranks = METHOD == 1 && skn > 0;
+  const unsigned long long kzero = 0x8000000000000000ull;  // d2ord(0.0)
+  // pb of one (key, id) pair = short-list keys (sorted descending, ties by id) that beat it: binary search, branch-free
+  // (every LDS read unconditional)
+  auto beaten_by = [&](unsigned long long k, int64_t i) -> int {
+    int lo = 0, hi = skn;
+    for (int step = skn; step > 0; step >>= 1) {  // ceil(log2(skn + 1)) rounds
+      const int mid = (lo + hi) >> 1;
+      const int m = mid < skn ? mid : skn - 1;
+      const unsigned long long kh = sh.sk_hi[m];
+      const unsigned kid = sh.sk_id[m];
+      const bool open = lo < hi;
+      const bool beats = kh > k || (kh == k && (int64_t)kid < i);
+      lo = (open && beats) ? mid + 1 : lo;
+      hi = (open && !beats) ? mid : hi;
+    }
+    return lo;
+  };
+  // ---- values and validity, in the double domain ----
+  double f[kFdPer];
   bool valid[kFdPer];
-  FD_STAMP(1);
-  fd_chunk_keys(p, smax, p.q0 + q, base, tid, key, valid);
-  if (p.stamps && blockIdx.x == 0 && stamp_on) {  // force the loads to have returned before the stamp
-    unsigned long long acc = 0;
-#pragma unroll
-    for (int e = 0; e < kFdPer; ++e) acc ^= key[e];
-    if (acc == 0x1234567ull && tid == 0) p.stamps[15] = acc;
-  }
-  FD_STAMP(2);
-  if (p.method == 1 && skn > 0) {
-    // rank histogram: pb = short-list keys that beat this entry (sorted descending).  The binary searches of a thread's
-    // kFdPer entries advance together, step by step, so their LDS reads overlap instead of forming one long chain.
-    // pb of one (key, id) pair: binary search, branch-free (every LDS read unconditional)
-    auto beaten_by = [&](unsigned long long k, int64_t i) -> int {
-      int lo = 0, hi = skn;
-      for (int step = skn; step > 0; step >>= 1) {  // ceil(log2(skn + 1)) rounds
-        const int mid = (lo + hi) >> 1;
-        const int m = mid < skn ? mid : skn - 1;
-        const unsigned long long kh = sh.sk_hi[m];
-        const unsigned kid = sh.sk_id[m];
-        const bool open = lo < hi;
-        const bool beats = kh > k || (kh == k && (int64_t)kid < i);
-        lo = (open && beats) ? mid + 1 : lo;
-        hi = (open && !beats) ? mid : hi;
-      }
-      return lo;
-    };
-    // A BM25 vector is mostly ZERO: two searches per thread (the chunk's first id and the next chunk's) bracket the
-    // zero-valued short-list ids that lie inside the chunk, and a zero entry's count is the first of them plus the few of
-    // those ids below it.  The other entries are searched one per round, `while any lane still has one` (a lane rarely
-    // holds two).  (Searching every entry: 8 x 7 rounds x ~12 instructions per wave, four waves per SIMD = 5.3 us of a
-    // 12-us chunk.)
-    const unsigned long long kzero = 0x8000000000000000ull;  // d2ord(0.0)
-    // short-list keys [pb_z0, pb_z1) are exactly the zero-valued short-list ids that lie inside this chunk, in id order
-    const int pb_z0 = beaten_by(kzero, base), pb_z1 = beaten_by(kzero, base + kFdChunk);
-    int lo[kFdPer];
-    unsigned pend = 0;
+  if (METHOD == 1) {
 #pragma unroll
     for (int e = 0; e < kFdPer; ++e) {
-      const int64_t i = base + e * kFdThreads + tid;
-      int pb = pb_z0;
-      for (int j = pb_z0; j < pb_z1; ++j) pb += ((int64_t)sh.sk_id[j] < i) ? 1 : 0;  // usually no iteration at all
-      lo[e] = pb;
-      if (valid[e] && key[e] != kzero) pend |= 1u << e;
+      f[e] = raw[e];
+      valid[e] = base + e * kFsThreads + tid < p.src[s0].len && raw[e] == raw[e];
     }
-    while (__any(pend != 0)) {
-      const int e = pend ? __ffs(pend) - 1 : -1;
-      unsigned long long k = 0ull;
-      int64_t i = 0;
+  } else {
+    // source after source, in the order fd_key adds them; a zero entry skips the f64 division (x / smax for x = +-0 is
+    // +-0 with the sign of x * smax, which is what the select below produces)
 #pragma unroll
-      for (int ee = 0; ee < kFdPer; ++ee)
-        if (ee == e) {
-          k = key[ee];
-          i = base + ee * kFdThreads + tid;
+    for (int e = 0; e < kFdPer; ++e) {
+      f[e] = 0.0;
+      valid[e] = false;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (!p.src[s].arr) {
+        if (s == 3) {
+#pragma unroll
+          for (int e = 0; e < kFdPer; ++e) f[e] = f[e] + p.w[3] * 0.0;
         }
-      const int r = beaten_by(k, i);
+        continue;
+      }
+      double v[kFdPer];
+      if (s == s0) {
 #pragma unroll
-      for (int ee = 0; ee < kFdPer; ++ee)
-        if (ee == e) lo[ee] = r;
-      pend &= pend - 1;
-    }
-    // histogram: wave-aggregated adds (a wave's zeros nearly always share one count)
+        for (int e = 0; e < kFdPer; ++e) v[e] = raw[e];
+      } else {
+        fd_load_raw<kFsThreads>(p.src[s], p.q0 + q, base, tid, v);
+      }
+      const double sm = s < 3 ? st.smax[s] : 0.0, w = p.w[s];
 #pragma unroll
-    for (int e = 0; e < kFdPer; ++e) {
-      const unsigned pb = (unsigned)lo[e];
-      const unsigned long long m = __ballot(valid[e]);
-      if (m) {
-        const int leader = __ffsll((long long)m) - 1;
-        const unsigned pl = (unsigned)__builtin_amdgcn_readlane((int)pb, leader);
-        const unsigned long long same = __ballot(valid[e] && pb == pl);
-        if (lane == leader) atomicAdd(&sh.H[pl], (unsigned)__popcll(same));
-        if (valid[e] && pb != pl) atomicAdd(&sh.H[pb], 1u);
+      for (int e = 0; e < kFdPer; ++e) {
+        const double x = v[e];
+        const bool ok = base + e * kFsThreads + tid < p.src[s].len && x == x;
+        if (s < 3) {
+          if (ok) {
+            double r = 0.0;
+            if (sm != 0.0) {
+              if (x == 0.0) r = sm < 0.0 ? -x : x;
+              else r = x / sm;
+            }
+            f[e] += w * r;
+            valid[e] = true;
+          }
+        } else {
+          f[e] = f[e] + (ok ? w * x : w * 0.0);
+          valid[e] = valid[e] || ok;
+        }
       }
     }
   }
-  FD_STAMP(3);
+  const bool has_t0 = st.tau0 != 0ull, has_T = T != 0ull;
+  const double t0d = has_t0 ? ord2d(st.tau0) : 0.0, Td = has_T ? ord2d(T) : 0.0;
+  const int par = st.par;
+  // ---- rrf: rank histogram ----
+  if (ranks) {
+    // short-list keys [pb_z0, pb_z1) are exactly the zero-valued short-list ids that lie inside this chunk, in id order
+    if (c != st.zc) st.zp = beaten_by(kzero, base);  // first chunk of a run; afterwards the pointer just advances
+    const int pb_z0 = st.zp;
+    int pb_z1 = pb_z0;
+    while (pb_z1 < st.z_hi && (int64_t)sh.sk_id[pb_z1] < base + kFsChunk) ++pb_z1;
+    st.zp = pb_z1;
+    st.zc = c + 1;
+    unsigned pend = 0, zmask = 0;
+#pragma unroll
+    for (int e = 0; e < kFdPer; ++e)
+      if (valid[e]) {
+        if (f[e] == 0.0) zmask |= 1u << e;
+        else pend |= 1u << e;
+      }
+    if (pb_z0 == pb_z1) {  // no such id in this chunk (nearly always): every zero entry of the wave has count pb_z0
+      unsigned nz = 0;
+#pragma unroll
+      for (int e = 0; e < kFdPer; ++e) nz += (unsigned)__popcll(__ballot((zmask >> e) & 1u));
+      if (lane == 0 && nz) atomicAdd(&sh.H[pb_z0], nz);
+    } else {
+#pragma unroll
+      for (int e = 0; e < kFdPer; ++e) {
+        const int64_t i = base + e * kFsThreads + tid;
+        const bool z = (zmask >> e) & 1u;
+        unsigned pb = (unsigned)pb_z0;
+        for (int j = pb_z0; j < pb_z1; ++j) pb += ((int64_t)sh.sk_id[j] < i) ? 1u : 0u;
+        const unsigned long long m = __ballot(z);
+        if (m) {  // wave-aggregated add for the leader's count, one atomic each for the rest
+          const int leader = __ffsll((long long)m) - 1;
+          const unsigned pl = (unsigned)__builtin_amdgcn_readlane((int)pb, leader);
+          const unsigned long long same = __ballot(z && pb == pl);
+          if (lane == leader) atomicAdd(&sh.H[pl], (unsigned)__popcll(same));
+          if (z && pb != pl) atomicAdd(&sh.H[pb], 1u);
+        }
+      }
+    }
+    if (__any(pend != 0)) {
+      unsigned wtotal = 0;
+#pragma unroll
+      for (int e = 0; e < kFdPer; ++e) wtotal += (unsigned)__popcll(__ballot((pend >> e) & 1u));
+      if (wtotal <= (unsigned)kFsPushMax) {  // a sparse wave: defer its searches
+        unsigned wb = 0;
+        if (lane == 0) wb = atomicAdd(&sh.pn, wtotal);
+        wb = (unsigned)__builtin_amdgcn_readfirstlane((int)wb);
+#pragma unroll
+        for (int e = 0; e < kFdPer; ++e) {
+          const bool b = (pend >> e) & 1u;
+          const unsigned long long m = __ballot(b);
+          if (m) {
+            if (b) {
+              const unsigned pos = wb + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+              sh.pk[pos] = d2ord(f[e]);
+              sh.pi[pos] = (unsigned)(base + e * kFsThreads + tid);
+            }
+            wb += (unsigned)__popcll(m);
+          }
+        }
+      } else {  // a dense wave: one search per round while any lane still has one
+        while (__any(pend != 0)) {
+          const int e = pend ? __ffs(pend) - 1 : -1;
+          double x = 0.0;
+#pragma unroll
+          for (int ee = 0; ee < kFdPer; ++ee)
+            if (ee == e) x = f[ee];
+          const int r = beaten_by(d2ord(x), base + (int64_t)e * kFsThreads + tid);
+          if (e >= 0) atomicAdd(&sh.H[r], 1u);
+          pend &= pend - 1;
+        }
+      }
+    }
+  }
+  // ---- entries that pass both thresholds are staged ----
+  unsigned pmask = 0;
 #pragma unroll
   for (int e = 0; e < kFdPer; ++e) {
-    const bool pass = valid[e] && key[e] > tau0 && key[e] >= T;
-    const unsigned long long pm = __ballot(pass);
-    if (pm) {
-      unsigned wbase = 0;
-      if (lane == 0) wbase = atomicAdd(&sh.n, (unsigned)__popcll(pm));
-      wbase = __shfl(wbase, 0);
-      if (pass) {
-        const unsigned pos = wbase + (unsigned)__popcll(pm & ((1ull << lane) - 1ull));
-        sh.hi[pos] = key[e];
-        sh.idx[pos] = (unsigned)(base + e * kFdThreads + tid);
+    const bool pass = valid[e] && (!has_t0 || f[e] > t0d) && (!has_T || f[e] >= Td);
+    pmask |= pass ? 1u << e : 0u;
+  }
+  if (__any(pmask != 0)) {
+#pragma unroll
+    for (int e = 0; e < kFdPer; ++e) {
+      const bool pass = (pmask >> e) & 1u;
+      const unsigned long long pm = __ballot(pass);
+      if (pm) {
+        unsigned wbase = 0;
+        if (lane == 0) wbase = atomicAdd(&sh.n3[par], (unsigned)__popcll(pm));
+        wbase = (unsigned)__builtin_amdgcn_readfirstlane((int)wbase);
+        if (pass) {
+          const unsigned pos = wbase + (unsigned)__popcll(pm & ((1ull << lane) - 1ull));
+          sh.hi[pos] = d2ord(f[e]);
+          sh.idx[pos] = (unsigned)(base + e * kFsThreads + tid);
+        }
       }
     }
   }
-  if (p.stamps && blockIdx.x == 0 && stamp_on && lane == 0) p.stamps[16 + (tid >> 6)] = wall_clock64();  // per-wave arrival
-  __syncthreads();
-  FD_STAMP(4);
-  const int n = (int)sh.n;
+  fs_barrier();  // ---- the chunk barrier ----
+  const int n = (int)sh.n3[par];
+  const bool drain = METHOD == 1 && sh.drain3[par] != 0;
+  if (drain) {
+    const int pn = (int)sh.pn;  // stable: this chunk's pushes are behind the barrier, the next chunk's behind the ones below
+    for (int i = tid; i < pn; i += kFsThreads) atomicAdd(&sh.H[beaten_by(sh.pk[i], (int64_t)sh.pi[i])], 1u);
+    fs_barrier();
+    if (tid == 0) sh.pn = 0;
+    fs_barrier();
+  }
+  if (tid == 0) {
+    sh.n3[par == 0 ? 2 : par - 1] = 0;                       // slot of chunk c + 2
+    sh.drain3[par == 2 ? 0 : par + 1] = sh.pn > kFsDrainAt;  // decided now, acted on after the next chunk's barrier
+  }
+  st.par = par == 2 ? 0 : par + 1;
+  if (n == 0) return;  // (c_cnt and tau0 were zeroed by the host)
   unsigned long long *lh = p.c_hi + ((int64_t)q * p.n_chunks + c) * p.lcap;
   unsigned *li = p.c_id + ((int64_t)q * p.n_chunks + c) * p.lcap;
-  const int room = p.prefix ? kp : p.lcap;
+  const int room = p.prefix ? st.kp : p.lcap;
   if (n <= room) {
-    for (int i = tid; i < n; i += kFdThreads) {
+    for (int i = tid; i < n; i += kFsThreads) {
       lh[i] = sh.hi[i];
       li[i] = sh.idx[i];
     }
-    if (tid == 0) {
-      p.c_cnt[(int64_t)q * p.n_chunks + c] = (unsigned)n;
-      if (p.prefix) p.tau0[q] = 0ull;  // fewer than K' ids in chunk 0: no threshold
-    }
-    __syncthreads();
-    FD_STAMP(5);
+    if (tid == 0) p.c_cnt[(int64_t)q * p.n_chunks + c] = (unsigned)n;  // (prefix: fewer than K' ids, tau0 stays 0)
+    fs_barrier();  // the staging area is free again
     return;
   }
-  fd_select_boundary(sh, n, kp);
+  if (tid == 0) sh.cnt = 0;
+  fd_select_boundary(sh, n, st.kp);
   const unsigned long long B = sh.bnd;
   const unsigned cut = sh.cut;
-  for (int i0 = 0; i0 < n; i0 += kFdThreads) {
+  for (int i0 = 0; i0 < n; i0 += kFsThreads) {
     const int i = i0 + tid;
     const bool sel = i < n && (sh.hi[i] > B || (sh.hi[i] == B && sh.idx[i] <= cut));
     const unsigned long long sm = __ballot(sel);
@@ -590,60 +729,122 @@ __device__ void fd_scan_chunk(const FdParams &p, FdShared &sh, const int q, cons
     }
   }
   if (tid == 0) {
-    p.c_cnt[(int64_t)q * p.n_chunks + c] = (unsigned)kp;
+    p.c_cnt[(int64_t)q * p.n_chunks + c] = (unsigned)st.kp;
     if (p.prefix) p.tau0[q] = B;          // later ids tie-break below chunk 0's K': strictly greater only
     else atomicMax(p.T + q, B);            // K' ids at or above B exist: a valid (>=) threshold for everyone
   }
   __syncthreads();
 }
 
-__global__ __launch_bounds__(kFdThreads) void k_fd_scan(FdParams p, int64_t n_items) {
+template <int METHOD>
+__global__ __launch_bounds__(kFsThreads, 4) void k_fd_scan(FdParams p, int64_t n_items) {
   extern __shared__ unsigned char fd_smem[];
-  FdShared &sh = *reinterpret_cast<FdShared *>(fd_smem);
+  FsShared &sh = *reinterpret_cast<FsShared *>(fd_smem);
   const int tid = threadIdx.x;
   const int per_q = p.prefix ? 1 : p.n_chunks - 1;  // items of one query in this launch
   const int64_t per_wg = (n_items + gridDim.x - 1) / gridDim.x;
   const int64_t it0 = (int64_t)blockIdx.x * per_wg, it1 = it0 + per_wg < n_items ? it0 + per_wg : n_items;
-  int cur_q = -1, skn = 0, kp = 0;
-  double smax[4] = {0.0, 0.0, 0.0, 0.0};
-  unsigned long long tau0 = 0ull;
-  auto flush = [&]() {  // the finished query's rank histogram joins the global one
-    if (cur_q >= 0 && p.method == 1 && skn > 0) {
-      unsigned *Hq = p.H + (int64_t)cur_q * (kFdMaxSparse + 1);
-      for (int i = tid; i <= skn; i += kFdThreads)
+  // the array source whose next chunk is prefetched (rrf has exactly one; linear: the first present)
+  const int s0 = METHOD == 1 ? p.r1_src : (p.src[0].arr ? 0 : p.src[1].arr ? 1 : p.src[2].arr ? 2 : 3);
+  FsState st{};
+  st.cur_q = -1;
+  st.zc = -1;
+  if (tid == 0) {
+    sh.pn = 0;
+    sh.n3[0] = sh.n3[1] = sh.n3[2] = 0;
+    sh.drain3[0] = sh.drain3[1] = sh.drain3[2] = 0;
+  }
+  __syncthreads();
+  const unsigned long long kzero = 0x8000000000000000ull;
+  auto finish_query = [&]() {  // deferred searches, then the finished query's rank histogram joins the global one
+    if (st.cur_q >= 0 && METHOD == 1 && st.skn > 0) {
+      const int skn = st.skn, pn = (int)sh.pn;
+      for (int i = tid; i < pn; i += kFsThreads) {
+        const unsigned long long k = sh.pk[i];
+        const int64_t id = (int64_t)sh.pi[i];
+        int lo = 0, hi = skn;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          const unsigned long long kh = sh.sk_hi[mid];
+          if (kh > k || (kh == k && (int64_t)sh.sk_id[mid] < id)) lo = mid + 1;
+          else hi = mid;
+        }
+        atomicAdd(&sh.H[lo], 1u);
+      }
+      __syncthreads();
+      if (tid == 0) sh.pn = 0;
+      unsigned *Hq = p.H + (int64_t)st.cur_q * (kFdMaxSparse + 1);
+      for (int i = tid; i <= skn; i += kFsThreads)
         if (sh.H[i]) atomicAdd(Hq + i, sh.H[i]);
     }
   };
+  auto item_qc = [&](int64_t item, int &q, int &c) {
+    q = (int)(item / per_q);
+    c = p.prefix ? 0 : 1 + (int)(item % per_q);
+  };
+  auto load_T = [&](int q) -> unsigned long long {
+    // a plain (cached) load: T only ever rises and any earlier value is still a valid threshold, so a stale line costs
+    // a few extra candidates at worst — an agent-scope atomic load went past the L2 and took ~4 us per chunk
+    return p.prefix ? 0ull : *reinterpret_cast<const volatile unsigned long long *>(p.T + q);
+  };
+  double nxt[kFdPer];
+  unsigned long long T_nxt = 0ull;
+  if (it0 < it1) {
+    int q, c;
+    item_qc(it0, q, c);
+    T_nxt = load_T(q);
+    fd_load_raw<kFsThreads>(p.src[s0], p.q0 + q, (int64_t)c * kFsChunk, tid, nxt);
+  }
   for (int64_t item = it0; item < it1; ++item) {
-    const int q = (int)(item / per_q);
-    const int c = p.prefix ? 0 : 1 + (int)(item % per_q);
-    if (q != cur_q) {
+    int q, c;
+    item_qc(item, q, c);
+    double raw[kFdPer];
+#pragma unroll
+    for (int e = 0; e < kFdPer; ++e) raw[e] = nxt[e];
+    const unsigned long long T = T_nxt;
+    if (item + 1 < it1) {
+      int q2, c2;
+      item_qc(item + 1, q2, c2);
+      T_nxt = load_T(q2);
+      fd_load_raw<kFsThreads>(p.src[s0], p.q0 + q2, (int64_t)c2 * kFsChunk, tid, nxt);
+    }
+    if (q != st.cur_q) {
       __syncthreads();
-      flush();
+      finish_query();
       __syncthreads();
-      cur_q = q;
-      kp = p.kprime[q];
-      if (p.method == 0) {
+      st.cur_q = q;
+      st.kp = p.kprime[q];
+      if (METHOD == 0) {
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
           const unsigned long long o = p.smax_ord[(int64_t)q * 4 + s];
-          smax[s] = o ? ord2d(o) : 0.0;
+          st.smax[s] = o ? ord2d(o) : 0.0;
         }
       } else {
-        skn = p.sk_n[q];
-        for (int i = tid; i < skn; i += kFdThreads) {
+        st.skn = p.sk_n[q];
+        for (int i = tid; i < st.skn; i += kFsThreads) {
           sh.sk_hi[i] = p.sk_hi[(int64_t)q * kFdMaxSparse + i];
           sh.sk_id[i] = p.sk_id[(int64_t)q * kFdMaxSparse + i];
         }
-        for (int i = tid; i <= skn; i += kFdThreads) sh.H[i] = 0;
+        for (int i = tid; i <= st.skn; i += kFsThreads) sh.H[i] = 0;
       }
-      tau0 = p.prefix ? 0ull : p.tau0[q];
+      st.tau0 = p.prefix ? 0ull : p.tau0[q];
       __syncthreads();
+      if (METHOD == 1) {  // where the zero-valued short-list keys end
+        int lo = 0, hi = st.skn;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (sh.sk_hi[mid] >= kzero) lo = mid + 1;
+          else hi = mid;
+        }
+        st.z_hi = lo;
+        st.zc = -1;
+      }
     }
-    fd_scan_chunk(p, sh, q, c, skn, kp, smax, tau0, item == it0 + 2);
+    fd_scan_chunk<METHOD>(p, sh, st, q, c, s0, raw, T);
   }
   __syncthreads();
-  flush();
+  finish_query();
 }
 
 // ---- build: K' best of the chunk lists, ordered; compose the short lists k_fuse<true> consumes ------------------
@@ -844,6 +1045,10 @@ struct DevBuf {
     return ANR_OK;
   }
 };
+void launch_scan(int method, unsigned grid, hipStream_t st, const FdParams &p, int64_t n_items) {
+  if (method == 1) hipLaunchKernelGGL(k_fd_scan<1>, dim3(grid), dim3(kFsThreads), sizeof(FsShared), st, p, n_items);
+  else hipLaunchKernelGGL(k_fd_scan<0>, dim3(grid), dim3(kFsThreads), sizeof(FsShared), st, p, n_items);
+}
 }  // namespace
 
 extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const anr_fuse_source *src,
@@ -901,11 +1106,11 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
   }
   DeviceGuard g(device);
   if (!g.ok) return fail(ANR_EHIP, "hipSetDevice(%d) failed", device);
-  const int n_chunks = (int)ceil_div(U, kFdChunk);
+  const int n_chunks = (int)ceil_div(U, kFsChunk);
   const int lcap = (int)std::max<int64_t>(256, round_up(std::min<int64_t>(kFdMaxK, pool + kFdMaxSparse), 64));
-  // query sub-batches so that the candidate lists stay below ~256 MiB
+  // query sub-batches so that the candidate lists stay below ~512 MiB
   const int64_t per_q = (int64_t)n_chunks * lcap * 12;
-  const int64_t QB = std::max<int64_t>(1, std::min<int64_t>(nq, ((int64_t)256 << 20) / std::max<int64_t>(per_q, 1)));
+  const int64_t QB = std::max<int64_t>(1, std::min<int64_t>(nq, ((int64_t)512 << 20) / std::max<int64_t>(per_q, 1)));
   DevBuf b_lids, b_lsc, b_offs, b_kp, b_su, b_sun, b_skh, b_ski, b_skn, b_H, b_smax, b_tau, b_T, b_chi, b_cid, b_ccnt,
       b_oi, b_os, b_or, b_oo, b_om, b_xi, b_xf, b_xs, b_xc;
   ANR_TRY(b_lids.alloc(lids.size() * 8));
@@ -937,7 +1142,8 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
     ANR_HIP(hipMemcpy(b_lids.p, lids.data(), lids.size() * 8, hipMemcpyHostToDevice));
     ANR_HIP(hipMemcpy(b_lsc.p, lsc.data(), lsc.size() * 8, hipMemcpyHostToDevice));
   }
-  ANR_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_fd_scan), (int)sizeof(FdShared)));
+  ANR_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_fd_scan<0>), (int)sizeof(FsShared)));
+  ANR_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_fd_scan<1>), (int)sizeof(FsShared)));
   ANR_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_fd_build), (int)sizeof(FdShared)));
   ANR_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_fuse<true>), (int)sizeof(FuseShared)));
   hipEvent_t ev[2] = {nullptr, nullptr};
@@ -949,9 +1155,6 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
   }
   int rc = ANR_OK;
   hipStream_t st = nullptr;
-  DevBuf b_st;
-  const bool want_stamps = getenv("ANORAG_FD_STAMPS") != nullptr;
-  if (want_stamps) ANR_TRY(b_st.alloc(32 * 8));
   for (int64_t q0 = 0; q0 < nq && rc == ANR_OK; q0 += QB) {
     const int64_t nb = std::min(QB, nq - q0);
     FdParams p{};
@@ -990,7 +1193,6 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
     p.o_rank = b_or.as<int>();
     p.o_offs = b_oo.as<int64_t>();
     p.o_smax = b_om.as<double>();
-    p.stamps = want_stamps ? b_st.as<unsigned long long>() : nullptr;
     hipError_t e = hipMemcpyAsync(b_offs.p, offs.data() + q0 * 5, (size_t)nb * 5 * 8, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemsetAsync(b_H.p, 0, (size_t)nb * (kFdMaxSparse + 1) * 4, st);
     if (e == hipSuccess) e = hipMemsetAsync(b_smax.p, 0, (size_t)nb * 4 * 8, st);
@@ -1003,16 +1205,20 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
     }
     hipLaunchKernelGGL(k_fd_prep, dim3((unsigned)nb), dim3(kFdThreads), 0, st, p);
     if (timed) (void)hipEventRecord(ev[0], st);
-    if (method == 0) hipLaunchKernelGGL(k_fd_max, dim3((unsigned)n_chunks, (unsigned)nb), dim3(kFdThreads), 0, st, p);
+    if (method == 0) {
+      const int64_t n8 = ceil_div(U, kFdChunk);
+      const int64_t gx = std::max<int64_t>(1, std::min<int64_t>(n8, ceil_div(4 * (int64_t)device_cu_count(device), nb)));
+      hipLaunchKernelGGL(k_fd_max, dim3((unsigned)gx, (unsigned)nb), dim3(kFdThreads), 0, st, p);
+    }
     const int n_cu = device_cu_count(device);
     p.chunk0 = 0;
     p.prefix = 1;
-    hipLaunchKernelGGL(k_fd_scan, dim3((unsigned)std::min<int64_t>(nb, n_cu)), dim3(kFdThreads), sizeof(FdShared), st, p, nb);
+    launch_scan(method, (unsigned)std::min<int64_t>(nb, 2 * n_cu), st, p, nb);
     if (n_chunks > 1) {
       p.chunk0 = 1;
       p.prefix = 0;
       const int64_t items = nb * (int64_t)(n_chunks - 1);
-      hipLaunchKernelGGL(k_fd_scan, dim3((unsigned)std::min<int64_t>(items, n_cu)), dim3(kFdThreads), sizeof(FdShared), st, p, items);
+      launch_scan(method, (unsigned)std::min<int64_t>(items, 2 * n_cu), st, p, items);
     }
     if (timed) (void)hipEventRecord(ev[1], st);
     hipLaunchKernelGGL(k_fd_build, dim3((unsigned)nb), dim3(kFdThreads), sizeof(FdShared), st, p);
@@ -1040,17 +1246,6 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
     if (e != hipSuccess) {
       rc = fail(ANR_EHIP, "fuse_dense failed: %s", hipGetErrorString(e));
       break;
-    }
-    if (want_stamps) {
-      unsigned long long sv[32];
-      if (hipMemcpy(sv, b_st.p, sizeof sv, hipMemcpyDeviceToHost) == hipSuccess) {
-        fprintf(stderr, "[fd] wave arrivals at the chunk barrier (us after the rank phase of wave 0):");
-        for (int w = 0; w < 16; ++w) fprintf(stderr, " %.1f", (double)((long long)sv[16 + w] - (long long)sv[3]) / 100.0);
-        fprintf(stderr, "\n");
-        auto us = [&](int a, int b) { return (double)((long long)sv[b] - (long long)sv[a]) / 100.0; };
-        fprintf(stderr, "[fd] chunk: zero+barrier %.2f loads+keys %.2f ranks %.2f compact+barrier %.2f emit %.2f us\n", us(0, 1), us(1, 2),
-                us(2, 3), us(3, 4), us(4, 5));
-      }
     }
     if (timed) {
       float ms = 0.f;

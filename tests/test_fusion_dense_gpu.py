@@ -177,7 +177,7 @@ def test_adversarial_orders_keep_the_candidate_lists_bounded():
             e_ids, e_fin = ofu.fuse_arrays(n, (dense[q], (full, bm[q]), None, None), [1.0, 0.5, 0.0, 0.0], method, 60, pool)
             assert cnt[q] == pool and fin[q].tolist() == e_fin.tolist()
             assert ids[q].tolist() == e_ids.tolist()
-        assert st["n_candidates"] <= 3 * ((n + 8191) // 8192) * 1100
+        assert st["n_candidates"] <= 3 * ((n + 4095) // 4096) * 1100
     arr.free()
 
 
