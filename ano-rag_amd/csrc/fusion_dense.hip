@@ -24,6 +24,8 @@
 // always candidates.  Ties: final desc, then the reference's order (rrf: ranks-dict insertion; linear: lower id,
 // where the reference iterates a set).
 #include <algorithm>
+#include <mutex>
+#include <cstring>
 #include <vector>
 
 #include "fusion_kernels.hpp"
@@ -456,38 +458,59 @@ __global__ __launch_bounds__(kFdThreads) void k_fd_max(FdParams p) {
 //     a sparse wave are DEFERRED to an LDS list that all threads search together every ~100 chunks (a 7-round
 //     dependent-LDS binary search inside the chunk made one wave late for the barrier every time); a wave with many
 //     non-zero entries (a dense vector) searches in place.
-constexpr int kFsPend = 768;     // deferred rank searches held in LDS
+constexpr int kFsWaves = kFsThreads / 64;
+constexpr int kFsPendW = 96;     // deferred rank searches held in LDS, per wave (a private segment: no atomics)
 constexpr int kFsPushMax = 8;    // a wave defers at most this many entries per chunk (more: it searches in place)
-constexpr unsigned kFsDrainAt = kFsPend - 3 * (kFsThreads / 64) * kFsPushMax;
+constexpr unsigned kFsDrainAt = kFsPendW - 3 * kFsPushMax;  // the drain is decided one chunk ahead, acted on one later
 struct FsShared : FdSharedT<kFsChunk> {
-  unsigned long long pk[kFsPend];
-  unsigned pi[kFsPend];
-  unsigned pn;
-  unsigned n3[3];      // staged entries of chunk c in slot c % 3
-  unsigned drain3[3];  // "search the deferred list after this chunk's barrier"
+  unsigned long long pk[kFsWaves * kFsPendW];
+  unsigned pi[kFsWaves * kFsPendW];
+  unsigned pw_n[kFsWaves];  // entries in each wave's segment (mirrors the wave's register copy)
+  // four-slot rotations indexed by the chunk counter c % 4, so that ONE barrier per chunk orders everything:
+  unsigned n4[4];      // staged entries of chunk c; slot (c + 2) % 4 is cleared after the barrier of chunk c
+  unsigned drain4[4];  // "search the deferred lists after this chunk's barrier": raised for chunk c + 1 by a wave whose
+                       // segment fills up during chunk c; slot (c + 3) % 4 is cleared after the barrier of chunk c
 };
 
 // workgroup barrier that waits for this wave's LDS traffic only (global loads of the next chunk stay in flight)
 __device__ __forceinline__ void fs_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int TH>
-__device__ __forceinline__ void fd_load_raw(const FdSrc &s, int64_t q, int64_t base, int tid, double (&v)[kFdPer]) {
-  const int64_t last = s.len - 1;
-  if (s.dtype == 0) {
-    const double *a = reinterpret_cast<const double *>(s.arr) + q * s.len;
+// the chunk's values of one array: thread tid holds ids base + e * TH + tid.  Chunk base pointer in scalar registers,
+// 32-bit per-thread offsets; only the array's last chunk clamps its index (64-bit index arithmetic and a clamp per
+// load were a third of the scan's instructions).
+template <int TH, int DT>
+__device__ __forceinline__ void fd_load_raw(const FdSrc &s, int64_t q, int64_t base, int tid,
+                                            unsigned long long (&v)[kFdPer]) {
+  // RAW bits (an f32 array's value sits in the low word): converting here would make the prefetch wait for its data.
+  // ONE code path (index clamped with a v_min, dtype a template parameter): with branches the loads landed in
+  // temporaries that had to be copied at the join — a wait for the prefetched data right where it was issued.
+  const int64_t room = s.len - base;  // ids of this array at or after base (may be <= 0: the array is shorter than U)
+  const int lim = room >= TH * kFdPer ? TH * kFdPer - 1 : (room > 0 ? (int)room - 1 : 0);
+  const int64_t row = q * s.len + (room > 0 ? base : s.len - 1);
+  if (DT == 0) {
+    const unsigned long long *a = reinterpret_cast<const unsigned long long *>(s.arr) + row;
 #pragma unroll
     for (int e = 0; e < kFdPer; ++e) {
-      const int64_t i = base + e * TH + tid;
-      v[e] = a[i < last ? i : last];
+      const int i = e * TH + tid;
+      v[e] = a[i < lim ? i : lim];
     }
   } else {
-    const float *a = reinterpret_cast<const float *>(s.arr) + q * s.len;
+    const unsigned *a = reinterpret_cast<const unsigned *>(s.arr) + row;
 #pragma unroll
     for (int e = 0; e < kFdPer; ++e) {
-      const int64_t i = base + e * TH + tid;
-      v[e] = (double)a[i < last ? i : last];
+      const int i = e * TH + tid;
+      v[e] = a[i < lim ? i : lim];
     }
   }
+}
+__device__ __forceinline__ double fd_raw_value(int dtype, unsigned long long bits) {
+  return dtype == 0 ? __longlong_as_double((long long)bits) : (double)__uint_as_float((unsigned)bits);
+}
+// A per-lane copy of a (really uniform) index: a load through it stays in a vector register and is waited for where it
+// is USED — the compiler moves a uniform load to scalar registers on the spot, which waits for it on the spot.
+__device__ __forceinline__ int fd_per_lane(int x) {
+  asm volatile("" : "+v"(x));
+  return x;
 }
 
 struct FsState {
@@ -496,13 +519,14 @@ struct FsState {
   unsigned long long tau0;
   int z_hi;   // rrf: short-list keys at or above zero (the zero-valued ones end here)
   int zp, zc; // rrf: short-list keys beating a zero entry at the first id of chunk zc
-  int par;    // chunk counter mod 3
+  int par;    // chunk counter mod 4
+  unsigned pw; // deferred entries in this wave's segment
 };
 
 // one chunk; `raw` = the prefetched values of array source s0, T = the running threshold read with them
-template <int METHOD>
+template <int METHOD, int DT0>
 __device__ __forceinline__ void fd_scan_chunk(const FdParams &p, FsShared &sh, FsState &st, const int q, const int c,
-                                              const int s0, const double (&raw)[kFdPer], const unsigned long long T) {
+                                              const int s0, const unsigned long long (&raw)[kFdPer], const unsigned long long T) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int64_t base = (int64_t)c * kFsChunk;
   const int skn = st.skn;
@@ -524,22 +548,28 @@ __device__ __forceinline__ void fd_scan_chunk(const FdParams &p, FsShared &sh, F
     }
     return lo;
   };
-  // ---- values and validity, in the double domain ----
+  // ---- values, in the double domain ----
+  // Everything per entry is expressed as WAVE MASKS (a v_cmp writes its 64-lane result straight into a scalar pair):
+  // per entry two to four compares, the rest is scalar; per-lane work only in the rare branches.  (Per-lane bit masks
+  // and exec-masked `if`s cost ~450 instructions per wave and chunk, and the scan is issue-bound.)
   double f[kFdPer];
-  bool valid[kFdPer];
+  auto ids_in_chunk = [&](const FdSrc &a) -> int {  // how many of the chunk's ids array a has
+    const int64_t room = a.len - base;
+    return room >= kFsChunk ? kFsChunk : (room > 0 ? (int)room : 0);
+  };
+  int nvalid = 0;           // METHOD 1: ids of the array in this chunk
+  unsigned long long vb[kFdPer];  // METHOD 0: lanes whose entry e has a value in at least one source
   if (METHOD == 1) {
+    nvalid = ids_in_chunk(p.src[s0]);
 #pragma unroll
-    for (int e = 0; e < kFdPer; ++e) {
-      f[e] = raw[e];
-      valid[e] = base + e * kFsThreads + tid < p.src[s0].len && raw[e] == raw[e];
-    }
+    for (int e = 0; e < kFdPer; ++e) f[e] = fd_raw_value(DT0, raw[e]);
   } else {
     // source after source, in the order fd_key adds them; a zero entry skips the f64 division (x / smax for x = +-0 is
-    // +-0 with the sign of x * smax, which is what the select below produces)
+    // +-0 with the sign of x * smax) — and a wave whose 64 entries are all zero skips it altogether
 #pragma unroll
     for (int e = 0; e < kFdPer; ++e) {
       f[e] = 0.0;
-      valid[e] = false;
+      vb[e] = 0ull;
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -550,150 +580,171 @@ __device__ __forceinline__ void fd_scan_chunk(const FdParams &p, FsShared &sh, F
         }
         continue;
       }
-      double v[kFdPer];
+      unsigned long long v[kFdPer];
       if (s == s0) {
 #pragma unroll
         for (int e = 0; e < kFdPer; ++e) v[e] = raw[e];
+      } else if (p.src[s].dtype == 0) {
+        fd_load_raw<kFsThreads, 0>(p.src[s], p.q0 + q, base, tid, v);
       } else {
-        fd_load_raw<kFsThreads>(p.src[s], p.q0 + q, base, tid, v);
+        fd_load_raw<kFsThreads, 1>(p.src[s], p.q0 + q, base, tid, v);
       }
       const double sm = s < 3 ? st.smax[s] : 0.0, w = p.w[s];
+      const int nv = ids_in_chunk(p.src[s]);
+      const int dt = s == s0 ? DT0 : p.src[s].dtype;
 #pragma unroll
       for (int e = 0; e < kFdPer; ++e) {
-        const double x = v[e];
-        const bool ok = base + e * kFsThreads + tid < p.src[s].len && x == x;
+        const double x = fd_raw_value(dt, v[e]);
+        const bool ok = (nv == kFsChunk || e * kFsThreads + tid < nv) && x == x;
+        vb[e] |= __ballot(ok);
         if (s < 3) {
-          if (ok) {
-            double r = 0.0;
-            if (sm != 0.0) {
-              if (x == 0.0) r = sm < 0.0 ? -x : x;
-              else r = x / sm;
-            }
-            f[e] += w * r;
-            valid[e] = true;
-          }
+          double r = sm < 0.0 ? -x : x;                       // the quotient of a zero entry
+          if (__any(ok && x != 0.0)) r = x == 0.0 ? r : x / sm;  // (uniform branch)
+          if (sm == 0.0) r = 0.0;
+          const double t = f[e] + w * r;
+          f[e] = ok ? t : f[e];
         } else {
           f[e] = f[e] + (ok ? w * x : w * 0.0);
-          valid[e] = valid[e] || ok;
         }
       }
     }
   }
-  const bool has_t0 = st.tau0 != 0ull, has_T = T != 0ull;
-  const double t0d = has_t0 ? ord2d(st.tau0) : 0.0, Td = has_T ? ord2d(T) : 0.0;
+  // lanes whose entry e exists (METHOD 1: in range and not NaN)
+  auto valid_mask = [&](int e) -> unsigned long long {
+    if (METHOD == 0) return vb[e];
+    return nvalid == kFsChunk ? __ballot(f[e] == f[e]) : __ballot(e * kFsThreads + tid < nvalid && f[e] == f[e]);
+  };
+  const unsigned long long Tu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(T >> 32)) << 32) |
+                                (unsigned)__builtin_amdgcn_readfirstlane((int)T);
+  const bool has_t0 = st.tau0 != 0ull, has_T = Tu != 0ull;
+  const double t0d = has_t0 ? ord2d(st.tau0) : 0.0, Td = has_T ? ord2d(Tu) : 0.0;
+  // lanes whose entry e passes both thresholds (for non-NaN doubles d2ord is strictly monotone with -0 == +0: exactly
+  // these double comparisons)
+  auto pass_mask = [&](int e) -> unsigned long long {
+    unsigned long long m = valid_mask(e);
+    if (has_t0) m &= __ballot(f[e] > t0d);
+    if (has_T) m &= __ballot(f[e] >= Td);
+    return m;
+  };
   const int par = st.par;
-  // ---- rrf: rank histogram ----
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  // do zero entries pass the thresholds?  (Almost never: chunk 0's K'-th best is >= 0 in a mostly-zero vector.)
+  const bool zero_passes = (!has_t0 || 0.0 > t0d) && (!has_T || 0.0 >= Td);
+  // ---- rrf bookkeeping for the zero entries ----
+  // short-list keys [pb_z0, pb_z1) are exactly the zero-valued short-list ids that lie inside this chunk, in id order
+  int pb_z0 = 0, nzid = 0;
+  int64_t sid0 = 0;      // the first (usually only) such id
+  unsigned cnt0 = 0, cnt1 = 0;  // zero entries of this wave with count pb_z0 / pb_z0 + 1
+  unsigned wtotal = 0;   // upper bound of the wave's non-zero entries
   if (ranks) {
-    // short-list keys [pb_z0, pb_z1) are exactly the zero-valued short-list ids that lie inside this chunk, in id order
     if (c != st.zc) st.zp = beaten_by(kzero, base);  // first chunk of a run; afterwards the pointer just advances
-    const int pb_z0 = st.zp;
+    pb_z0 = st.zp;
     int pb_z1 = pb_z0;
     while (pb_z1 < st.z_hi && (int64_t)sh.sk_id[pb_z1] < base + kFsChunk) ++pb_z1;
     st.zp = pb_z1;
     st.zc = c + 1;
-    unsigned pend = 0, zmask = 0;
+    nzid = pb_z1 - pb_z0;
+    if (nzid > 0) sid0 = (int64_t)sh.sk_id[pb_z0];
 #pragma unroll
-    for (int e = 0; e < kFdPer; ++e)
-      if (valid[e]) {
-        if (f[e] == 0.0) zmask |= 1u << e;
-        else pend |= 1u << e;
-      }
-    if (pb_z0 == pb_z1) {  // no such id in this chunk (nearly always): every zero entry of the wave has count pb_z0
-      unsigned nz = 0;
-#pragma unroll
-      for (int e = 0; e < kFdPer; ++e) nz += (unsigned)__popcll(__ballot((zmask >> e) & 1u));
-      if (lane == 0 && nz) atomicAdd(&sh.H[pb_z0], nz);
-    } else {
-#pragma unroll
-      for (int e = 0; e < kFdPer; ++e) {
-        const int64_t i = base + e * kFsThreads + tid;
-        const bool z = (zmask >> e) & 1u;
-        unsigned pb = (unsigned)pb_z0;
-        for (int j = pb_z0; j < pb_z1; ++j) pb += ((int64_t)sh.sk_id[j] < i) ? 1u : 0u;
-        const unsigned long long m = __ballot(z);
-        if (m) {  // wave-aggregated add for the leader's count, one atomic each for the rest
-          const int leader = __ffsll((long long)m) - 1;
-          const unsigned pl = (unsigned)__builtin_amdgcn_readlane((int)pb, leader);
-          const unsigned long long same = __ballot(z && pb == pl);
-          if (lane == leader) atomicAdd(&sh.H[pl], (unsigned)__popcll(same));
-          if (z && pb != pl) atomicAdd(&sh.H[pb], 1u);
-        }
-      }
-    }
-    if (__any(pend != 0)) {
-      unsigned wtotal = 0;
-#pragma unroll
-      for (int e = 0; e < kFdPer; ++e) wtotal += (unsigned)__popcll(__ballot((pend >> e) & 1u));
-      if (wtotal <= (unsigned)kFsPushMax) {  // a sparse wave: defer its searches
-        unsigned wb = 0;
-        if (lane == 0) wb = atomicAdd(&sh.pn, wtotal);
-        wb = (unsigned)__builtin_amdgcn_readfirstlane((int)wb);
-#pragma unroll
-        for (int e = 0; e < kFdPer; ++e) {
-          const bool b = (pend >> e) & 1u;
-          const unsigned long long m = __ballot(b);
-          if (m) {
-            if (b) {
-              const unsigned pos = wb + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-              sh.pk[pos] = d2ord(f[e]);
-              sh.pi[pos] = (unsigned)(base + e * kFsThreads + tid);
-            }
-            wb += (unsigned)__popcll(m);
-          }
-        }
-      } else {  // a dense wave: one search per round while any lane still has one
-        while (__any(pend != 0)) {
-          const int e = pend ? __ffs(pend) - 1 : -1;
-          double x = 0.0;
-#pragma unroll
-          for (int ee = 0; ee < kFdPer; ++ee)
-            if (ee == e) x = f[ee];
-          const int r = beaten_by(d2ord(x), base + (int64_t)e * kFsThreads + tid);
-          if (e >= 0) atomicAdd(&sh.H[r], 1u);
-          pend &= pend - 1;
-        }
-      }
-    }
+    for (int e = 0; e < kFdPer; ++e) wtotal += (unsigned)__popcll(__ballot(!(f[e] == 0.0)));
   }
-  // ---- entries that pass both thresholds are staged ----
-  unsigned pmask = 0;
+  const bool defer = wtotal <= (unsigned)kFsPushMax;  // a sparse wave defers its searches to its own LDS segment
+  const int wstart = tid & ~63;
+  // zero entries zb of entry row e: their rank counts, all in scalar registers unless two or more ids fall in the chunk
+  auto add_zeros = [&](int e, unsigned long long zb) {
+    if (nzid == 0) {
+      cnt0 += (unsigned)__popcll(zb);
+    } else if (nzid == 1) {
+      const int64_t rel = sid0 - (base + e * kFsThreads + wstart);  // lanes <= rel hold ids <= sid0
+      const unsigned long long below = rel < 0 ? 0ull : (rel >= 63 ? ~0ull : ((2ull << rel) - 1ull));
+      cnt0 += (unsigned)__popcll(zb & below);
+      cnt1 += (unsigned)__popcll(zb & ~below);
+    } else {
+      const int64_t i = base + e * kFsThreads + tid;
+      unsigned pb = (unsigned)pb_z0;
+      for (int j = 0; j < nzid; ++j) pb += ((int64_t)sh.sk_id[pb_z0 + j] < i) ? 1u : 0u;
+      if ((zb >> lane) & 1ull) atomicAdd(&sh.H[pb], 1u);
+    }
+  };
+  // ---- one pass over the entry rows: an all-zero row (94 % of them at BM25 density) costs three instructions ----
 #pragma unroll
   for (int e = 0; e < kFdPer; ++e) {
-    const bool pass = valid[e] && (!has_t0 || f[e] > t0d) && (!has_T || f[e] >= Td);
-    pmask |= pass ? 1u << e : 0u;
-  }
-  if (__any(pmask != 0)) {
-#pragma unroll
-    for (int e = 0; e < kFdPer; ++e) {
-      const bool pass = (pmask >> e) & 1u;
-      const unsigned long long pm = __ballot(pass);
-      if (pm) {
-        unsigned wbase = 0;
-        if (lane == 0) wbase = atomicAdd(&sh.n3[par], (unsigned)__popcll(pm));
-        wbase = (unsigned)__builtin_amdgcn_readfirstlane((int)wbase);
-        if (pass) {
-          const unsigned pos = wbase + (unsigned)__popcll(pm & ((1ull << lane) - 1ull));
-          sh.hi[pos] = d2ord(f[e]);
-          sh.idx[pos] = (unsigned)(base + e * kFsThreads + tid);
+    const unsigned long long nzm = __ballot(!(f[e] == 0.0));  // non-zero or NaN
+    if (nzm == 0ull && !zero_passes) {
+      if (ranks) add_zeros(e, valid_mask(e));
+      continue;
+    }
+    const unsigned long long ok = valid_mask(e);
+    if (ranks) {
+      add_zeros(e, ok & ~nzm);
+      const unsigned long long nb = ok & nzm;
+      if (nb && defer) {
+        if ((nb >> lane) & 1ull) {
+          const unsigned pos = (unsigned)(tid >> 6) * kFsPendW + st.pw + (unsigned)__popcll(nb & lt_mask);
+          sh.pk[pos] = d2ord(f[e]);
+          sh.pi[pos] = (unsigned)(base + e * kFsThreads + tid);
         }
+        st.pw += (unsigned)__popcll(nb);
+      }
+    }
+    const unsigned long long pm = pass_mask(e);
+    if (pm) {
+      unsigned wbase = 0;
+      if (lane == 0) wbase = atomicAdd(&sh.n4[par], (unsigned)__popcll(pm));
+      wbase = (unsigned)__builtin_amdgcn_readfirstlane((int)wbase);
+      if ((pm >> lane) & 1ull) {
+        const unsigned pos = wbase + (unsigned)__popcll(pm & lt_mask);
+        sh.hi[pos] = d2ord(f[e]);
+        sh.idx[pos] = (unsigned)(base + e * kFsThreads + tid);
+      }
+    }
+  }
+  if (ranks) {
+    if (lane == 0) {
+      if (cnt0) atomicAdd(&sh.H[pb_z0], cnt0);
+      if (cnt1) atomicAdd(&sh.H[pb_z0 + 1], cnt1);
+      if (defer && wtotal) {
+        sh.pw_n[tid >> 6] = st.pw;
+        if (st.pw > kFsDrainAt) sh.drain4[(par + 1) & 3] = 1;  // acted on after the NEXT chunk's barrier
+      }
+    }
+    if (!defer) {  // a dense wave: one search per round while any lane still has one
+      unsigned pend = 0;
+#pragma unroll
+      for (int e = 0; e < kFdPer; ++e) {
+        const unsigned long long nb = valid_mask(e) & __ballot(!(f[e] == 0.0));
+        pend |= (unsigned)((nb >> lane) & 1ull) << e;
+      }
+      while (__any(pend != 0)) {
+        const int e = pend ? __ffs(pend) - 1 : -1;
+        double x = 0.0;
+#pragma unroll
+        for (int ee = 0; ee < kFdPer; ++ee)
+          if (ee == e) x = f[ee];
+        const int r = beaten_by(d2ord(x), base + (int64_t)e * kFsThreads + tid);
+        if (e >= 0) atomicAdd(&sh.H[r], 1u);
+        pend &= pend - 1;
       }
     }
   }
   fs_barrier();  // ---- the chunk barrier ----
-  const int n = (int)sh.n3[par];
-  const bool drain = METHOD == 1 && sh.drain3[par] != 0;
-  if (drain) {
-    const int pn = (int)sh.pn;  // stable: this chunk's pushes are behind the barrier, the next chunk's behind the ones below
-    for (int i = tid; i < pn; i += kFsThreads) atomicAdd(&sh.H[beaten_by(sh.pk[i], (int64_t)sh.pi[i])], 1u);
+  const int n = (int)sh.n4[par];
+  const bool drain = METHOD == 1 && sh.drain4[par] != 0;
+  if (drain) {  // (uniform: the flag was raised before this chunk's barrier at the latest)
+    for (int w = 0; w < kFsWaves; ++w) {
+      const int pn = (int)sh.pw_n[w];
+      for (int i = tid; i < pn; i += kFsThreads)
+        atomicAdd(&sh.H[beaten_by(sh.pk[w * kFsPendW + i], (int64_t)sh.pi[w * kFsPendW + i])], 1u);
+    }
     fs_barrier();
-    if (tid == 0) sh.pn = 0;
-    fs_barrier();
+    if (lane == 0) sh.pw_n[tid >> 6] = 0;
+    st.pw = 0;
   }
   if (tid == 0) {
-    sh.n3[par == 0 ? 2 : par - 1] = 0;                       // slot of chunk c + 2
-    sh.drain3[par == 2 ? 0 : par + 1] = sh.pn > kFsDrainAt;  // decided now, acted on after the next chunk's barrier
+    sh.n4[(par + 2) & 3] = 0;
+    sh.drain4[(par + 3) & 3] = 0;
   }
-  st.par = par == 2 ? 0 : par + 1;
+  st.par = (par + 1) & 3;
   if (n == 0) return;  // (c_cnt and tau0 were zeroed by the host)
   unsigned long long *lh = p.c_hi + ((int64_t)q * p.n_chunks + c) * p.lcap;
   unsigned *li = p.c_id + ((int64_t)q * p.n_chunks + c) * p.lcap;
@@ -736,7 +787,7 @@ __device__ __forceinline__ void fd_scan_chunk(const FdParams &p, FsShared &sh, F
   __syncthreads();
 }
 
-template <int METHOD>
+template <int METHOD, int DT0>  // DT0: dtype of the prefetched array source
 __global__ __launch_bounds__(kFsThreads, 4) void k_fd_scan(FdParams p, int64_t n_items) {
   extern __shared__ unsigned char fd_smem[];
   FsShared &sh = *reinterpret_cast<FsShared *>(fd_smem);
@@ -750,63 +801,74 @@ __global__ __launch_bounds__(kFsThreads, 4) void k_fd_scan(FdParams p, int64_t n
   st.cur_q = -1;
   st.zc = -1;
   if (tid == 0) {
-    sh.pn = 0;
-    sh.n3[0] = sh.n3[1] = sh.n3[2] = 0;
-    sh.drain3[0] = sh.drain3[1] = sh.drain3[2] = 0;
+    for (int i = 0; i < 4; ++i) sh.n4[i] = sh.drain4[i] = 0;
+    for (int w = 0; w < kFsWaves; ++w) sh.pw_n[w] = 0;
   }
   __syncthreads();
   const unsigned long long kzero = 0x8000000000000000ull;
   auto finish_query = [&]() {  // deferred searches, then the finished query's rank histogram joins the global one
     if (st.cur_q >= 0 && METHOD == 1 && st.skn > 0) {
-      const int skn = st.skn, pn = (int)sh.pn;
-      for (int i = tid; i < pn; i += kFsThreads) {
-        const unsigned long long k = sh.pk[i];
-        const int64_t id = (int64_t)sh.pi[i];
-        int lo = 0, hi = skn;
-        while (lo < hi) {
-          const int mid = (lo + hi) >> 1;
-          const unsigned long long kh = sh.sk_hi[mid];
-          if (kh > k || (kh == k && (int64_t)sh.sk_id[mid] < id)) lo = mid + 1;
-          else hi = mid;
+      const int skn = st.skn;
+      for (int w = 0; w < kFsWaves; ++w) {
+        const int pn = (int)sh.pw_n[w];
+        for (int i = tid; i < pn; i += kFsThreads) {
+          const unsigned long long k = sh.pk[w * kFsPendW + i];
+          const int64_t id = (int64_t)sh.pi[w * kFsPendW + i];
+          int lo = 0, hi = skn;
+          while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            const unsigned long long kh = sh.sk_hi[mid];
+            if (kh > k || (kh == k && (int64_t)sh.sk_id[mid] < id)) lo = mid + 1;
+            else hi = mid;
+          }
+          atomicAdd(&sh.H[lo], 1u);
         }
-        atomicAdd(&sh.H[lo], 1u);
       }
       __syncthreads();
-      if (tid == 0) sh.pn = 0;
+      if ((tid & 63) == 0) sh.pw_n[tid >> 6] = 0;
+      st.pw = 0;
+      for (int i = 0; i < 4; ++i)
+        if (tid == 0) sh.drain4[i] = 0;  // (a pending request is moot: the segments are empty)
       unsigned *Hq = p.H + (int64_t)st.cur_q * (kFdMaxSparse + 1);
       for (int i = tid; i <= skn; i += kFsThreads)
         if (sh.H[i]) atomicAdd(Hq + i, sh.H[i]);
     }
   };
-  auto item_qc = [&](int64_t item, int &q, int &c) {
-    q = (int)(item / per_q);
-    c = p.prefix ? 0 : 1 + (int)(item % per_q);
+  // (query, chunk) of an item advance incrementally — a 64-bit division per item was ~300 scalar instructions per chunk
+  auto advance = [&](int &q, int &c) {
+    if (p.prefix) ++q;
+    else if (++c == p.n_chunks) {
+      c = 1;
+      ++q;
+    }
   };
   auto load_T = [&](int q) -> unsigned long long {
     // a plain (cached) load: T only ever rises and any earlier value is still a valid threshold, so a stale line costs
     // a few extra candidates at worst — an agent-scope atomic load went past the L2 and took ~4 us per chunk
-    return p.prefix ? 0ull : *reinterpret_cast<const volatile unsigned long long *>(p.T + q);
+    // (relaxed agent-scope atomic: re-read every chunk, but — unlike a volatile load — not waited for on the spot; it
+    // is consumed one chunk later, with the prefetched values)
+    return p.prefix ? 0ull : __hip_atomic_load(p.T + fd_per_lane(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
-  double nxt[kFdPer];
+  unsigned long long nxt[kFdPer];
   unsigned long long T_nxt = 0ull;
+  int q = 0, c = 0, q2 = 0, c2 = 0;
   if (it0 < it1) {
-    int q, c;
-    item_qc(it0, q, c);
-    T_nxt = load_T(q);
-    fd_load_raw<kFsThreads>(p.src[s0], p.q0 + q, (int64_t)c * kFsChunk, tid, nxt);
+    q2 = (int)(it0 / per_q);
+    c2 = p.prefix ? 0 : 1 + (int)(it0 % per_q);
+    T_nxt = load_T(q2);
+    fd_load_raw<kFsThreads, DT0>(p.src[s0], p.q0 + q2, (int64_t)c2 * kFsChunk, tid, nxt);
   }
   for (int64_t item = it0; item < it1; ++item) {
-    int q, c;
-    item_qc(item, q, c);
-    double raw[kFdPer];
+    q = q2;
+    c = c2;
+    unsigned long long raw[kFdPer];
 #pragma unroll
     for (int e = 0; e < kFdPer; ++e) raw[e] = nxt[e];
     const unsigned long long T = T_nxt;
     if (item + 1 < it1) {
-      int q2, c2;
-      item_qc(item + 1, q2, c2);
+      advance(q2, c2);
       T_nxt = load_T(q2);
-      fd_load_raw<kFsThreads>(p.src[s0], p.q0 + q2, (int64_t)c2 * kFsChunk, tid, nxt);
+      fd_load_raw<kFsThreads, DT0>(p.src[s0], p.q0 + q2, (int64_t)c2 * kFsChunk, tid, nxt);
     }
     if (q != st.cur_q) {
       __syncthreads();
@@ -841,7 +903,7 @@ __global__ __launch_bounds__(kFsThreads, 4) void k_fd_scan(FdParams p, int64_t n
         st.zc = -1;
       }
     }
-    fd_scan_chunk<METHOD>(p, sh, st, q, c, s0, raw, T);
+    fd_scan_chunk<METHOD, DT0>(p, sh, st, q, c, s0, raw, T);
   }
   __syncthreads();
   finish_query();
@@ -852,6 +914,8 @@ __global__ __launch_bounds__(kFdThreads) void k_fd_build(FdParams p) {
   extern __shared__ unsigned char fd_smem[];
   FdShared &sh = *reinterpret_cast<FdShared *>(fd_smem);
   __shared__ unsigned s_off[6];
+  __shared__ unsigned s_pref[kFdThreads + 1];
+  __shared__ unsigned s_wsum[kFdThreads / 64];
   const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int kp = p.kprime[q];
   int n = 0;
@@ -889,18 +953,57 @@ __global__ __launch_bounds__(kFdThreads) void k_fd_build(FdParams p) {
     __syncthreads();
     n = kp;
   };
-  for (int c = 0; c < p.n_chunks; ++c) {
-    const int cnt = (int)p.c_cnt[(int64_t)q * p.n_chunks + c];
-    if (cnt == 0) continue;
-    if (n + cnt > kFdChunk) reduce();
-    const unsigned long long *lh = p.c_hi + ((int64_t)q * p.n_chunks + c) * p.lcap;
-    const unsigned *li = p.c_id + ((int64_t)q * p.n_chunks + c) * p.lcap;
-    for (int i = tid; i < cnt; i += kFdThreads) {
-      sh.hi[n + i] = lh[i];
-      sh.idx[n + i] = li[i];
+  // gather the chunk lists, a tile of kFdThreads chunks at a time: counts -> prefix sums in LDS, then one thread per
+  // ENTRY (its chunk found by bisection).  (One chunk after the other — a dependent count load, a handful of entries,
+  // a barrier — took 0.75 us per chunk: 180 us at 244 chunks.)
+  for (int tile0 = 0; tile0 < p.n_chunks; tile0 += kFdThreads) {
+    const int nt = p.n_chunks - tile0 < kFdThreads ? p.n_chunks - tile0 : kFdThreads;
+    const unsigned cnt = tid < nt ? p.c_cnt[(int64_t)q * p.n_chunks + tile0 + tid] : 0u;
+    unsigned incl = cnt;
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned t = __shfl_up(incl, o);
+      if (lane >= o) incl += t;
     }
-    n += cnt;
+    __syncthreads();  // (s_pref / s_wsum of the previous tile are no longer read)
+    if (lane == 63) s_wsum[tid >> 6] = incl;
     __syncthreads();
+    unsigned woff = 0;
+    for (int w = 0; w < (tid >> 6); ++w) woff += s_wsum[w];
+    s_pref[tid + 1] = woff + incl;
+    if (tid == 0) s_pref[0] = 0;
+    __syncthreads();
+    int g0 = 0;
+    while (g0 < nt) {
+      // the longest run of chunks [g0, g1) whose entries still fit the staging area
+      const unsigned limit = s_pref[g0] + (unsigned)(kFdChunk - n);
+      int lo = g0, hi = nt;  // largest g1 with s_pref[g1] <= limit
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (s_pref[mid] <= limit) lo = mid;
+        else hi = mid - 1;
+      }
+      const int g1 = lo;
+      if (g1 == g0) {  // not even one more chunk fits: keep the best kp and go on (a list holds <= lcap entries)
+        reduce();
+        continue;
+      }
+      const unsigned first = s_pref[g0], total = s_pref[g1] - first;
+      for (unsigned i = tid; i < total; i += kFdThreads) {
+        const unsigned target = first + i;
+        int a = g0, b = g1 - 1;  // the chunk j with s_pref[j] <= target < s_pref[j + 1]
+        while (a < b) {
+          const int mid = (a + b + 1) >> 1;
+          if (s_pref[mid] <= target) a = mid;
+          else b = mid - 1;
+        }
+        const int64_t at = ((int64_t)q * p.n_chunks + tile0 + a) * p.lcap + (target - s_pref[a]);
+        sh.hi[n + i] = p.c_hi[at];
+        sh.idx[n + i] = p.c_id[at];
+      }
+      n += (int)total;
+      g0 = g1;
+      __syncthreads();
+    }
   }
   reduce();
   // order the n <= kFdMaxK candidates: (key desc, id asc) by rank counting into the upper half of the arrays
@@ -1033,21 +1136,57 @@ __global__ __launch_bounds__(kFdThreads) void k_fd_build(FdParams p) {
 using namespace anr;
 
 namespace {
-struct DevBuf {
-  void *p = nullptr;
-  ~DevBuf() {
-    if (p) (void)hipFree(p);
-  }
-  template <typename T>
-  T *as() { return reinterpret_cast<T *>(p); }
-  int alloc(size_t bytes) {
-    if (hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) return fail(ANR_EHIP, "hipMalloc(%zu) failed", bytes);
+// Work space of anr_fuse_dense: ONE device block and one pinned host block per device, grown on demand and kept for
+// the life of the process (25 hipMalloc/hipFree pairs and pageable copies were ~1.4 ms of a 2.6 ms call).  A call holds
+// the device's arena lock from start to finish, so concurrent calls on one device run one after the other.
+struct FdArena {
+  std::mutex mu;
+  char *dev = nullptr;
+  size_t dev_cap = 0;
+  char *host = nullptr;
+  size_t host_cap = 0;
+  int reserve(size_t dev_bytes, size_t host_bytes) {
+    if (dev_bytes > dev_cap) {
+      if (dev) (void)hipFree(dev);
+      dev = nullptr;
+      dev_cap = 0;
+      const size_t want = dev_bytes + dev_bytes / 4;
+      if (hipMalloc(reinterpret_cast<void **>(&dev), want) != hipSuccess) return fail(ANR_EHIP, "hipMalloc(%zu) failed", want);
+      dev_cap = want;
+    }
+    if (host_bytes > host_cap) {
+      if (host) (void)hipHostFree(host);
+      host = nullptr;
+      host_cap = 0;
+      const size_t want = host_bytes + host_bytes / 4;
+      if (hipHostMalloc(reinterpret_cast<void **>(&host), want, hipHostMallocDefault) != hipSuccess)
+        return fail(ANR_EHIP, "hipHostMalloc(%zu) failed", want);
+      host_cap = want;
+    }
     return ANR_OK;
   }
 };
+constexpr int kFdMaxDevices = 64;
+FdArena g_fd_arena[kFdMaxDevices];
+struct Carve {  // bump allocation inside a block (256-byte aligned pieces)
+  size_t off = 0;
+  size_t take(size_t bytes) {
+    const size_t at = off;
+    off += (bytes + 255) & ~(size_t)255;
+    return at;
+  }
+};
 void launch_scan(int method, unsigned grid, hipStream_t st, const FdParams &p, int64_t n_items) {
-  if (method == 1) hipLaunchKernelGGL(k_fd_scan<1>, dim3(grid), dim3(kFsThreads), sizeof(FsShared), st, p, n_items);
-  else hipLaunchKernelGGL(k_fd_scan<0>, dim3(grid), dim3(kFsThreads), sizeof(FsShared), st, p, n_items);
+  // the prefetched source, as the kernel picks it
+  const int s0 = method == 1 ? p.r1_src : (p.src[0].arr ? 0 : p.src[1].arr ? 1 : p.src[2].arr ? 2 : 3);
+  const int sel = (method == 1 ? 2 : 0) + (p.src[s0].dtype ? 1 : 0);
+  const dim3 g(grid), b(kFsThreads);
+  switch (sel) {
+    case 0: hipLaunchKernelGGL((k_fd_scan<0, 0>), g, b, sizeof(FsShared), st, p, n_items); break;
+    case 1: hipLaunchKernelGGL((k_fd_scan<0, 1>), g, b, sizeof(FsShared), st, p, n_items); break;
+    case 2: hipLaunchKernelGGL((k_fd_scan<1, 0>), g, b, sizeof(FsShared), st, p, n_items); break;
+    default: hipLaunchKernelGGL((k_fd_scan<1, 1>), g, b, sizeof(FsShared), st, p, n_items); break;
+  }
 }
 }  // namespace
 
@@ -1104,46 +1243,41 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
       return fail(ANR_EINVAL, "query %lld: pool %d with %lld short-list entries and %d arrays exceeds the fused kernel's %d entries",
                   (long long)q, pool, (long long)m, n_arr, kFuseMax);
   }
+  if (device < 0 || device >= kFdMaxDevices) return fail(ANR_EINVAL, "device %d out of range", device);
   DeviceGuard g(device);
   if (!g.ok) return fail(ANR_EHIP, "hipSetDevice(%d) failed", device);
   const int n_chunks = (int)ceil_div(U, kFsChunk);
   const int lcap = (int)std::max<int64_t>(256, round_up(std::min<int64_t>(kFdMaxK, pool + kFdMaxSparse), 64));
-  // query sub-batches so that the candidate lists stay below ~512 MiB
+  // query sub-batches so that the candidate lists stay below ~1 GiB
   const int64_t per_q = (int64_t)n_chunks * lcap * 12;
-  const int64_t QB = std::max<int64_t>(1, std::min<int64_t>(nq, ((int64_t)512 << 20) / std::max<int64_t>(per_q, 1)));
-  DevBuf b_lids, b_lsc, b_offs, b_kp, b_su, b_sun, b_skh, b_ski, b_skn, b_H, b_smax, b_tau, b_T, b_chi, b_cid, b_ccnt,
-      b_oi, b_os, b_or, b_oo, b_om, b_xi, b_xf, b_xs, b_xc;
-  ANR_TRY(b_lids.alloc(lids.size() * 8));
-  ANR_TRY(b_lsc.alloc(lsc.size() * 8));
-  ANR_TRY(b_offs.alloc((size_t)QB * 5 * 8));
-  ANR_TRY(b_kp.alloc((size_t)QB * 4));
-  ANR_TRY(b_su.alloc((size_t)QB * kFdMaxSparse * 4));
-  ANR_TRY(b_sun.alloc((size_t)QB * 4));
-  ANR_TRY(b_skh.alloc((size_t)QB * kFdMaxSparse * 8));
-  ANR_TRY(b_ski.alloc((size_t)QB * kFdMaxSparse * 4));
-  ANR_TRY(b_skn.alloc((size_t)QB * 4));
-  ANR_TRY(b_H.alloc((size_t)QB * (kFdMaxSparse + 1) * 4));
-  ANR_TRY(b_smax.alloc((size_t)QB * 4 * 8));
-  ANR_TRY(b_tau.alloc((size_t)QB * 8));
-  ANR_TRY(b_T.alloc((size_t)QB * 8));
-  ANR_TRY(b_chi.alloc((size_t)QB * n_chunks * lcap * 8));
-  ANR_TRY(b_cid.alloc((size_t)QB * n_chunks * lcap * 4));
-  ANR_TRY(b_ccnt.alloc((size_t)QB * n_chunks * 4));
-  ANR_TRY(b_oi.alloc((size_t)QB * kFuseMax * 8));
-  ANR_TRY(b_os.alloc((size_t)QB * kFuseMax * 8));
-  ANR_TRY(b_or.alloc((size_t)QB * kFuseMax * 4));
-  ANR_TRY(b_oo.alloc((size_t)QB * 5 * 8));
-  ANR_TRY(b_om.alloc((size_t)QB * 4 * 8));
-  ANR_TRY(b_xi.alloc((size_t)QB * pool * 8));
-  ANR_TRY(b_xf.alloc((size_t)QB * pool * 8));
-  ANR_TRY(b_xs.alloc((size_t)QB * pool * 4 * 8));
-  ANR_TRY(b_xc.alloc((size_t)QB * 4));
-  if (!lids.empty()) {
-    ANR_HIP(hipMemcpy(b_lids.p, lids.data(), lids.size() * 8, hipMemcpyHostToDevice));
-    ANR_HIP(hipMemcpy(b_lsc.p, lsc.data(), lsc.size() * 8, hipMemcpyHostToDevice));
-  }
-  ANR_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_fd_scan<0>), (int)sizeof(FsShared)));
-  ANR_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_fd_scan<1>), (int)sizeof(FsShared)));
+  const int64_t QB = std::max<int64_t>(1, std::min<int64_t>(nq, ((int64_t)1 << 30) / std::max<int64_t>(per_q, 1)));
+  // ---- carve the arena ----
+  Carve dc, hc;
+  const size_t n_ent = lids.size();
+  // uploaded once per call: [ids | scores | offsets of all queries]
+  const size_t d_up = dc.take(n_ent * 16 + (size_t)nq * 5 * 8);
+  // zeroed per sub-batch with one memset: [H | smax | T | tau0 | c_cnt]
+  const size_t z_H = 0, z_smax = z_H + (((size_t)QB * (kFdMaxSparse + 1) * 4 + 7) & ~(size_t)7), z_T = z_smax + (size_t)QB * 32,
+               z_tau = z_T + (size_t)QB * 8, z_cnt = z_tau + (size_t)QB * 8, z_bytes = z_cnt + (size_t)QB * n_chunks * 4;
+  const size_t d_zero = dc.take(z_bytes);
+  const size_t d_kp = dc.take((size_t)QB * 4), d_su = dc.take((size_t)QB * kFdMaxSparse * 4), d_sun = dc.take((size_t)QB * 4),
+               d_skh = dc.take((size_t)QB * kFdMaxSparse * 8), d_ski = dc.take((size_t)QB * kFdMaxSparse * 4),
+               d_skn = dc.take((size_t)QB * 4), d_chi = dc.take((size_t)QB * n_chunks * lcap * 8),
+               d_cid = dc.take((size_t)QB * n_chunks * lcap * 4), d_oi = dc.take((size_t)QB * kFuseMax * 8),
+               d_os = dc.take((size_t)QB * kFuseMax * 8), d_or = dc.take((size_t)QB * kFuseMax * 4),
+               d_oo = dc.take((size_t)QB * 5 * 8), d_om = dc.take((size_t)QB * 4 * 8);
+  // results of a sub-batch, downloaded with one copy: [ids | final | per-source | count]
+  const size_t out_bytes = (size_t)QB * ((size_t)pool * 48 + 4);
+  const size_t d_out = dc.take(out_bytes);
+  const size_t h_up = hc.take(n_ent * 16 + (size_t)nq * 5 * 8), h_out = hc.take(out_bytes);
+  FdArena &ar = g_fd_arena[device];
+  std::lock_guard<std::mutex> lock(ar.mu);
+  ANR_TRY(ar.reserve(dc.off, hc.off));
+  char *D = ar.dev, *Hs = ar.host;
+  ANR_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_fd_scan<0, 0>), (int)sizeof(FsShared)));
+  ANR_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_fd_scan<0, 1>), (int)sizeof(FsShared)));
+  ANR_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_fd_scan<1, 0>), (int)sizeof(FsShared)));
+  ANR_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_fd_scan<1, 1>), (int)sizeof(FsShared)));
   ANR_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_fd_build), (int)sizeof(FdShared)));
   ANR_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_fuse<true>), (int)sizeof(FuseShared)));
   hipEvent_t ev[2] = {nullptr, nullptr};
@@ -1155,6 +1289,17 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
   }
   int rc = ANR_OK;
   hipStream_t st = nullptr;
+  // one upload for the whole call
+  if (n_ent) {
+    std::memcpy(Hs + h_up, lids.data(), n_ent * 8);
+    std::memcpy(Hs + h_up + n_ent * 8, lsc.data(), n_ent * 8);
+  }
+  std::memcpy(Hs + h_up + n_ent * 16, offs.data(), (size_t)nq * 5 * 8);
+  {
+    const hipError_t e = hipMemcpyAsync(D + d_up, Hs + h_up, n_ent * 16 + (size_t)nq * 5 * 8, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) rc = fail(ANR_EHIP, "fuse_dense upload failed: %s", hipGetErrorString(e));
+  }
+  const int n_cu = device_cu_count(device);
   for (int64_t q0 = 0; q0 < nq && rc == ANR_OK; q0 += QB) {
     const int64_t nb = std::min(QB, nq - q0);
     FdParams p{};
@@ -1170,35 +1315,30 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
     p.rrf_k = rrf_k;
     p.U = U;
     p.q0 = q0;
-    p.l_ids = b_lids.as<int64_t>();
-    p.l_sc = b_lsc.as<double>();
-    p.l_offs = b_offs.as<int64_t>();
-    p.kprime = b_kp.as<int>();
-    p.su_id = b_su.as<unsigned>();
-    p.su_n = b_sun.as<int>();
-    p.sk_hi = b_skh.as<unsigned long long>();
-    p.sk_id = b_ski.as<unsigned>();
-    p.sk_n = b_skn.as<int>();
-    p.H = b_H.as<unsigned>();
-    p.smax_ord = b_smax.as<unsigned long long>();
-    p.tau0 = b_tau.as<unsigned long long>();
-    p.T = b_T.as<unsigned long long>();
-    p.c_hi = b_chi.as<unsigned long long>();
-    p.c_id = b_cid.as<unsigned>();
-    p.c_cnt = b_ccnt.as<unsigned>();
+    p.l_ids = reinterpret_cast<int64_t *>(D + d_up);
+    p.l_sc = reinterpret_cast<double *>(D + d_up + n_ent * 8);
+    p.l_offs = reinterpret_cast<int64_t *>(D + d_up + n_ent * 16) + q0 * 5;
+    p.kprime = reinterpret_cast<int *>(D + d_kp);
+    p.su_id = reinterpret_cast<unsigned *>(D + d_su);
+    p.su_n = reinterpret_cast<int *>(D + d_sun);
+    p.sk_hi = reinterpret_cast<unsigned long long *>(D + d_skh);
+    p.sk_id = reinterpret_cast<unsigned *>(D + d_ski);
+    p.sk_n = reinterpret_cast<int *>(D + d_skn);
+    p.H = reinterpret_cast<unsigned *>(D + d_zero + z_H);
+    p.smax_ord = reinterpret_cast<unsigned long long *>(D + d_zero + z_smax);
+    p.T = reinterpret_cast<unsigned long long *>(D + d_zero + z_T);
+    p.tau0 = reinterpret_cast<unsigned long long *>(D + d_zero + z_tau);
+    p.c_cnt = reinterpret_cast<unsigned *>(D + d_zero + z_cnt);
+    p.c_hi = reinterpret_cast<unsigned long long *>(D + d_chi);
+    p.c_id = reinterpret_cast<unsigned *>(D + d_cid);
     p.lcap = lcap;
     p.n_chunks = n_chunks;
-    p.o_ids = b_oi.as<int64_t>();
-    p.o_sc = b_os.as<double>();
-    p.o_rank = b_or.as<int>();
-    p.o_offs = b_oo.as<int64_t>();
-    p.o_smax = b_om.as<double>();
-    hipError_t e = hipMemcpyAsync(b_offs.p, offs.data() + q0 * 5, (size_t)nb * 5 * 8, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemsetAsync(b_H.p, 0, (size_t)nb * (kFdMaxSparse + 1) * 4, st);
-    if (e == hipSuccess) e = hipMemsetAsync(b_smax.p, 0, (size_t)nb * 4 * 8, st);
-    if (e == hipSuccess) e = hipMemsetAsync(b_T.p, 0, (size_t)nb * 8, st);
-    if (e == hipSuccess) e = hipMemsetAsync(b_tau.p, 0, (size_t)nb * 8, st);
-    if (e == hipSuccess) e = hipMemsetAsync(b_ccnt.p, 0, (size_t)nb * n_chunks * 4, st);
+    p.o_ids = reinterpret_cast<int64_t *>(D + d_oi);
+    p.o_sc = reinterpret_cast<double *>(D + d_os);
+    p.o_rank = reinterpret_cast<int *>(D + d_or);
+    p.o_offs = reinterpret_cast<int64_t *>(D + d_oo);
+    p.o_smax = reinterpret_cast<double *>(D + d_om);
+    hipError_t e = hipMemsetAsync(D + d_zero, 0, z_bytes, st);
     if (e != hipSuccess) {
       rc = fail(ANR_EHIP, "fuse_dense setup failed: %s", hipGetErrorString(e));
       break;
@@ -1207,10 +1347,9 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
     if (timed) (void)hipEventRecord(ev[0], st);
     if (method == 0) {
       const int64_t n8 = ceil_div(U, kFdChunk);
-      const int64_t gx = std::max<int64_t>(1, std::min<int64_t>(n8, ceil_div(4 * (int64_t)device_cu_count(device), nb)));
+      const int64_t gx = std::max<int64_t>(1, std::min<int64_t>(n8, ceil_div(4 * (int64_t)n_cu, nb)));
       hipLaunchKernelGGL(k_fd_max, dim3((unsigned)gx, (unsigned)nb), dim3(kFdThreads), 0, st, p);
     }
-    const int n_cu = device_cu_count(device);
     p.chunk0 = 0;
     p.prefix = 1;
     launch_scan(method, (unsigned)std::min<int64_t>(nb, 2 * n_cu), st, p, nb);
@@ -1222,6 +1361,9 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
     }
     if (timed) (void)hipEventRecord(ev[1], st);
     hipLaunchKernelGGL(k_fd_build, dim3((unsigned)nb), dim3(kFdThreads), sizeof(FdShared), st, p);
+    // the sub-batch's results, packed: [ids nb*pool | final nb*pool | per-source nb*pool*4 | count nb]
+    const size_t o_ids = 0, o_fin = (size_t)nb * pool * 8, o_src = o_fin + (size_t)nb * pool * 8,
+                 o_cnt = o_src + (size_t)nb * pool * 32, o_bytes = o_cnt + (size_t)nb * 4;
     FuseParams fp{};
     fp.method = method;
     fp.ids = p.o_ids;
@@ -1230,23 +1372,24 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
     for (int s = 0; s < 4; ++s) fp.w[s] = weights[s];
     fp.rrf_k = rrf_k;
     fp.pool = pool;
-    fp.out_ids = b_xi.as<int64_t>();
-    fp.out_final = b_xf.as<double>();
-    fp.out_src = b_xs.as<double>();
-    fp.out_count = b_xc.as<int>();
+    fp.out_ids = reinterpret_cast<int64_t *>(D + d_out + o_ids);
+    fp.out_final = reinterpret_cast<double *>(D + d_out + o_fin);
+    fp.out_src = reinterpret_cast<double *>(D + d_out + o_src);
+    fp.out_count = reinterpret_cast<int *>(D + d_out + o_cnt);
     fp.smax_ovr = p.o_smax;
     fp.rank_ovr = p.o_rank;
     hipLaunchKernelGGL(k_fuse<true>, dim3((unsigned)nb), dim3(1024), sizeof(FuseShared), st, fp);
     e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(out_ids + q0 * pool, b_xi.p, (size_t)nb * pool * 8, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(out_final + q0 * pool, b_xf.p, (size_t)nb * pool * 8, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(out_src + q0 * pool * 4, b_xs.p, (size_t)nb * pool * 32, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(out_count + q0, b_xc.p, (size_t)nb * 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(Hs + h_out, D + d_out, o_bytes, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) {
       rc = fail(ANR_EHIP, "fuse_dense failed: %s", hipGetErrorString(e));
       break;
     }
+    std::memcpy(out_ids + q0 * pool, Hs + h_out + o_ids, (size_t)nb * pool * 8);
+    std::memcpy(out_final + q0 * pool, Hs + h_out + o_fin, (size_t)nb * pool * 8);
+    std::memcpy(out_src + q0 * pool * 4, Hs + h_out + o_src, (size_t)nb * pool * 32);
+    std::memcpy(out_count + q0, Hs + h_out + o_cnt, (size_t)nb * 4);
     if (timed) {
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) stats->scan_ms += ms;
@@ -1256,7 +1399,7 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
       stats->scan_bytes += bytes * nb;
       stats->n_queries += nb;
       std::vector<unsigned> cc((size_t)nb * n_chunks);
-      if (hipMemcpy(cc.data(), b_ccnt.p, cc.size() * 4, hipMemcpyDeviceToHost) == hipSuccess)
+      if (hipMemcpy(cc.data(), p.c_cnt, cc.size() * 4, hipMemcpyDeviceToHost) == hipSuccess)
         for (unsigned v : cc) stats->n_candidates += v;
     }
   }
