@@ -104,9 +104,10 @@ class DeviceBM25:
         from .fusion import DeviceArray
         indptr, terms = self._encode_queries(queries)
         out = DeviceArray(len(queries), self.doc_count, np.float64, self.device)
+        out.row_max = DeviceArray(len(queries), 1, np.float64, self.device)  # by-product: each row's maximum
         _lib.check(self._lib.anr_bm25_scores_dev(self._h, len(queries), indptr.ctypes.data_as(C.c_void_p),
                                                  terms.ctypes.data_as(C.c_void_p), int(bool(normalize)),
-                                                 C.c_void_p(out.ptr)), "anr_bm25_scores_dev")
+                                                 C.c_void_p(out.ptr), C.c_void_p(out.row_max.ptr)), "anr_bm25_scores_dev")
         return out
 
     def nonzero_batch(self, queries: Sequence[Sequence[str]], normalize: bool = True, cap: int = 4096):
@@ -166,11 +167,13 @@ class DeviceFieldWeightedBM25:
         nq = len(queries)
         parts = [bm.scores_device(queries, normalize=False) for bm in self.fields.values()]
         out = DeviceArray(nq, self.doc_count, np.float64, self.device)
+        out.row_max = DeviceArray(nq, 1, np.float64, self.device)
         ptrs = (C.c_void_p * len(parts))(*[p.ptr for p in parts])
         w = np.asarray([float(v) for v in self.field_weights.values()], dtype=np.float64)
         try:
             _lib.check(_lib.load().anr_bm25_combine_fields(self.device, len(parts), ptrs, w.ctypes.data_as(C.c_void_p), nq,
-                                                           self.doc_count, int(bool(normalize)), C.c_void_p(out.ptr)),
+                                                           self.doc_count, int(bool(normalize)), C.c_void_p(out.ptr),
+                                                           C.c_void_p(out.row_max.ptr)),
                        "anr_bm25_combine_fields")
         finally:
             for p in parts:

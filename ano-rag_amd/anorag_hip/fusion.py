@@ -19,9 +19,12 @@ SOURCES = ("dense", "bm25", "graph", "path")
 
 
 class DeviceArray:
-    """[nq, n] float64 / float32 array in device memory (row-major)."""
+    """[nq, n] float64 / float32 array in device memory (row-major).  ``row_max`` (optional): a [nq, 1] float64
+    ``DeviceArray`` holding each row's maximum, set by the producers that know it (``DeviceBM25.scores_device``);
+    ``fuse_dense`` hands it on and the linear fusion skips its own max pass over the array."""
 
     def __init__(self, nq: int, n: int, dtype=np.float64, device: int = 0):
+        self.row_max = None
         self.nq, self.n, self.device = int(nq), int(n), int(device)
         self.dtype = np.dtype(dtype)
         if self.dtype not in (np.dtype(np.float64), np.dtype(np.float32)):
@@ -32,7 +35,9 @@ class DeviceArray:
         self.ptr = p.value
 
     @classmethod
-    def from_numpy(cls, a: np.ndarray, device: int = 0) -> "DeviceArray":
+    def from_numpy(cls, a: np.ndarray, device: int = 0, with_max: bool = False) -> "DeviceArray":
+        """with_max: also upload each row's maximum over its non-NaN entries (``row_max``) — the host has the rows in
+        hand anyway, and the linear fusion then skips its max pass"""
         a = np.ascontiguousarray(a)
         if a.ndim != 2:
             raise ValueError("expected [nq, n]")
@@ -41,6 +46,9 @@ class DeviceArray:
         out = cls(a.shape[0], a.shape[1], a.dtype, device)
         _lib.check(_lib.load().anr_device_copy(device, C.c_void_p(out.ptr), a.ctypes.data_as(C.c_void_p), a.nbytes, 0),
                    "anr_device_copy")
+        if with_max and a.shape[1] > 0:
+            m = np.fmax.reduce(a.astype(np.float64, copy=False), axis=1).reshape(-1, 1)  # fmax skips NaN; all-NaN row -> NaN
+            out.row_max = cls.from_numpy(m, device)
         return out
 
     def numpy(self) -> np.ndarray:
@@ -50,6 +58,9 @@ class DeviceArray:
         return out
 
     def free(self) -> None:
+        if getattr(self, "row_max", None) is not None:
+            self.row_max.free()
+            self.row_max = None
         if getattr(self, "ptr", None):
             _lib.load().anr_device_free(self.device, C.c_void_p(self.ptr))
             self.ptr = None
@@ -80,6 +91,8 @@ def fuse_dense(method: str, weights: Dict[str, float], rrf_k: float, pool: int, 
             src[si].array_dev = v.ptr
             src[si].array_len = v.n
             src[si].array_dtype = 0 if v.dtype == np.float64 else 1
+            if v.row_max is not None and v.row_max.ptr:
+                src[si].array_max_dev = v.row_max.ptr
             continue
         if len(v) != nq:
             raise ValueError(f"{name}: {len(v)} lists for {nq} queries")

@@ -25,6 +25,7 @@ struct Bm25Params {
   const int32_t *q_terms;
   double *scores;          // [nq][n_docs], zeroed
   int normalize;
+  double *max_out;         // [nq] maximum of each query's OUTPUT row, or nullptr
 };
 
 __global__ __launch_bounds__(1024) void k_bm25(Bm25Params p) {
@@ -32,20 +33,36 @@ __global__ __launch_bounds__(1024) void k_bm25(Bm25Params p) {
   __shared__ double s_max;
   const int q = blockIdx.x, tid = threadIdx.x;
   double *sc = p.scores + (int64_t)q * p.n_docs;
+  int64_t touched = 0;  // postings added (an upper bound of the documents touched)
   for (int64_t t = p.q_indptr[q]; t < p.q_indptr[q + 1]; ++t) {
     const int term = p.q_terms[t];
     const int64_t lo = p.indptr[term], hi = p.indptr[term + 1];
     for (int64_t e = lo + tid; e < hi; e += 1024) atomicAdd(sc + p.docs[e], p.weights[e]);
+    touched += hi - lo;
     __syncthreads();  // token order == the reference's addition order
   }
-  if (!p.normalize) return;
+  if (!p.normalize && !p.max_out) return;
   __threadfence_block();
+  // the row's maximum.  Fewer postings than documents: some document kept its 0.0, and the maximum is the larger of 0.0
+  // and the largest touched score — a pass over the query's postings instead of over all n_docs scores.
   double m = 0.0;
   bool any = false;
-  for (int64_t d = tid; d < p.n_docs; d += 1024) {
-    const double v = __hip_atomic_load(sc + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    m = (!any || v > m) ? v : m;
+  if (touched < p.n_docs) {
     any = true;
+    for (int64_t t = p.q_indptr[q]; t < p.q_indptr[q + 1]; ++t) {
+      const int term = p.q_terms[t];
+      const int64_t lo = p.indptr[term], hi = p.indptr[term + 1];
+      for (int64_t e = lo + tid; e < hi; e += 1024) {
+        const double v = __hip_atomic_load(sc + p.docs[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        m = v > m ? v : m;
+      }
+    }
+  } else {
+    for (int64_t d = tid; d < p.n_docs; d += 1024) {
+      const double v = __hip_atomic_load(sc + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      m = (!any || v > m) ? v : m;
+      any = true;
+    }
   }
   if (!any) m = -__builtin_inf();
   for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
@@ -58,7 +75,9 @@ __global__ __launch_bounds__(1024) void k_bm25(Bm25Params p) {
   }
   __syncthreads();
   const double mx = s_max;
-  if (mx > 0.0)
+  const bool divide = p.normalize && mx > 0.0;
+  if (tid == 0 && p.max_out) p.max_out[q] = divide ? 1.0 : mx;  // (mx / mx == 1.0 exactly; division is monotone)
+  if (divide)
     for (int64_t d = tid; d < p.n_docs; d += 1024) {
       const double v = __hip_atomic_load(sc + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       sc[d] = v / mx;
@@ -105,6 +124,7 @@ struct CombineParams {
   int64_t n_docs;
   int normalize;
   double *out;  // [nq][n_docs]
+  double *max_out;  // [nq] maximum of each query's output row, or nullptr
 };
 
 __global__ __launch_bounds__(1024) void k_bm25_combine(CombineParams p) {
@@ -119,7 +139,7 @@ __global__ __launch_bounds__(1024) void k_bm25_combine(CombineParams p) {
     o[d] = t;
     m = fmax(m, t);
   }
-  if (!p.normalize) return;
+  if (!p.normalize && !p.max_out) return;
   for (int s = 32; s > 0; s >>= 1) m = fmax(m, __shfl_xor(m, s));
   if ((tid & 63) == 0) s_red[tid >> 6] = m;
   __syncthreads();
@@ -130,7 +150,9 @@ __global__ __launch_bounds__(1024) void k_bm25_combine(CombineParams p) {
   }
   __syncthreads();
   const double mx = s_max;
-  if (mx > 0.0)
+  const bool divide = p.normalize && mx > 0.0;
+  if (tid == 0 && p.max_out) p.max_out[q] = divide ? 1.0 : mx;
+  if (divide)
     for (int64_t d = tid; d < p.n_docs; d += 1024) o[d] = o[d] / mx;
 }
 
@@ -175,7 +197,7 @@ int validate_queries(const anr_bm25 *h, int64_t nq, const int64_t *q_indptr, con
 // runs the scoring of one chunk of queries into a fresh device buffer (caller frees *d_scores) or, when `into` is
 // given, into that caller-owned device buffer
 int score_chunk(anr_bm25 *h, int64_t nq, const int64_t *q_indptr, const int32_t *q_terms, int normalize,
-                double **d_scores, double *into = nullptr) {
+                double **d_scores, double *into = nullptr, double *max_into = nullptr) {
   int64_t *dq = nullptr;
   int32_t *dt = nullptr;
   const int64_t nt = q_indptr[nq] - q_indptr[0];
@@ -194,7 +216,7 @@ int score_chunk(anr_bm25 *h, int64_t nq, const int64_t *q_indptr, const int32_t 
       e = hipMemcpyAsync(dt, q_terms + q_indptr[0], (size_t)nt * 4, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) e = hipMemsetAsync(*d_scores, 0, (size_t)nq * h->n_docs * 8, h->stream);
     if (e == hipSuccess) {
-      Bm25Params p{h->indptr, h->docs, h->weights, h->n_docs, dq, dt, *d_scores, normalize};
+      Bm25Params p{h->indptr, h->docs, h->weights, h->n_docs, dq, dt, *d_scores, normalize, max_into};
       hipLaunchKernelGGL(k_bm25, dim3((unsigned)nq), dim3(1024), 0, h->stream, p);
       e = hipGetLastError();
     }
@@ -285,18 +307,18 @@ int anr_bm25_scores(anr_bm25 *h, int64_t nq, const int64_t *q_indptr, const int3
 }
 
 int anr_bm25_scores_dev(anr_bm25 *h, int64_t nq, const int64_t *q_indptr, const int32_t *q_terms, int32_t normalize,
-                        double *out_dev) {
+                        double *out_dev, double *max_dev) {
   ANR_TRY(validate_queries(h, nq, q_indptr, q_terms));
   if (!out_dev) return fail(ANR_EINVAL, "out is null");
   if (nq == 0 || h->n_docs == 0) return ANR_OK;
   DeviceGuard g(h->device);
   std::lock_guard<std::mutex> lk(h->mu);
   double *d = nullptr;
-  return score_chunk(h, nq, q_indptr, q_terms, normalize, &d, out_dev);
+  return score_chunk(h, nq, q_indptr, q_terms, normalize, &d, out_dev, max_dev);
 }
 
 int anr_bm25_combine_fields(int32_t device, int32_t n_fields, const double *const *field_scores_dev, const double *weights,
-                            int64_t nq, int64_t n_docs, int32_t normalize, double *out_dev) {
+                            int64_t nq, int64_t n_docs, int32_t normalize, double *out_dev, double *max_dev) {
   if (n_fields < 1 || n_fields > 8 || !field_scores_dev || !weights || nq < 0 || n_docs < 0 || !out_dev)
     return fail(ANR_EINVAL, "bad argument (1..8 fields)");
   if (nq == 0 || n_docs == 0) return ANR_OK;
@@ -312,6 +334,7 @@ int anr_bm25_combine_fields(int32_t device, int32_t n_fields, const double *cons
   p.n_docs = n_docs;
   p.normalize = normalize;
   p.out = out_dev;
+  p.max_out = max_dev;
   hipLaunchKernelGGL(k_bm25_combine, dim3((unsigned)nq), dim3(1024), 0, 0, p);
   ANR_HIP(hipGetLastError());
   ANR_HIP(hipStreamSynchronize(nullptr));

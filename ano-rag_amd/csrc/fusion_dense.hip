@@ -10,7 +10,7 @@
 //   k_fd_prep    unique ids of the short lists; K' = pool + that count; (rrf) their keys in the array, sorted
 //   k_fd_max     linear: per-source maximum over the whole array (the reference max-normalises, :26-32)
 //   k_fd_scan    THE kernel, HBM-bound: streams the arrays once, computes the fused value of every id from its array
-//                sources ("elementwise"), and keeps the K' best per 8192-id chunk ("arg-k"): chunk 0 first (its K'-th
+//                sources ("elementwise"), and keeps the K' best per 4096-id chunk ("arg-k"): chunk 0 first (its K'-th
 //                value is a strict threshold for all later ids — they rank below chunk 0's K' on ties), then all
 //                other chunks, threshold-gated; a chunk that lets more than its list holds through selects its own
 //                K' best in LDS (radix select) and raises a shared running threshold.  rrf with one array source
@@ -59,6 +59,7 @@ struct FdSrc {
   const void *arr;  // device [nq][len] or nullptr (short list / absent)
   int dtype;        // 0 float64, 1 float32
   int64_t len;      // ids >= len are absent from this source
+  const double *known_max;  // device [nq_total] maxima supplied by the caller, or nullptr (k_fd_max computes them)
 };
 
 struct FdParams {
@@ -407,6 +408,13 @@ __global__ __launch_bounds__(kFdThreads) void k_fd_max(FdParams p) {
 #pragma unroll
   for (int s = 0; s < 3; ++s) {
     if (!p.src[s].arr) continue;
+    if (p.src[s].known_max) {  // the producer's maximum (NaN = the row has no entry)
+      if (blockIdx.x == 0 && tid == 0) {
+        const double m = p.src[s].known_max[p.q0 + q];
+        if (m == m) p.smax_ord[(int64_t)q * 4 + s] = d2ord(m);
+      }
+      continue;
+    }
     double best = 0.0;
     bool any = false;
     for (int64_t c = blockIdx.x; c < n8; c += gridDim.x) {
@@ -1310,6 +1318,7 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
       p.src[s].arr = src[s].array_dev;
       p.src[s].dtype = src[s].array_dtype;
       p.src[s].len = src[s].array_dev ? src[s].array_len : 0;
+      p.src[s].known_max = src[s].array_dev ? src[s].array_max_dev : nullptr;
       p.w[s] = weights[s];
     }
     p.rrf_k = rrf_k;
@@ -1346,8 +1355,10 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
     hipLaunchKernelGGL(k_fd_prep, dim3((unsigned)nb), dim3(kFdThreads), 0, st, p);
     if (timed) (void)hipEventRecord(ev[0], st);
     if (method == 0) {
+      bool need_pass = false;  // a max pass over the arrays only for the sources whose maxima the caller did not supply
+      for (int s = 0; s < 3; ++s) need_pass = need_pass || (p.src[s].arr && !p.src[s].known_max);
       const int64_t n8 = ceil_div(U, kFdChunk);
-      const int64_t gx = std::max<int64_t>(1, std::min<int64_t>(n8, ceil_div(4 * (int64_t)n_cu, nb)));
+      const int64_t gx = need_pass ? std::max<int64_t>(1, std::min<int64_t>(n8, ceil_div(4 * (int64_t)n_cu, nb))) : 1;
       hipLaunchKernelGGL(k_fd_max, dim3((unsigned)gx, (unsigned)nb), dim3(kFdThreads), 0, st, p);
     }
     p.chunk0 = 0;

@@ -180,7 +180,7 @@ class HybridSearcher:
                 n = lens[s] if s == arrays[0] else len(names)
                 a = np.full((1, n), np.nan, dtype=np.float64)
                 a[0, [to_int[nid] for nid in dicts[s]]] = [float(v) for v in dicts[s].values()]
-                arr = DeviceArray.from_numpy(a, self.device)
+                arr = DeviceArray.from_numpy(a, self.device, with_max=self.fusion_method != "rrf")
                 held.append(arr)
                 sources[_SOURCES[s]] = arr
             else:

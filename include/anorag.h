@@ -194,6 +194,10 @@ typedef struct anr_fuse_source {
   const int64_t *list_ids;   /* host, concatenated over the queries, or NULL      */
   const double *list_scores;
   const int64_t *list_offs;  /* host [nq + 1], or NULL                            */
+  const double *array_max_dev; /* device [nq], or NULL: the maximum of each query's row of array_dev (non-NaN entries),
+                                  when the producer knows it (anr_bm25_scores_dev, anr_bm25_combine_fields): linear
+                                  then needs no max pass over the array.  Must be exact — it is the reference's
+                                  max(scores) normaliser (hybrid_search.py:26-32) */
 } anr_fuse_source;
 typedef struct anr_fuse_dense_stats {
   int64_t n_queries;
@@ -275,16 +279,19 @@ int anr_bm25_destroy(anr_bm25 *h);
 int anr_bm25_scores(anr_bm25 *h, int64_t nq, const int64_t *q_indptr, const int32_t *q_terms, int32_t normalize,
                     double *out_host);
 /* the same scores left in DEVICE memory ([nq][n_docs] float64, caller-allocated on the handle's device): the array
- * source anr_fuse_dense takes — the N-vector never crosses PCIe */
+ * source anr_fuse_dense takes — the N-vector never crosses PCIe.  max_dev (device [nq], may be NULL): the maximum of each
+ * output row, a by-product of the scoring (a pass over the query's postings, not over n_docs) — hand it to
+ * anr_fuse_source.array_max_dev and linear fusion needs no max pass of its own */
 int anr_bm25_scores_dev(anr_bm25 *h, int64_t nq, const int64_t *q_indptr, const int32_t *q_terms, int32_t normalize,
-                        double *out_dev);
+                        double *out_dev, double *max_dev);
 /* FieldWeightedBM25 (utils/bm25_search.py:66-146, :190-234): per field one anr_bm25 handle scores the queries
  * (anr_bm25_scores_dev, normalize = 0); this adds the fields up — total = sum_f weights[f] * field_scores[f], in field
  * order, float64, bit-identical to get_scores — and, with normalize != 0, divides by the per-query maximum when it is
  * > 0 (field_weighted_bm25_scores).  field_scores_dev: host array of n_fields (<= 8) device pointers [nq][n_docs];
- * out_dev [nq][n_docs] on the same device (it may be one of the inputs). */
+ * out_dev [nq][n_docs] on the same device (it may be one of the inputs); max_dev as in anr_bm25_scores_dev. */
 int anr_bm25_combine_fields(int32_t device, int32_t n_fields, const double *const *field_scores_dev,
-                            const double *weights, int64_t nq, int64_t n_docs, int32_t normalize, double *out_dev);
+                            const double *weights, int64_t nq, int64_t n_docs, int32_t normalize, double *out_dev,
+                            double *max_dev);
 /* sparse form for the fusion: the documents with a non-zero score, unordered; out_count may exceed cap
  * (the lists are then truncated) */
 int anr_bm25_nonzero(anr_bm25 *h, int64_t nq, const int64_t *q_indptr, const int32_t *q_terms, int32_t normalize,

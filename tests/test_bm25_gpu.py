@@ -103,3 +103,39 @@ def test_field_weighted_bm25_feeds_the_fusion_without_leaving_the_device():
         ids, fin = ofu.fuse_arrays(9000, (dense[i], (full, np.asarray(exp_scores)), None, None), [1.0, 0.5, 0.5, 0.1], "rrf", 60, 40)
         assert [r["note_id"] for r in got[i]] == ids.tolist() and [r["final_similarity"] for r in got[i]] == fin.tolist()
     dev.close()
+
+
+def test_device_scores_carry_their_row_maxima_and_linear_fusion_uses_them():
+    """scores_device leaves each row's maximum beside the N-vector (a by-product of the scoring pass); the linear
+    fusion takes it instead of a max pass of its own — results identical to computing it, and to the oracle"""
+    from anorag_hip import bm25_search as dbm
+    from anorag_hip.fusion import fuse_dense
+    from oracle import fusion as ofu
+    rng = np.random.default_rng(21)
+    vocab = [f"w{i}" for i in range(800)]
+    notes = [{"title": " ".join(rng.choice(vocab, 2)), "entities": list(rng.choice(vocab, 2)),
+              "content": " ".join(rng.choice(vocab, size=rng.integers(0, 30)))} for _ in range(12000)]
+    queries = [" ".join(rng.choice(vocab, size=rng.integers(1, 6))) for _ in range(7)] + ["zzz qqq"]  # last: no hit at all
+    toks = [dbm.tokenize_text(q) for q in queries]
+    nq = len(queries)
+    dense = [(rng.choice(12000, 60, replace=False).astype(np.int64), np.sort(rng.uniform(0.3, 0.9, 60))[::-1].copy())
+             for _ in queries]
+    w = {"dense": 1.0, "bm25": 0.5, "graph": 0.5, "path": 0.1}
+    full = np.arange(12000, dtype=np.int64)
+    for corpus in (dbm.build_bm25_corpus(notes, _text), dbm.build_field_weighted_bm25_corpus(notes)):
+        for normalize in (False, True):
+            arr = corpus.scores_device(toks, normalize=normalize)
+            host = arr.numpy()
+            assert arr.row_max is not None
+            assert arr.row_max.numpy().reshape(-1).tolist() == host.max(axis=1).tolist()
+            with_max = fuse_dense("linear", w, 60.0, 50, nq, {"dense": dense, "bm25": arr})
+            kept, arr.row_max = arr.row_max, None
+            without = fuse_dense("linear", w, 60.0, 50, nq, {"dense": dense, "bm25": arr})
+            arr.row_max = kept
+            for a, b in zip(with_max, without):
+                assert np.array_equal(a, b, equal_nan=True)
+            for i in range(nq):
+                ids, fin = ofu.fuse_arrays(12000, (dense[i], (full, host[i]), None, None), [1.0, 0.5, 0.5, 0.1], "linear", 60, 50)
+                assert with_max[1][i, :len(fin)].tolist() == fin.tolist()
+            arr.free()
+        corpus.close()

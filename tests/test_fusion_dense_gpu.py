@@ -193,3 +193,27 @@ def test_fuse_dense_argument_errors():
     with pytest.raises(AnoragError):  # no array at all
         fuse_dense("linear", w, 60.0, 10, 1, {"dense": [(np.arange(5), np.ones(5))]})
     a.free()
+
+
+def test_host_supplied_row_maxima_match_the_device_max_pass():
+    """DeviceArray.from_numpy(with_max=True): rows with NaN (absent ids), an all-NaN row, an all-negative row, an
+    all-zero row — the linear fusion with the supplied maxima equals the one that runs k_fd_max"""
+    from anorag_hip.fusion import DeviceArray, fuse_dense
+    rng = np.random.default_rng(31)
+    n, nq, pool = 30_000, 5, 48
+    a = rng.standard_normal((nq, n))
+    a[0, rng.random(n) < 0.5] = np.nan
+    a[1, :] = np.nan
+    a[2, :] = -np.abs(a[2]) - 0.5
+    a[3, :] = 0.0
+    dense = [(rng.choice(n, 40, replace=False).astype(np.int64), rng.uniform(0.1, 0.9, 40)) for _ in range(nq)]
+    w = {"dense": 1.0, "bm25": 0.7, "graph": 0.0, "path": 0.0}
+    plain = DeviceArray.from_numpy(a)
+    known = DeviceArray.from_numpy(a, with_max=True)
+    assert known.row_max is not None and plain.row_max is None
+    r0 = fuse_dense("linear", w, 60.0, pool, nq, {"dense": dense, "bm25": plain})
+    r1 = fuse_dense("linear", w, 60.0, pool, nq, {"dense": dense, "bm25": known})
+    for x, y in zip(r0, r1):
+        assert np.array_equal(x, y, equal_nan=True)
+    plain.free()
+    known.free()
