@@ -24,6 +24,11 @@ import numpy as np
 from anorag_hip import _lib
 from anorag_hip.fusion import DeviceArray, fuse_dense
 
+try:  # C shaping of the fused arrays into the reference's result dicts (csrc/pyshape.c)
+    from anorag_hip import _pyshape
+except ImportError:  # pragma: no cover - the extension is built by `make` next to libanorag_hip.so
+    _pyshape = None
+
 _SOURCES = ("dense", "bm25", "graph", "path")
 _LIST_MAX = 4096    # entries per query of the LDS-resident list kernel (csrc/fusion_kernels.hpp kFuseMax)
 _SHORT_MAX = 1024   # short-list entries per query beside the arrays of anr_fuse_dense
@@ -219,21 +224,35 @@ class HybridSearcher:
                          {"dense": dense, "bm25": bm25, "graph": graph, "path": path}, device=self.device,
                          want_stats=want_stats)
         o_ids, o_fin, o_src, o_cnt = out[:4]
-        results = []
-        ids_l, fin_l = o_ids.tolist(), o_fin.tolist()
-        src_l = np.where(np.isnan(o_src), None, o_src.astype(object)).tolist()
-        for qi in range(nq):
-            res = []
-            for j in range(int(o_cnt[qi])):
-                i = ids_l[qi][j]
-                sc = src_l[qi][j]
-                res.append({"note_id": note_ids[i] if note_ids is not None else i,
-                            "scores": dict(zip(_SOURCES, sc)),
-                            "final_similarity": fin_l[qi][j],
-                            "tags": {"source": "graph" if sc[2] is not None else "semantic",
-                                     "is_bridge": sc[3] is not None}})
-            results.append(res)
+        results = _shape_fused(o_ids, o_fin, o_src, o_cnt, note_ids)
         return (results, out[4]) if want_stats else results
+
+
+def _shape_fused_py(o_ids, o_fin, o_src, o_cnt, note_ids=None):
+    """the result dicts of the reference's fuse (hybrid_search.py:85-103) from the anr_fuse_dense output arrays"""
+    results = []
+    ids_l, fin_l = o_ids.tolist(), o_fin.tolist()
+    src_l = np.where(np.isnan(o_src), None, o_src.astype(object)).tolist()
+    for qi in range(o_ids.shape[0]):
+        res = []
+        for j in range(int(o_cnt[qi])):
+            i = ids_l[qi][j]
+            sc = src_l[qi][j]
+            res.append({"note_id": note_ids[i] if note_ids is not None else i,
+                        "scores": dict(zip(_SOURCES, sc)),
+                        "final_similarity": fin_l[qi][j],
+                        "tags": {"source": "graph" if sc[2] is not None else "semantic",
+                                 "is_bridge": sc[3] is not None}})
+        results.append(res)
+    return results
+
+
+def _shape_fused(o_ids, o_fin, o_src, o_cnt, note_ids=None):
+    if _pyshape is not None:  # the same dicts, built in C: 16 000 results took 9 ms in the Python loop
+        nq, pool = o_ids.shape
+        return _pyshape.shape_fused(np.ascontiguousarray(o_ids), np.ascontiguousarray(o_fin), np.ascontiguousarray(o_src),
+                                    np.ascontiguousarray(o_cnt, dtype=np.int32), nq, pool, note_ids)
+    return _shape_fused_py(o_ids, o_fin, o_src, o_cnt, note_ids)
 
 
 def create_hybrid_searcher(config: Dict[str, Any]) -> HybridSearcher:

@@ -157,3 +157,41 @@ def test_bfloat16_and_float16_checkpoints_load_as_float32(tmp_path):
         for k in ref:
             assert w[k].dtype == np.float32 and w[k].shape == ref[k].shape
             assert np.max(np.abs(w[k] - ref[k])) <= tol * max(1.0, float(np.max(np.abs(ref[k]))))
+
+
+def test_c_result_shaping_builds_the_same_objects_as_the_python_loops():
+    """csrc/pyshape.c (host-side formatting, no device work): shape_hits == VectorIndex's loop, shape_fused ==
+    HybridSearcher's loop — same keys in the same order, same Python types, same values"""
+    from anorag_hip import _pyshape
+    from retrieval import hybrid_search as hsm
+    from vector_store import vector_index as vim
+    rng = np.random.default_rng(3)
+    nq, pool = 7, 12
+    ids = rng.integers(0, 50, size=(nq, pool)).astype(np.int64)
+    fin = rng.standard_normal((nq, pool))
+    src = rng.standard_normal((nq, pool, 4))
+    src[rng.random((nq, pool, 4)) < 0.4] = np.nan
+    cnt = rng.integers(0, pool + 1, size=nq).astype(np.int32)
+    cnt[0], cnt[1] = 0, pool
+    names = [f"note_{i}" for i in range(50)]
+    for note_ids in (None, names):
+        got = _pyshape.shape_fused(ids, fin, src, cnt, nq, pool, note_ids)
+        exp = hsm._shape_fused_py(ids, fin, src, cnt, note_ids)
+        assert got == exp
+        for g, e in zip(got, exp):
+            for a, b in zip(g, e):
+                assert list(a) == list(b) and list(a["scores"]) == list(b["scores"]) and list(a["tags"]) == list(b["tags"])
+                assert type(a["note_id"]) is type(b["note_id"]) and type(a["tags"]["is_bridge"]) is bool
+    assert hsm._shape_fused(ids, fin, src, cnt, names) == hsm._shape_fused_py(ids, fin, src, cnt, names)
+    with pytest.raises(ValueError):
+        _pyshape.shape_fused(ids, fin, src, cnt, nq + 1, pool, None)
+    with pytest.raises(IndexError):
+        _pyshape.shape_fused(ids, fin, src, cnt, nq, pool, names[:3])
+    # VectorIndex.search's shaping, cosine and L2
+    I = rng.integers(-1, 30, size=(4, 9)).astype(np.int64)
+    S = rng.random((4, 9)).astype(np.float32)
+    for cosine in (True, False):
+        sim = S.tolist() if cosine else (1.0 / (1.0 + S.astype(np.float64))).tolist()
+        exp = [[{"index": i, "score": s, "rank": r, "similarity": m} for r, (i, s, m) in enumerate(zip(a, b, c)) if i != -1]
+               for a, b, c in zip(I.tolist(), S.tolist(), sim)]
+        assert vim._shape_hits(I, S, cosine) == exp

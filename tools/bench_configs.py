@@ -118,7 +118,7 @@ dense = []
 for q in range(NQ):
     nz = rng.choice(NN, 1000, replace=False); v = np.abs(rng.standard_normal(1000)); bm[q, nz] = v / v.max()
     dense.append((rng.choice(NN, 100, replace=False).astype(np.int64), np.sort(rng.random(100))[::-1].copy()))
-arr = DeviceArray.from_numpy(bm)
+arr = DeviceArray.from_numpy(bm, with_max=True)  # row maxima beside the vector, as DeviceBM25.scores_device leaves them
 res = {}
 full = np.arange(NN, dtype=np.int64)
 for method in ("linear", "rrf"):

@@ -13,9 +13,12 @@ dense = []
 for q in range(NQ):
     nz = rng.choice(NN, NN // 1000, replace=False); v = np.abs(rng.standard_normal(len(nz))); bm[q, nz] = v / v.max()
     dense.append((rng.choice(NN, 100, replace=False).astype(np.int64), np.sort(rng.random(100))[::-1].copy()))
-arr = DeviceArray.from_numpy(bm)
+arr = DeviceArray.from_numpy(bm, with_max=True)  # row maxima as DeviceBM25.scores_device leaves them
+row_max = arr.row_max
 w = {"dense": 1.0, "bm25": 0.5, "graph": 0.5, "path": 0.1}
-for method in ("linear", "rrf"):
+for method in ("linear", "linear+max", "rrf"):
+    label, method = method, method.split("+")[0]
+    arr.row_max = row_max if label == "linear+max" else None
     fuse_dense(method, w, 60.0, 80, NQ, {"dense": dense, "bm25": arr})
     best = None
     for _ in range(5):
@@ -24,7 +27,10 @@ for method in ("linear", "rrf"):
         if best is None or st["scan_ms"] < best[0]["scan_ms"]: best = (st, dt)
     st, dt = best
     gbps = st["scan_bytes"] / 1e9 / (st["scan_ms"] / 1e3)
-    print(f"{method:6s} {NQ} queries x {NN} notes: streaming kernels {st['scan_ms']:.3f} ms for {st['scan_bytes']/1e9:.2f} GB algorithmic "
-          f"({'two passes: max + scan' if method == 'linear' else 'one pass: scan + rank count'}) = {gbps:.0f} GB/s = {gbps/8000:.3f} of the 8 TB/s HBM peak; "
+    what = {"linear": "two passes: max + scan", "linear+max": "one pass: scan, row maxima from the producer",
+            "rrf": "one pass: scan + rank count"}[label]
+    print(f"{label:10s} {NQ} queries x {NN} notes: streaming kernels {st['scan_ms']:.3f} ms for {st['scan_bytes']/1e9:.2f} GB algorithmic "
+          f"({what}) = {gbps:.0f} GB/s = {gbps/8000:.3f} of the 8 TB/s HBM peak; "
           f"call {dt*1e3:.2f} ms; candidates/query {st['n_candidates']/NQ:.0f}")
+arr.row_max = row_max
 arr.free()
