@@ -11,7 +11,7 @@ rng = np.random.default_rng(99)
 bm = np.zeros((NQ, NN))
 dense = []
 for q in range(NQ):
-    nz = rng.choice(NN, NN // 1000, replace=False); v = np.abs(rng.standard_normal(len(nz))); bm[q, nz] = v / v.max()
+    nz = rng.choice(NN, int(os.environ.get("NZ", NN // 1000)), replace=False); v = np.abs(rng.standard_normal(len(nz))); bm[q, nz] = v / v.max()
     dense.append((rng.choice(NN, 100, replace=False).astype(np.int64), np.sort(rng.random(100))[::-1].copy()))
 arr = DeviceArray.from_numpy(bm, with_max=True)  # row maxima as DeviceBM25.scores_device leaves them
 row_max = arr.row_max
