@@ -6,7 +6,8 @@
 // CDNA4 design: every activation lives in HBM in MFMA *operand* layout, so no kernel needs LDS or a
 // transpose and every global access is a contiguous 1 KiB per wave instruction:
 //   act  [T/32][KB][64 lanes][8]  f16   token (t%32) on lane&31, 8 features per lane
-//   res  same shape, f32 (residual stream, LayerNorm input/output)
+//        (the residual stream too: a LayerNorm adds its input activations and the f16 projection in f32, normalises
+//        in f32 and writes f16; only the LAST LayerNorm's output is also kept in f32, for the pooling)
 //   W    [N/32][KB][64][8]        f16   output feature (n%32) on lane&31, 8 input features per lane
 // with the *same* feature permutation inside each 16-feature block kb:
 //   element j of lane half h  <->  feature kb*16 + 8*(j>>2) + 4*h + (j&3)
@@ -15,7 +16,7 @@
 // 16-block, r&7 the element), so a GEMM epilogue is two 16-byte stores and the next GEMM / the attention
 // consume them as is.  GEMMs run "token on lane" (C^T = W * act^T); V is projected with the operands
 // swapped so that it lands "feature on lane, keys in k" — the A operand P*V needs.
-// f16 operands, f32 accumulation, f32 residual stream and LayerNorm.
+// f16 operands and activations, f32 accumulation, f32 LayerNorm arithmetic.
 #include <algorithm>
 #include <mutex>
 #include <string>
@@ -72,7 +73,6 @@ struct EmbedParams {
   const float *word, *pos, *type;  // blocked rows
   const float *g, *b;              // blocked LN params
   float eps;
-  float *res;
   _Float16 *act;
 };
 
@@ -140,8 +140,6 @@ __global__ __launch_bounds__(256) void k_embed_ln(EmbedParams p) {
         hv[j] = (_Float16)out[j];
       }
       const int64_t e = ((tb * p.KB + kb) * 64 + lane) * 8;
-      *reinterpret_cast<float4 *>(p.res + e) = make_float4(out[0], out[1], out[2], out[3]);
-      *reinterpret_cast<float4 *>(p.res + e + 4) = make_float4(out[4], out[5], out[6], out[7]);
       *reinterpret_cast<half8 *>(p.act + e) = hv;
     }
   }
@@ -196,21 +194,31 @@ __global__ __launch_bounds__(256) void k_embed_ln_wave(EmbedParams p) {
       hv[j] = (_Float16)out[j];
     }
     const int64_t e = ((tb * p.KB + kb) * 64 + lane) * 8;
-    *reinterpret_cast<float4 *>(p.res + e) = make_float4(out[0], out[1], out[2], out[3]);
-    *reinterpret_cast<float4 *>(p.res + e + 4) = make_float4(out[4], out[5], out[6], out[7]);
     *reinterpret_cast<half8 *>(p.act + e) = hv;
   }
 }
 
+// LayerNorm of (x + delta): x = the residual stream (f16, act layout — the layer's input activations), delta = the
+// projection the GEMM before it wrote (f16).  Sum, statistics and normalisation in f32; the output replaces x in place
+// (act) and, for the last LayerNorm of the forward, is also kept in f32 for the pooling (res != nullptr).
+// (Round 2, first half: the GEMM epilogue added an f32 residual and wrote the f32 sum, this kernel read it and wrote
+// an f32 residual + the f16 activations — 225 MB per GEMM + LN pair at 16 K tokens x 768, a quarter of the layer's
+// time in the ablation runs; now 100 MB.)
 struct LnParams {
-  const float *in;  // blocked f32 (pre-LN sum)
+  const _Float16 *x;      // residual in
+  const _Float16 *delta;  // projection output
   int64_t TB;
   int H, KB;
   const float *g, *b;
   float eps;
-  float *res;
-  _Float16 *act;
+  float *res;             // optional f32 copy of the output
+  _Float16 *act;          // output (may alias x)
 };
+__device__ __forceinline__ void ln_load8(const LnParams &p, int64_t e, float (&v)[8]) {
+  const half8 a = *reinterpret_cast<const half8 *>(p.x + e), d = *reinterpret_cast<const half8 *>(p.delta + e);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (float)a[j] + (float)d[j];
+}
 
 // one workgroup per 32-token block; each of the 4 waves owns a quarter of the feature blocks, keeps it in
 // registers (<= 16 blocks x 8 values per lane), and the per-token sums meet in LDS: the row is read once and
@@ -221,25 +229,24 @@ __global__ __launch_bounds__(256) void k_layernorm(LnParams p) {
   const int64_t tb = blockIdx.x;
   const int h = lane >> 5;
   const int kbw = p.KB / 4, kb0 = wave * kbw;
+  float v[kLnMaxKbw][8];
+#pragma unroll
+  for (int i = 0; i < kLnMaxKbw; ++i)
+    if (i < kbw) ln_load8(p, ((tb * p.KB + kb0 + i) * 64 + lane) * 8, v[i]);
   // shifted single-pass statistics: sums of (x - c) and (x - c)^2 with c = the token's first value, so the
   // variance does not cancel
-  const float c = __shfl(p.in[(tb * p.KB * 64 + (lane & 31)) * 8], lane & 31);
-  float4 v[kLnMaxKbw][2];
+  float c0;
+  {
+    const int64_t e0 = (tb * p.KB * 64 + (lane & 31)) * 8;
+    c0 = (float)p.x[e0] + (float)p.delta[e0];
+  }
+  const float c = __shfl(c0, lane & 31);
   float s = 0.f, s2 = 0.f;
 #pragma unroll
   for (int i = 0; i < kLnMaxKbw; ++i) {
     if (i < kbw) {
-      const float4 *x = reinterpret_cast<const float4 *>(p.in + ((tb * p.KB + kb0 + i) * 64 + lane) * 8);
-      v[i][0] = x[0];
-      v[i][1] = x[1];
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < kLnMaxKbw; ++i) {
-    if (i < kbw) {
-      const float4 a = v[i][0], b = v[i][1];
-      const float d0 = a.x - c, d1 = a.y - c, d2 = a.z - c, d3 = a.w - c, d4 = b.x - c, d5 = b.y - c, d6 = b.z - c,
-                  d7 = b.w - c;
+      const float d0 = v[i][0] - c, d1 = v[i][1] - c, d2 = v[i][2] - c, d3 = v[i][3] - c, d4 = v[i][4] - c, d5 = v[i][5] - c,
+                  d6 = v[i][6] - c, d7 = v[i][7] - c;
       s += (d0 + d1) + (d2 + d3) + (d4 + d5) + (d6 + d7);
       s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3) + (d4 * d4 + d5 * d5) + (d6 * d6 + d7 * d7);
     }
@@ -263,16 +270,17 @@ __global__ __launch_bounds__(256) void k_layernorm(LnParams p) {
       const int kb = kb0 + i;
       const int64_t e = ((tb * p.KB + kb) * 64 + lane) * 8;
       const int o = (kb * 2 + h) * 8;
-      const float in[8] = {v[i][0].x, v[i][0].y, v[i][0].z, v[i][0].w, v[i][1].x, v[i][1].y, v[i][1].z, v[i][1].w};
       float out[8];
       half8 hv;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        out[j] = (in[j] - mean) * rstd * p.g[o + j] + p.b[o + j];
+        out[j] = (v[i][j] - mean) * rstd * p.g[o + j] + p.b[o + j];
         hv[j] = (_Float16)out[j];
       }
-      *reinterpret_cast<float4 *>(p.res + e) = make_float4(out[0], out[1], out[2], out[3]);
-      *reinterpret_cast<float4 *>(p.res + e + 4) = make_float4(out[4], out[5], out[6], out[7]);
+      if (p.res) {
+        *reinterpret_cast<float4 *>(p.res + e) = make_float4(out[0], out[1], out[2], out[3]);
+        *reinterpret_cast<float4 *>(p.res + e + 4) = make_float4(out[4], out[5], out[6], out[7]);
+      }
       *reinterpret_cast<half8 *>(p.act + e) = hv;
     }
   }
@@ -286,13 +294,18 @@ __global__ __launch_bounds__(256) void k_layernorm_wave(LnParams p) {
   const int h = lane >> 5;
   // one statistics pass: sums of (x - c) and (x - c)^2 with c = the token's first value (shifted, so the
   // single-pass variance does not cancel), then the normalising pass: two reads of the row instead of three
-  const float c = __shfl(p.in[(tb * p.KB * 64 + (lane & 31)) * 8], lane & 31);
+  float c0;
+  {
+    const int64_t e0 = (tb * p.KB * 64 + (lane & 31)) * 8;
+    c0 = (float)p.x[e0] + (float)p.delta[e0];
+  }
+  const float c = __shfl(c0, lane & 31);
   float s = 0.f, s2 = 0.f;
   for (int kb = 0; kb < p.KB; ++kb) {
-    const float4 *x = reinterpret_cast<const float4 *>(p.in + ((tb * p.KB + kb) * 64 + lane) * 8);
-    const float4 a = x[0], b = x[1];
-    const float d0 = a.x - c, d1 = a.y - c, d2 = a.z - c, d3 = a.w - c, d4 = b.x - c, d5 = b.y - c, d6 = b.z - c,
-                d7 = b.w - c;
+    float v[8];
+    ln_load8(p, ((tb * p.KB + kb) * 64 + lane) * 8, v);
+    const float d0 = v[0] - c, d1 = v[1] - c, d2 = v[2] - c, d3 = v[3] - c, d4 = v[4] - c, d5 = v[5] - c, d6 = v[6] - c,
+                d7 = v[7] - c;
     s += (d0 + d1) + (d2 + d3) + (d4 + d5) + (d6 + d7);
     s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3) + (d4 * d4 + d5 * d5) + (d6 * d6 + d7 * d7);
   }
@@ -305,15 +318,18 @@ __global__ __launch_bounds__(256) void k_layernorm_wave(LnParams p) {
   for (int kb = 0; kb < p.KB; ++kb) {
     const int64_t e = ((tb * p.KB + kb) * 64 + lane) * 8;
     const int o = (kb * 2 + h) * 8;
-    float out[8];
+    float v[8], out[8];
+    ln_load8(p, e, v);
     half8 hv;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      out[j] = (p.in[e + j] - mean) * rstd * p.g[o + j] + p.b[o + j];
+      out[j] = (v[j] - mean) * rstd * p.g[o + j] + p.b[o + j];
       hv[j] = (_Float16)out[j];
     }
-    *reinterpret_cast<float4 *>(p.res + e) = make_float4(out[0], out[1], out[2], out[3]);
-    *reinterpret_cast<float4 *>(p.res + e + 4) = make_float4(out[4], out[5], out[6], out[7]);
+    if (p.res) {
+      *reinterpret_cast<float4 *>(p.res + e) = make_float4(out[0], out[1], out[2], out[3]);
+      *reinterpret_cast<float4 *>(p.res + e + 4) = make_float4(out[4], out[5], out[6], out[7]);
+    }
     *reinterpret_cast<half8 *>(p.act + e) = hv;
   }
 }
@@ -324,7 +340,7 @@ static void launch_layernorm(const LnParams &p, hipStream_t st) {
 }
 
 // ---- GEMM: out[t][n] = sum_k act[t][k] * W[n][k] + bias[n] -------------------------------------------
-enum { EPI_ACT = 0, EPI_GELU = 1, EPI_RES = 2, EPI_VT = 3 };
+enum { EPI_ACT = 0, EPI_GELU = 1, EPI_VT = 3 };
 
 struct GemmParams {
   const uint4 *act;   // [TB][KB][64]
@@ -333,8 +349,6 @@ struct GemmParams {
   int NB, KB;
   const float *bias_acc;  // [NB][2][16] (token-on-lane epilogues)
   const float *bias;      // [N] plain (EPI_VT)
-  const float *res_in;    // EPI_RES: blocked f32 [TB][NB*2][64][8]
-  float *res_out;         // EPI_RES
   _Float16 *out;          // EPI_ACT / EPI_GELU: [TB][NB*2][64][8]; EPI_VT: [NB][TB*2][64][8]
 };
 
@@ -389,17 +403,10 @@ __device__ __forceinline__ void gemm_store_tile(const GemmParams &p, const float
       float o[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = c[8 * s + j] + ba[8 * s + j];
-      if (EPI == EPI_RES) {
-        const float4 r0 = *reinterpret_cast<const float4 *>(p.res_in + e);
-        const float4 r1 = *reinterpret_cast<const float4 *>(p.res_in + e + 4);
-        *reinterpret_cast<float4 *>(p.res_out + e) = make_float4(o[0] + r0.x, o[1] + r0.y, o[2] + r0.z, o[3] + r0.w);
-        *reinterpret_cast<float4 *>(p.res_out + e + 4) = make_float4(o[4] + r1.x, o[5] + r1.y, o[6] + r1.z, o[7] + r1.w);
-      } else {
-        half8 hv;
+      half8 hv;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) hv[j] = (_Float16)(EPI == EPI_GELU ? gelu_poly(o[j]) : o[j]);
-        *reinterpret_cast<half8 *>(p.out + e) = hv;
-      }
+      for (int j = 0; j < 8; ++j) hv[j] = (_Float16)(EPI == EPI_GELU ? gelu_poly(o[j]) : o[j]);
+      *reinterpret_cast<half8 *>(p.out + e) = hv;
     }
   }
 }
@@ -740,7 +747,7 @@ __global__ __launch_bounds__(512) void k_gemm_lds8(GemmParams p) {
 // loop waits for); two workgroups per CU on a 5-slot ring (the epilogue of one beside the k-loop of the other: +5 % on
 // the GEMMs that ran 2 rounds, nothing overall); XCD-contiguous instead of round-robin patch assignment (no change in
 // TCC misses, which are mostly the output stores).  MFMA pipes: 54 % busy at the 1.66 GHz the chip holds under this load.
-template <int EPI, int TN, int ABL = 0>  // ABL: developer ablations (1 no copies in the loop, 2 no MFMAs, 3 no epilogue)
+template <int EPI, int TN, int ABL = 0>  // ABL: developer ablations (1 no copies in the loop, 2 no MFMAs, 3 no epilogue, 4 no k-loop barriers)
 __global__ __launch_bounds__(512) void k_gemm_pp(GemmParams p, PatchGrid pg, int64_t n_slots) {
   constexpr int TM = 8, F = TM + TN, NW = TN / 2;
   constexpr int R = 8, PF = 5;
@@ -808,7 +815,7 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmParams p, PatchGrid pg, int
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-      __builtin_amdgcn_s_barrier();
+      if (ABL != 4) __builtin_amdgcn_s_barrier();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
@@ -830,7 +837,7 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmParams p, PatchGrid pg, int
         }
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
+      if (ABL != 4) __builtin_amdgcn_s_barrier();
       rd = rd + 1 == R ? 0 : rd + 1;
       wr = wr + 1 == R ? 0 : wr + 1;
     }
@@ -1020,8 +1027,8 @@ struct anr_encoder {
   int64_t ws_tokens = 0;
   int *d_ids = nullptr, *d_types = nullptr, *d_lens = nullptr, *d_rows = nullptr;
   int64_t ws_b = 0, ws_bl = 0;
-  float *res = nullptr, *res2 = nullptr, *out = nullptr;
-  _Float16 *act = nullptr, *qk = nullptr, *vt = nullptr, *ctx = nullptr, *ffn = nullptr;
+  float *res = nullptr, *out = nullptr;  // res: the last LayerNorm's output in f32 (pooling input)
+  _Float16 *act = nullptr, *delta = nullptr, *qk = nullptr, *vt = nullptr, *ctx = nullptr, *ffn = nullptr;
 };
 
 namespace {
@@ -1107,7 +1114,7 @@ void launch_gemm8(anr_encoder *e, GemmParams &g, int64_t blocks) {
     hipLaunchKernelGGL((k_gemm_pp<EPI, TN, A>), dim3((unsigned)grid), dim3(512), lds_pp, e->stream, g, pg, n_slots); \
   }
 #ifdef ANR_GEMM_ABLATIONS
-    if (abl == 1) ANR_PP(1) else if (abl == 2) ANR_PP(2) else if (abl == 3) ANR_PP(3) else
+    if (abl == 1) ANR_PP(1) else if (abl == 2) ANR_PP(2) else if (abl == 3) ANR_PP(3) else if (abl == 4) ANR_PP(4) else
 #endif
     ANR_PP(0)
     (void)abl;
@@ -1165,14 +1172,14 @@ int ensure_ws(anr_encoder *e, int B, int L, int Lp) {
   const auto &c = e->cfg;
   if (T > e->ws_tokens) {
     enc_free(e->res);
-    enc_free(e->res2);
+    enc_free(e->delta);
     enc_free(e->act);
     enc_free(e->qk);
     enc_free(e->vt);
     enc_free(e->ctx);
     enc_free(e->ffn);
     ANR_TRY(enc_alloc(&e->res, T * c.hidden));
-    ANR_TRY(enc_alloc(&e->res2, T * c.hidden));
+    ANR_TRY(enc_alloc(&e->delta, T * c.hidden));
     ANR_TRY(enc_alloc(&e->act, T * c.hidden));
     ANR_TRY(enc_alloc(&e->qk, T * c.hidden * 2));
     ANR_TRY(enc_alloc(&e->vt, T * c.hidden));
@@ -1244,7 +1251,7 @@ int anr_encoder_destroy(anr_encoder *e) {
     enc_free(l.ln1g); enc_free(l.ln1b); enc_free(l.ln2g); enc_free(l.ln2b);
   }
   enc_free(e->d_ids); enc_free(e->d_types); enc_free(e->d_lens); enc_free(e->d_rows);
-  enc_free(e->res); enc_free(e->res2); enc_free(e->out);
+  enc_free(e->res); enc_free(e->delta); enc_free(e->out);
   enc_free(e->act); enc_free(e->qk); enc_free(e->vt); enc_free(e->ctx); enc_free(e->ffn);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
@@ -1351,7 +1358,7 @@ int forward_impl(anr_encoder *e, const int32_t *ids, const int32_t *lengths, con
   ep.lens = e->d_lens;
   ep.B = B; ep.L = L; ep.Lp = Lp; ep.H = H; ep.KB = KB; ep.pos_offset = c.pos_offset; ep.max_pos = c.max_positions;
   ep.word = e->word; ep.pos = e->pos; ep.type = e->type; ep.g = e->eg; ep.b = e->eb; ep.eps = c.ln_eps;
-  ep.res = e->res; ep.act = e->act;
+  ep.act = e->act;
   if (KB % 4 == 0 && KB / 4 <= kLnMaxKbw) hipLaunchKernelGGL(k_embed_ln, dim3((unsigned)TB), dim3(256), 0, st, ep);
   else hipLaunchKernelGGL(k_embed_ln_wave, dim3((unsigned)ceil_div(TB, 4)), dim3(256), 0, st, ep);
 
@@ -1377,9 +1384,9 @@ int forward_impl(anr_encoder *e, const int32_t *ids, const int32_t *lengths, con
     else hipLaunchKernelGGL(k_attention<128>, dim3((unsigned)ceil_div(aw, 4)), dim3(256), 0, st, ap);
     GemmParams go{};
     go.act = reinterpret_cast<const uint4 *>(e->ctx); go.w = reinterpret_cast<const uint4 *>(l.wo);
-    go.TB = TB; go.NB = H / 32; go.KB = KB; go.bias_acc = l.bo; go.res_in = e->res; go.res_out = e->res2;
-    launch_gemm<EPI_RES>(e, go);
-    LnParams l1{e->res2, TB, H, KB, l.ln1g, l.ln1b, c.ln_eps, e->res, e->act};
+    go.TB = TB; go.NB = H / 32; go.KB = KB; go.bias_acc = l.bo; go.out = e->delta;
+    launch_gemm<EPI_ACT>(e, go);
+    LnParams l1{e->act, e->delta, TB, H, KB, l.ln1g, l.ln1b, c.ln_eps, nullptr, e->act};
     launch_layernorm(l1, st);
     GemmParams g1{};
     g1.act = reinterpret_cast<const uint4 *>(e->act); g1.w = reinterpret_cast<const uint4 *>(l.w1);
@@ -1387,9 +1394,10 @@ int forward_impl(anr_encoder *e, const int32_t *ids, const int32_t *lengths, con
     launch_gemm<EPI_GELU>(e, g1);
     GemmParams g2{};
     g2.act = reinterpret_cast<const uint4 *>(e->ffn); g2.w = reinterpret_cast<const uint4 *>(l.w2);
-    g2.TB = TB; g2.NB = H / 32; g2.KB = I / 16; g2.bias_acc = l.b2; g2.res_in = e->res; g2.res_out = e->res2;
-    launch_gemm<EPI_RES>(e, g2);
-    LnParams l2{e->res2, TB, H, KB, l.ln2g, l.ln2b, c.ln_eps, e->res, e->act};
+    g2.TB = TB; g2.NB = H / 32; g2.KB = I / 16; g2.bias_acc = l.b2; g2.out = e->delta;
+    launch_gemm<EPI_ACT>(e, g2);
+    // the last LayerNorm of the forward also leaves its output in f32: the pooling input
+    LnParams l2{e->act, e->delta, TB, H, KB, l.ln2g, l.ln2b, c.ln_eps, li + 1 == c.n_layers ? e->res : nullptr, e->act};
     launch_layernorm(l2, st);
   }
   PoolParams pp{e->res, e->d_lens, B, Lp, H, KB, c.pooling, normalize ? 1 : 0, out_dev ? out_dev : e->out,

@@ -1,4 +1,4 @@
-"""GPU parity: the HIP sentence encoder (anr_encoder_*, f16 MFMA operands / f32 accumulate / f32 residual)
+"""GPU parity: the HIP sentence encoder (anr_encoder_*, f16 MFMA operands and activations / f32 accumulate / f32 LayerNorm arithmetic)
 against the float32 CPU oracle (transformers forward through the sentence-transformers pipeline) on seeded
 random weights of the reference's model shapes.  Tolerance (f16 operands): cosine >= 0.9995 and max abs
 difference of the unit-norm embeddings <= 5e-3; the pooled (un-normalised) output within 2 % relative."""

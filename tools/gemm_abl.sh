@@ -1,6 +1,6 @@
 #!/bin/bash
 # Developer tool (GPU box): per-kernel times of the encoder GEMMs for the schedule ablations of k_gemm_pp
-# (build csrc with `make FLAGS+=-DANR_GEMM_ABLATIONS` first; ablated builds compute wrong results).
+# (build csrc with `make EXTRA=-DANR_GEMM_ABLATIONS` first; ablated builds compute wrong results).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for abl in ${ABLS:-0 1 2 3}; do
