@@ -106,30 +106,6 @@ __device__ __forceinline__ bool fd_val(const FdSrc &s, int64_t q, int64_t i, dou
   return v == v;
 }
 
-// fused value of id i from the ARRAY sources only, in the reference's order of operations (dense, bm25, graph, then
-// path; an absent term contributes w * 0.0 exactly as `normed[k].get(nid, 0.0)` does); false: the id occurs in none
-__device__ __forceinline__ bool fd_key(const FdParams &p, const double (&smax)[4], int64_t q, int64_t i,
-                                       unsigned long long &key) {
-  double v;
-  if (p.method == 1) {
-    if (!fd_val(p.src[p.r1_src], q, i, v)) return false;
-    key = d2ord(v);
-    return true;
-  }
-  double f = 0.0;
-  bool any = false;
-#pragma unroll
-  for (int s = 0; s < 3; ++s)
-    if (fd_val(p.src[s], q, i, v)) {
-      f += p.w[s] * (smax[s] == 0.0 ? 0.0 : v / smax[s]);
-      any = true;
-    }
-  const bool hp = fd_val(p.src[3], q, i, v);
-  f = f + (hp ? p.w[3] * v : p.w[3] * 0.0);
-  key = d2ord(f);
-  return any || hp;
-}
-
 // One chunk's entries of a source for this thread: ids base + e * kFdThreads + tid.  The loads are UNCONDITIONAL (index
 // clamped, the array / dtype tests are uniform and sit outside the element loop): a per-element `if (i < len) load`
 // makes hipcc branch around every load and wait for each one before the next — eight dependent HBM round trips per
@@ -572,7 +548,8 @@ __device__ __forceinline__ void fd_scan_chunk(const FdParams &p, FsShared &sh, F
 #pragma unroll
     for (int e = 0; e < kFdPer; ++e) f[e] = fd_raw_value(DT0, raw[e]);
   } else {
-    // source after source, in the order fd_key adds them; a zero entry skips the f64 division (x / smax for x = +-0 is
+    // source after source, in the reference's order of operations (dense, bm25, graph, then path; an absent term
+    // contributes w * 0.0 exactly as `normed[k].get(nid, 0.0)` does); a zero entry skips the f64 division (x / smax for x = +-0 is
     // +-0 with the sign of x * smax) — and a wave whose 64 entries are all zero skips it altogether
 #pragma unroll
     for (int e = 0; e < kFdPer; ++e) {
