@@ -60,7 +60,7 @@ rm -rf $O/enc
 bash $R/tools/pmc_kernel.sh "k_gemm_pp<1" SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY TCC_HIT_sum TCC_MISS_sum -- $R/tools/enc_perf.py 256 64 > $O/${ROUND}_pmc_k_gemm_pp_ffn_up.txt 2>&1
 echo "[5] fusion" >&2
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/fd -- python3 $R/tools/fuse_dense_perf.py > $O/${ROUND}_fuse_dense_c5.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/fd -- python3 $R/tools/fuse_dense_perf.py 2>&1 | grep "queries x" > $O/${ROUND}_fuse_dense_c5.txt
 cp $(ls $O/fd/*/*kernel_stats.csv | head -1) $O/${ROUND}_fuse_dense_c5_kernel_stats.csv
 rm -rf $O/fd
 ls -la $O >&2
