@@ -291,15 +291,28 @@ class SentenceEncoder:
         """length-sorted batches (longest first, as SentenceTransformer.encode), tokenised one batch AHEAD on a worker
         thread: the tokenizer (Rust, releases the GIL) prepares batch i + 1 while the device runs the forward of
         batch i (the ctypes call releases the GIL as well).  The forward size is the device's business, not the
-        caller's memory knob: inputs of >= 256 sentences go in forwards of 128 (the second half is tokenised while the
-        first runs: at 256 queries the tokenizer is a third of the time), >= 2048 in forwards of 256; an embedding does
-        not depend on which sentences share its forward (padding is masked)."""
+        caller's memory knob (``batch_size`` is accepted and ignored): fewer than 256 sentences go in ONE forward (100
+        sentences as four forwards of 32 took 5 ms, as one 2.5 ms — small forwards leave most CUs idle), 256 and more
+        in forwards of 128 (the next is tokenised while one runs: at 256 queries the tokenizer is a third of the time),
+        2048 and more in forwards of 256; a forward also ends where the sorted texts get shorter than 60 % of its
+        first; an embedding does not depend on which sentences share its forward (padding is masked)."""
         n = len(sentences)
         if n == 0:
             return
         order = np.argsort([-len(s) for s in sentences], kind="stable")
-        fb = int(batch_size) if n < 256 else (128 if n < 2048 else 256)
-        sels = [order[s:s + fb] for s in range(0, n, fb)]
+        fb = n if n < 256 else (128 if n < 2048 else 256)
+        # a forward is padded to its longest sentence: cut where the texts (longest first) fall below 60 % of the
+        # forward's first one, but never before 16 sentences — mixed-length notes do not pay for the longest of all
+        sels, i = [], 0
+        while i < n:
+            first = max(len(sentences[order[i]]), 1)
+            j = i + 1
+            while j < n and j - i < fb and (j - i < 16 or len(sentences[order[j]]) * 10 >= first * 6):
+                j += 1
+            sels.append(order[i:j])
+            i = j
+        if len(sels) >= 2 and len(sels[-1]) < 16:  # a short tail rides with the forward before it
+            sels[-2:] = [np.concatenate(sels[-2:])]
         if len(sels) == 1:
             yield sels[0], self.tokenize([sentences[i] for i in sels[0]])
             return

@@ -1097,7 +1097,7 @@ int plain_copy(const float *host, int64_t n, float **dst) {
 template <int EPI, int TN>
 void launch_gemm8(anr_encoder *e, GemmParams &g, int64_t blocks) {
   static const bool pp = getenv("ANORAG_GEMM_LDS8") == nullptr;  // developer switch: set to run the older k_gemm_lds8 instead
-  if (pp) {
+  if (pp || TN < 6) {  // (the older kernel has no 128-wide form)
     constexpr int lds_pp = 8 * (8 + TN) * 1024;
 #ifdef ANR_GEMM_ABLATIONS
     static const int abl = getenv("ANORAG_GEMM_ABL") ? atoi(getenv("ANORAG_GEMM_ABL")) : 0;  // developer ablations (wrong results)
@@ -1121,14 +1121,16 @@ void launch_gemm8(anr_encoder *e, GemmParams &g, int64_t blocks) {
 #undef ANR_PP
     return;
   }
-  if (g.KB % 3 == 0) {
-    constexpr int lds8 = 3 * 3 * (8 + TN) * 1024;
-    (void)ensure_dynamic_lds(reinterpret_cast<const void *>(&k_gemm_lds8<EPI, TN, 3>), lds8);
-    hipLaunchKernelGGL((k_gemm_lds8<EPI, TN, 3>), dim3((unsigned)blocks), dim3(512), lds8, e->stream, g);
-  } else {  // KB is even (hidden sizes are multiples of 32): two k-steps per slot, e.g. H = 1024 (bge-m3, XLM-R large)
-    constexpr int lds8 = 3 * 2 * (8 + TN) * 1024;
-    (void)ensure_dynamic_lds(reinterpret_cast<const void *>(&k_gemm_lds8<EPI, TN, 2>), lds8);
-    hipLaunchKernelGGL((k_gemm_lds8<EPI, TN, 2>), dim3((unsigned)blocks), dim3(512), lds8, e->stream, g);
+  if constexpr (TN >= 6) {
+    if (g.KB % 3 == 0) {
+      constexpr int lds8 = 3 * 3 * (8 + TN) * 1024;
+      (void)ensure_dynamic_lds(reinterpret_cast<const void *>(&k_gemm_lds8<EPI, TN, 3>), lds8);
+      hipLaunchKernelGGL((k_gemm_lds8<EPI, TN, 3>), dim3((unsigned)blocks), dim3(512), lds8, e->stream, g);
+    } else {  // KB is even (hidden sizes are multiples of 32): two k-steps per slot, e.g. H = 1024 (bge-m3, XLM-R large)
+      constexpr int lds8 = 3 * 2 * (8 + TN) * 1024;
+      (void)ensure_dynamic_lds(reinterpret_cast<const void *>(&k_gemm_lds8<EPI, TN, 2>), lds8);
+      hipLaunchKernelGGL((k_gemm_lds8<EPI, TN, 2>), dim3((unsigned)blocks), dim3(512), lds8, e->stream, g);
+    }
   }
 }
 
@@ -1142,8 +1144,9 @@ void launch_gemm(anr_encoder *e, GemmParams &g) {
     return;
   }
   static const bool no_skinny = getenv("ANORAG_GEMM_NOSKINNY") != nullptr;  // developer switch
-  // measured crossover with the 256 x 256 tile at the bge-base shape: ~6000 tokens (tools/enc_perf.py)
-  static const int skinny_max = getenv("ANORAG_SKINNY_MAX") ? atoi(getenv("ANORAG_SKINNY_MAX")) : 160;
+  // measured crossover with the tile kernels at the bge-base shape (tools/enc_perf.py): 3072 tokens 1.80 ms skinny vs
+  // 2.25 tiled, 4096 tokens 2.16 vs 2.07
+  static const int skinny_max = getenv("ANORAG_SKINNY_MAX") ? atoi(getenv("ANORAG_SKINNY_MAX")) : 120;
   if (!no_skinny && g.TB <= skinny_max && g.KB % 4 == 0) {
     const int64_t blocks = (int64_t)g.NB * ceil_div(g.TB, 2);
     hipLaunchKernelGGL((k_gemm_skinny<EPI>), dim3((unsigned)blocks), dim3(256), 0, e->stream, g);
@@ -1151,13 +1154,14 @@ void launch_gemm(anr_encoder *e, GemmParams &g) {
   }
   static const bool wide = getenv("ANORAG_GEMM_NARROW") == nullptr;  // developer switch: the 4-wave tile everywhere
   if (wide && g.KB % 2 == 0 && g.TB >= 8 * 16) {
-    // tile width by grid shape: fewest rounds of workgroups over the CUs, weighted by the work per workgroup
-    const int64_t b8 = ceil_div(g.TB, 8) * ceil_div(g.NB, 8), b6 = ceil_div(g.TB, 8) * ceil_div(g.NB, 6);
-    // rounds of workgroups over the CUs x tile width; at equal cost the 192-wide tile (deeper ring: 8 k-steps in flight)
-    static const bool lds8 = getenv("ANORAG_GEMM_LDS8") != nullptr;
-    const int64_t cost8 = ceil_div(b8, e->n_cu) * 8, cost6 = ceil_div(b6, e->n_cu) * 6;
-    (void)lds8;
-    if (cost6 < cost8) launch_gemm8<EPI, 6>(e, g, b6);
+    // tile width by grid shape: fewest rounds of workgroups over the CUs, weighted by the work per workgroup.  The
+    // 128-wide tile exists for mid-sized inputs (8 K tokens x N = 768: 96 / 128 / 192 tiles at width 256 / 192 / 128 on
+    // 256 CUs — one round each way, so the narrowest tile, which spreads the same work over the most CUs, wins).
+    const int64_t rt = ceil_div(g.TB, 8);
+    const int64_t b8 = rt * ceil_div(g.NB, 8), b6 = rt * ceil_div(g.NB, 6), b4 = rt * ceil_div(g.NB, 4);
+    const int64_t cost8 = ceil_div(b8, e->n_cu) * 8, cost6 = ceil_div(b6, e->n_cu) * 6, cost4 = ceil_div(b4, e->n_cu) * 4;
+    if (cost4 < cost6 && cost4 < cost8) launch_gemm8<EPI, 4>(e, g, b4);
+    else if (cost6 < cost8) launch_gemm8<EPI, 6>(e, g, b6);
     else launch_gemm8<EPI, 8>(e, g, b8);
     return;
   }

@@ -276,10 +276,23 @@ def test_update_note_optimize_params_and_tfidf_namespace_fallback(cfg, model_dir
     vj.cleanup()
 
 
+def _same_hits(D1, I1, D2, I2, tol=5e-4):
+    """two top-k results over embeddings that agree to rounding: scores within tol; ids equal except where the scores of
+    the swapped entries are within tol of each other (a near tie may flip)"""
+    assert D1.shape == D2.shape and np.allclose(D1, D2, atol=tol)
+    for r in range(I1.shape[0]):
+        for p in np.nonzero(I1[r] != I2[r])[0]:
+            where = np.nonzero(I1[r] == I2[r, p])[0]
+            other = D1[r, where[0]] if len(where) else D1[r, -1]   # (pushed out of the list: compare with its end)
+            assert abs(float(other) - float(D1[r, p])) <= 2 * tol
+
+
 def test_streamed_and_sharded_builds_equal_the_one_shot_build(cfg, model_dir, tmp_path):
     """anorag_hip.offline_build: chunked device-resident encode -> add (with the embeddings.npy side file), and the
     per-rank shard builds (two ranks played one after the other on this device) whose merged search equals the single
-    index"""
+    index.  The chunked builds run forwards of other sizes than the one-shot encode (other GEMM kernel variants,
+    other summation orders whose f32 results round to different f16 activations), so the embeddings agree to the encoder's
+    tolerance (cosine >= 0.99999 here), not bit for bit."""
     from anorag_hip import FlatIndex, METRIC_IP
     from anorag_hip.offline_build import sharded_build, stream_build
     from anorag_hip.sharded import merge_topk_host_c
@@ -297,11 +310,12 @@ def test_streamed_and_sharded_builds_equal_the_one_shot_build(cfg, model_dir, tm
     idx = FlatIndex(em.embedding_dim, METRIC_IP, normalize=True)
     npy = str(tmp_path / "embeddings.npy")
     assert stream_build(idx, em, notes, chunk_notes=64, embeddings_npy=npy) == 150 and idx.ntotal == 150
-    assert np.array_equal(np.load(npy), ref)
+    got = np.load(npy)
+    assert got.shape == ref.shape and np.max(np.abs(got - ref)) <= 1e-3 and np.sum(got * ref, axis=1).min() >= 0.99999
     q = em.encode_queries(words[:9])
     D1, I1 = one.search(q, 12)
     D2, I2 = idx.search(q, 12)
-    assert np.array_equal(I1, I2) and np.array_equal(D1, D2)
+    _same_hits(D1, I1, D2, I2)
     parts = []
     for rank in range(2):
         searcher, shard, (lo, hi) = sharded_build(em, notes, world=2, rank=rank, chunk_notes=50)
@@ -309,7 +323,7 @@ def test_streamed_and_sharded_builds_equal_the_one_shot_build(cfg, model_dir, tm
         parts.append(shard.search(q, 12))          # global ids (ANR_OPT_ID_OFFSET set by the searcher)
         shard.close()
     Dm, Im = merge_topk_host_c(np.stack([p[0] for p in parts]), np.stack([p[1] for p in parts]), True)
-    assert np.array_equal(Im, I1) and np.array_equal(Dm, D1)
+    _same_hits(D1, I1, Dm, Im)
     one.close()
     idx.close()
     EmbeddingManager._reset_singleton()
