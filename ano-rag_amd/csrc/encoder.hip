@@ -223,16 +223,33 @@ __device__ __forceinline__ void ln_load8(const LnParams &p, int64_t e, float (&v
 // one workgroup per 32-token block; each of the 4 waves owns a quarter of the feature blocks, keeps it in
 // registers (<= 16 blocks x 8 values per lane), and the per-token sums meet in LDS: the row is read once and
 // 4x as many waves stream as with one wave per token block
-__global__ __launch_bounds__(256) void k_layernorm(LnParams p) {
-  __shared__ float red[4][32][2];
+// NW waves per 32-token block, each owning KB / NW feature blocks in registers.  <4, false> is the throughput form
+// (large batches).  <16 / 8, true> is the LATENCY form for small inputs — a query at a time is the reference's own
+// calling pattern, and there a forward is ~100 dependent tiny kernels: the scale / shift vectors are requested together
+// with the activations (one memory round trip instead of two before the stores) and the block's work is spread over
+// four times the waves.  (At one 32-token block the 4-wave kernel took 11.7 us, a third of the single-query forward.)
+template <int NW, bool PRE>
+__global__ __launch_bounds__(NW * 64) void k_layernorm(LnParams p) {
+  constexpr int MAXI = kLnMaxKbw * 4 / NW;
+  __shared__ float red[NW][32][2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t tb = blockIdx.x;
   const int h = lane >> 5;
-  const int kbw = p.KB / 4, kb0 = wave * kbw;
-  float v[kLnMaxKbw][8];
+  const int kbw = p.KB / NW, kb0 = wave * kbw;
+  float v[MAXI][8];
+  float4 gv[PRE ? MAXI : 1][2], bv[PRE ? MAXI : 1][2];
 #pragma unroll
-  for (int i = 0; i < kLnMaxKbw; ++i)
-    if (i < kbw) ln_load8(p, ((tb * p.KB + kb0 + i) * 64 + lane) * 8, v[i]);
+  for (int i = 0; i < MAXI; ++i)
+    if (i < kbw) {
+      ln_load8(p, ((tb * p.KB + kb0 + i) * 64 + lane) * 8, v[i]);
+      if (PRE) {
+        const int o = ((kb0 + i) * 2 + h) * 8;
+        gv[i][0] = *reinterpret_cast<const float4 *>(p.g + o);
+        gv[i][1] = *reinterpret_cast<const float4 *>(p.g + o + 4);
+        bv[i][0] = *reinterpret_cast<const float4 *>(p.b + o);
+        bv[i][1] = *reinterpret_cast<const float4 *>(p.b + o + 4);
+      }
+    }
   // shifted single-pass statistics: sums of (x - c) and (x - c)^2 with c = the token's first value, so the
   // variance does not cancel
   float c0;
@@ -243,7 +260,7 @@ __global__ __launch_bounds__(256) void k_layernorm(LnParams p) {
   const float c = __shfl(c0, lane & 31);
   float s = 0.f, s2 = 0.f;
 #pragma unroll
-  for (int i = 0; i < kLnMaxKbw; ++i) {
+  for (int i = 0; i < MAXI; ++i) {
     if (i < kbw) {
       const float d0 = v[i][0] - c, d1 = v[i][1] - c, d2 = v[i][2] - c, d3 = v[i][3] - c, d4 = v[i][4] - c, d5 = v[i][5] - c,
                   d6 = v[i][6] - c, d7 = v[i][7] - c;
@@ -258,23 +275,46 @@ __global__ __launch_bounds__(256) void k_layernorm(LnParams p) {
     red[wave][lane][1] = s2;
   }
   __syncthreads();
-  s = (red[0][lane & 31][0] + red[1][lane & 31][0]) + (red[2][lane & 31][0] + red[3][lane & 31][0]);
-  s2 = (red[0][lane & 31][1] + red[1][lane & 31][1]) + (red[2][lane & 31][1] + red[3][lane & 31][1]);
+  s = 0.f;
+  s2 = 0.f;
+  if (NW == 4) {  // (the round-1 summation order of the throughput form, kept bit for bit)
+    s = (red[0][lane & 31][0] + red[1][lane & 31][0]) + (red[2][lane & 31][0] + red[3][lane & 31][0]);
+    s2 = (red[0][lane & 31][1] + red[1][lane & 31][1]) + (red[2][lane & 31][1] + red[3][lane & 31][1]);
+  } else {
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      s += red[w][lane & 31][0];
+      s2 += red[w][lane & 31][1];
+    }
+  }
   const float md = s / p.H;                       // mean - c
   const float var = fmaxf(s2 / p.H - md * md, 0.f);
   const float mean = c + md;
   const float rstd = rsqrtf(var + p.eps);
 #pragma unroll
-  for (int i = 0; i < kLnMaxKbw; ++i) {
+  for (int i = 0; i < MAXI; ++i) {
     if (i < kbw) {
       const int kb = kb0 + i;
       const int64_t e = ((tb * p.KB + kb) * 64 + lane) * 8;
       const int o = (kb * 2 + h) * 8;
+      float gg[8], bb[8];
+      if (PRE) {
+        gg[0] = gv[i][0].x; gg[1] = gv[i][0].y; gg[2] = gv[i][0].z; gg[3] = gv[i][0].w;
+        gg[4] = gv[i][1].x; gg[5] = gv[i][1].y; gg[6] = gv[i][1].z; gg[7] = gv[i][1].w;
+        bb[0] = bv[i][0].x; bb[1] = bv[i][0].y; bb[2] = bv[i][0].z; bb[3] = bv[i][0].w;
+        bb[4] = bv[i][1].x; bb[5] = bv[i][1].y; bb[6] = bv[i][1].z; bb[7] = bv[i][1].w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          gg[j] = p.g[o + j];
+          bb[j] = p.b[o + j];
+        }
+      }
       float out[8];
       half8 hv;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        out[j] = (v[i][j] - mean) * rstd * p.g[o + j] + p.b[o + j];
+        out[j] = (v[i][j] - mean) * rstd * gg[j] + bb[j];
         hv[j] = (_Float16)out[j];
       }
       if (p.res) {
@@ -335,7 +375,13 @@ __global__ __launch_bounds__(256) void k_layernorm_wave(LnParams p) {
 }
 
 static void launch_layernorm(const LnParams &p, hipStream_t st) {
-  if (p.KB % 4 == 0 && p.KB / 4 <= kLnMaxKbw) hipLaunchKernelGGL(k_layernorm, dim3((unsigned)p.TB), dim3(256), 0, st, p);
+  const bool small = p.TB <= 64;  // <= 2048 tokens: latency matters, not throughput
+  if (small && p.KB % 16 == 0 && p.KB / 16 <= kLnMaxKbw / 4)
+    hipLaunchKernelGGL((k_layernorm<16, true>), dim3((unsigned)p.TB), dim3(1024), 0, st, p);
+  else if (small && p.KB % 8 == 0 && p.KB / 8 <= kLnMaxKbw / 2)
+    hipLaunchKernelGGL((k_layernorm<8, true>), dim3((unsigned)p.TB), dim3(512), 0, st, p);
+  else if (p.KB % 4 == 0 && p.KB / 4 <= kLnMaxKbw)
+    hipLaunchKernelGGL((k_layernorm<4, false>), dim3((unsigned)p.TB), dim3(256), 0, st, p);
   else hipLaunchKernelGGL(k_layernorm_wave, dim3((unsigned)ceil_div(p.TB, 4)), dim3(256), 0, st, p);
 }
 
@@ -499,22 +545,28 @@ __global__ __launch_bounds__(256) void k_gemm_skinny(GemmParams p) {
     c0[r] = 0.f;
     c1[r] = 0.f;
   }
-  for (int k = 0; k < kq; k += 2) {  // kq is even (KB is a multiple of 8): two k-steps' operands in flight
-    half8 wv[2], x0[2], x1[2];
+  // Six k-steps' operands in flight per round: at 32 tokens this kernel is a chain of memory round trips (K = 768 is
+  // 12 k-steps per wave: two rounds instead of six), and a query at a time is the reference's own calling pattern.
+  constexpr int U = 6;
+  for (int k = 0; k < kq; k += U) {
+    half8 wv[U], x0[U], x1[U];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      wv[u] = __builtin_bit_cast(half8, wp[(int64_t)(k + u) * 64]);
-      x0[u] = __builtin_bit_cast(half8, a0[(int64_t)(k + u) * 64]);
-      x1[u] = __builtin_bit_cast(half8, a1[(int64_t)(k + u) * 64]);
+    for (int u = 0; u < U; ++u) {
+      const int kk = k + u < kq ? k + u : kq - 1;  // (clamped: the tail round repeats its last k-step's loads, unused)
+      wv[u] = __builtin_bit_cast(half8, wp[(int64_t)kk * 64]);
+      x0[u] = __builtin_bit_cast(half8, a0[(int64_t)kk * 64]);
+      x1[u] = __builtin_bit_cast(half8, a1[(int64_t)kk * 64]);
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      if (EPI == EPI_VT) {
-        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x0[u], wv[u], c0, 0, 0, 0);  // rows = tokens
-        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x1[u], wv[u], c1, 0, 0, 0);
-      } else {
-        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[u], x0[u], c0, 0, 0, 0);  // rows = features
-        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[u], x1[u], c1, 0, 0, 0);
+    for (int u = 0; u < U; ++u) {
+      if (k + u < kq) {
+        if (EPI == EPI_VT) {
+          c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x0[u], wv[u], c0, 0, 0, 0);  // rows = tokens
+          c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x1[u], wv[u], c1, 0, 0, 0);
+        } else {
+          c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[u], x0[u], c0, 0, 0, 0);  // rows = features
+          c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[u], x1[u], c1, 0, 0, 0);
+        }
       }
     }
   }
@@ -1330,35 +1382,16 @@ int anr_encoder_finalize(anr_encoder *e) {
 
 namespace {
 // out_host: [B][hidden] host memory; or out_dev: device memory, sequence b written to row out_rows[b] (host [B], or row b)
-int forward_impl(anr_encoder *e, const int32_t *ids, const int32_t *lengths, const int32_t *type_ids, int32_t B,
-                 int32_t L, int32_t normalize, float *out_host, float *out_dev, const int32_t *out_rows) {
-  if (!e || !ids || !lengths || (!out_host && !out_dev)) return fail(ANR_EINVAL, "null argument");
-  if (B <= 0 || L <= 0) return fail(ANR_EINVAL, "B and L must be positive");
+// every kernel of one forward, enqueued on the encoder's stream
+void enqueue_forward(anr_encoder *e, int B, int L, int Lp, bool use_types, int normalize, float *out, const int *rows) {
   const auto &c = e->cfg;
-  if (L + c.pos_offset > c.max_positions) return fail(ANR_EINVAL, "sequence length %d exceeds the position table", L);
-  for (int b = 0; b < B; ++b)
-    if (lengths[b] <= 0 || lengths[b] > L) return fail(ANR_EINVAL, "lengths[%d] = %d out of range 1..%d", b, lengths[b], L);
-  for (int64_t i = 0; i < (int64_t)B * L; ++i) {
-    if (ids[i] < 0 || ids[i] >= c.vocab_size) return fail(ANR_EINVAL, "token id %d out of range", ids[i]);
-    if (type_ids && (type_ids[i] < 0 || type_ids[i] >= c.type_vocab_size)) return fail(ANR_EINVAL, "type id out of range");
-  }
-  DeviceGuard g(e->device);
-  if (!g.ok) return fail(ANR_EHIP, "hipSetDevice failed");
-  std::lock_guard<std::mutex> lk(e->mu);
-  if (!e->finalized) return fail(ANR_ESTATE, "encoder weights are not finalized");
-  const int Lp = (int)round_up(L, 32);
-  ANR_TRY(ensure_ws(e, B, L, Lp));
   hipStream_t st = e->stream;
-  ANR_HIP(hipMemcpyAsync(e->d_ids, ids, (size_t)B * L * sizeof(int), hipMemcpyHostToDevice, st));
-  if (type_ids) ANR_HIP(hipMemcpyAsync(e->d_types, type_ids, (size_t)B * L * sizeof(int), hipMemcpyHostToDevice, st));
-  ANR_HIP(hipMemcpyAsync(e->d_lens, lengths, (size_t)B * sizeof(int), hipMemcpyHostToDevice, st));
-  if (out_dev && out_rows) ANR_HIP(hipMemcpyAsync(e->d_rows, out_rows, (size_t)B * sizeof(int), hipMemcpyHostToDevice, st));
   const int H = c.hidden, I = c.intermediate, KB = H / 16;
   const int64_t TB = (int64_t)B * Lp / 32;
 
   EmbedParams ep{};
   ep.ids = e->d_ids;
-  ep.types = type_ids ? e->d_types : nullptr;
+  ep.types = use_types ? e->d_types : nullptr;
   ep.lens = e->d_lens;
   ep.B = B; ep.L = L; ep.Lp = Lp; ep.H = H; ep.KB = KB; ep.pos_offset = c.pos_offset; ep.max_pos = c.max_positions;
   ep.word = e->word; ep.pos = e->pos; ep.type = e->type; ep.g = e->eg; ep.b = e->eb; ep.eps = c.ln_eps;
@@ -1404,11 +1437,40 @@ int forward_impl(anr_encoder *e, const int32_t *ids, const int32_t *lengths, con
     LnParams l2{e->act, e->delta, TB, H, KB, l.ln2g, l.ln2b, c.ln_eps, li + 1 == c.n_layers ? e->res : nullptr, e->act};
     launch_layernorm(l2, st);
   }
-  PoolParams pp{e->res, e->d_lens, B, Lp, H, KB, c.pooling, normalize ? 1 : 0, out_dev ? out_dev : e->out,
-                (out_dev && out_rows) ? e->d_rows : nullptr};
+  PoolParams pp{e->res, e->d_lens, B, Lp, H, KB, c.pooling, normalize ? 1 : 0, out, rows};
   hipLaunchKernelGGL(k_pool, dim3(B), dim3(256), 0, st, pp);
+}
+
+int forward_impl(anr_encoder *e, const int32_t *ids, const int32_t *lengths, const int32_t *type_ids, int32_t B,
+                 int32_t L, int32_t normalize, float *out_host, float *out_dev, const int32_t *out_rows) {
+  if (!e || !ids || !lengths || (!out_host && !out_dev)) return fail(ANR_EINVAL, "null argument");
+  if (B <= 0 || L <= 0) return fail(ANR_EINVAL, "B and L must be positive");
+  const auto &c = e->cfg;
+  if (L + c.pos_offset > c.max_positions) return fail(ANR_EINVAL, "sequence length %d exceeds the position table", L);
+  for (int b = 0; b < B; ++b)
+    if (lengths[b] <= 0 || lengths[b] > L) return fail(ANR_EINVAL, "lengths[%d] = %d out of range 1..%d", b, lengths[b], L);
+  for (int64_t i = 0; i < (int64_t)B * L; ++i) {
+    if (ids[i] < 0 || ids[i] >= c.vocab_size) return fail(ANR_EINVAL, "token id %d out of range", ids[i]);
+    if (type_ids && (type_ids[i] < 0 || type_ids[i] >= c.type_vocab_size)) return fail(ANR_EINVAL, "type id out of range");
+  }
+  DeviceGuard g(e->device);
+  if (!g.ok) return fail(ANR_EHIP, "hipSetDevice failed");
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (!e->finalized) return fail(ANR_ESTATE, "encoder weights are not finalized");
+  const int Lp = (int)round_up(L, 32);
+  ANR_TRY(ensure_ws(e, B, L, Lp));
+  hipStream_t st = e->stream;
+  ANR_HIP(hipMemcpyAsync(e->d_ids, ids, (size_t)B * L * sizeof(int), hipMemcpyHostToDevice, st));
+  if (type_ids) ANR_HIP(hipMemcpyAsync(e->d_types, type_ids, (size_t)B * L * sizeof(int), hipMemcpyHostToDevice, st));
+  ANR_HIP(hipMemcpyAsync(e->d_lens, lengths, (size_t)B * sizeof(int), hipMemcpyHostToDevice, st));
+  if (out_dev && out_rows) ANR_HIP(hipMemcpyAsync(e->d_rows, out_rows, (size_t)B * sizeof(int), hipMemcpyHostToDevice, st));
+  float *out = out_dev ? out_dev : e->out;
+  const int *rows = (out_dev && out_rows) ? e->d_rows : nullptr;
+  // (Replaying the kernel sequence from a captured hipGraph was tried for small forwards — a query at a time is ~100
+  // dependent launches — and changed nothing: 0.80 vs 0.76 ms; the time is inside the tiny kernels, not between them.)
+  enqueue_forward(e, B, L, Lp, type_ids != nullptr, normalize, out, rows);
   ANR_HIP(hipGetLastError());
-  if (out_host) ANR_HIP(hipMemcpyAsync(out_host, e->out, (size_t)B * H * sizeof(float), hipMemcpyDeviceToHost, st));
+  if (out_host) ANR_HIP(hipMemcpyAsync(out_host, e->out, (size_t)B * c.hidden * sizeof(float), hipMemcpyDeviceToHost, st));
   ANR_HIP(hipStreamSynchronize(st));
   return ANR_OK;
 }
