@@ -278,13 +278,14 @@ class SentenceEncoder:
         tok.enable_truncation(max_length=max_len)
         tok.no_padding()
         encs = tok.encode_batch([str(t) for t in texts])
-        lens = np.array([len(e.ids) for e in encs], dtype=np.int32)
+        lists = [e.ids for e in encs]  # ONE conversion per sentence (each `.ids` / `.type_ids` access builds a new list)
+        lens = np.fromiter((len(x) for x in lists), dtype=np.int32, count=len(lists))
         L = int(lens.max())
-        ids = np.full((len(encs), L), self._pad, dtype=np.int32)
-        types = np.zeros((len(encs), L), dtype=np.int32)
-        for i, e in enumerate(encs):
-            ids[i, :lens[i]] = e.ids
-            types[i, :lens[i]] = e.type_ids
+        ids = np.full((len(lists), L), self._pad, dtype=np.int32)
+        for i, x in enumerate(lists):
+            ids[i, :len(x)] = x
+        # single sentences: every token is of segment 0 (the reference never encodes pairs, embedding_manager.py:392)
+        types = np.zeros((len(lists), L), dtype=np.int32)
         return ids, lens, types
 
     def _batches(self, sentences, batch_size):
