@@ -315,6 +315,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # the reference-facing call is timed BEFORE the CPU legs: after the oracle's 10 M-row BLAS passes (recall) the same
+    # loop ran 2.3x slower on two boxes (6.4 vs 2.8 ms per call) — host threads left spinning, nothing on the device
+    facade = None
+    if rank == 0 and world == 1 and not args.no_facade:
+        facade = facade_leg(idx, args, Q[nb - 1].cpu().numpy())
+
     # recall@k of the last batch's first few queries vs the oracle: every rank ranks its own rows on the CPU
     # (float64), rank 0 merges the partial lists and compares with the ids the GPU path returned
     recall = None
@@ -335,9 +341,6 @@ def main():
             parts = [part]
         if rank == 0:
             recall = recall_from_partials(parts, I_gpu, args.k)
-    facade = None
-    if rank == 0 and world == 1 and not args.no_facade:
-        facade = facade_leg(idx, args, Q[nb - 1].cpu().numpy())
 
     if rank == 0:
         tnotes = []
