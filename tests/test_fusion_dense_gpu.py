@@ -217,3 +217,32 @@ def test_host_supplied_row_maxima_match_the_device_max_pass():
         assert np.array_equal(x, y, equal_nan=True)
     plain.free()
     known.free()
+
+
+def test_one_long_query_drains_the_deferred_rank_searches_inside_the_scan():
+    """ONE query over 48 M notes at 1 % density: every workgroup walks ~23 chunks of the same query and every wave defers
+    ~5 rank searches per chunk, so the per-wave LDS segments fill and are searched INSIDE the scan (the drain protocol:
+    flag raised one chunk ahead, acted on after the next chunk's barrier) — the 1 M-note shapes above never get there,
+    they finish a query before a segment fills.  rrf (exact ranks of the short-list ids among all 48 M) and linear."""
+    from anorag_hip.fusion import DeviceArray, fuse_dense
+    rng = np.random.default_rng(77)
+    n, pool = 48_000_000, 60
+    bm = np.zeros((1, n), dtype=np.float64)
+    nz = rng.choice(n, n // 100, replace=False)
+    bm[0, nz] = np.round(np.abs(rng.standard_normal(len(nz))), 3) + 0.001    # ties among the non-zero values too
+    d_ids = np.concatenate([rng.choice(nz, 40, replace=False), rng.choice(n, 60, replace=False)]).astype(np.int64)
+    d_ids = np.unique(d_ids)
+    dense = [(d_ids, np.sort(rng.uniform(0.2, 0.9, len(d_ids)))[::-1].copy())]
+    w = {"dense": 1.0, "bm25": 0.5, "graph": 0.0, "path": 0.0}
+    arr = DeviceArray.from_numpy(bm, with_max=True)
+    full = np.arange(n, dtype=np.int64)
+    for method in ("rrf", "linear"):
+        ids, fin, _, cnt, st = fuse_dense(method, w, 60.0, pool, 1, {"dense": dense, "bm25": arr}, want_stats=True)
+        e_ids, e_fin = ofu.fuse_arrays(n, (dense[0], (full, bm[0]), None, None), [1.0, 0.5, 0.0, 0.0], method, 60, pool)
+        assert cnt[0] == pool and fin[0].tolist() == e_fin.tolist()
+        if method == "rrf":
+            assert ids[0].tolist() == e_ids.tolist()
+        else:
+            assert sorted(ids[0][fin[0] > e_fin[-1]].tolist()) == sorted(e_ids[e_fin > e_fin[-1]].tolist())
+        assert st["scan_bytes"] == n * 8
+    arr.free()
