@@ -246,3 +246,49 @@ def test_one_long_query_drains_the_deferred_rank_searches_inside_the_scan():
             assert sorted(ids[0][fin[0] > e_fin[-1]].tolist()) == sorted(e_ids[e_fin > e_fin[-1]].tolist())
         assert st["scan_bytes"] == n * 8
     arr.free()
+
+
+@pytest.mark.parametrize("method", ["rrf", "linear"])
+def test_float32_score_arrays_equal_the_float64_arrays_of_the_same_values(method):
+    """array_dtype = 1: a float32 vector stands for the float64 values it converts to exactly — same results as the
+    float64 array of those values (and as the oracle on them); mixed with a second, float64, array source for linear;
+    lengths that end inside a chunk"""
+    from anorag_hip.fusion import DeviceArray, fuse_dense
+    rng = np.random.default_rng(13)
+    n, nq, pool = 150_001, 3, 50
+    v32 = np.zeros((nq, n), dtype=np.float32)
+    for q in range(nq):
+        nz = rng.choice(n, 900, replace=False)
+        v32[q, nz] = np.abs(rng.standard_normal(900)).astype(np.float32)
+    v32[1, rng.choice(n, 200, replace=False)] = np.nan  # absent ids
+    v64 = v32.astype(np.float64)
+    dense = [(rng.choice(n, 70, replace=False).astype(np.int64), np.sort(rng.uniform(0.1, 0.9, 70))[::-1].copy())
+             for _ in range(nq)]
+    w = {"dense": 1.0, "bm25": 0.5, "graph": 0.3, "path": 0.0}
+    a32, a64 = DeviceArray.from_numpy(v32), DeviceArray.from_numpy(v64)
+    assert a32.dtype == np.float32
+    r32 = fuse_dense(method, w, 60.0, pool, nq, {"dense": dense, "bm25": a32})
+    r64 = fuse_dense(method, w, 60.0, pool, nq, {"dense": dense, "bm25": a64})
+    for x, y in zip(r32, r64):
+        assert np.array_equal(x, y, equal_nan=True)
+    full = np.arange(n, dtype=np.int64)
+    for q in range(nq):
+        ok = ~np.isnan(v64[q])
+        e_ids, e_fin = ofu.fuse_arrays(n, (dense[q], (full[ok], v64[q][ok]), None, None), [1.0, 0.5, 0.3, 0.0], method, 60, pool)
+        assert r32[1][q].tolist() == e_fin.tolist()
+    if method == "linear":  # a second array source (graph), float64 and shorter than the first
+        g64 = np.abs(rng.standard_normal((nq, 100_000)))
+        g64[:, rng.random(100_000) < 0.99] = 0.0
+        ag = DeviceArray.from_numpy(g64)
+        m32 = fuse_dense("linear", w, 60.0, pool, nq, {"dense": dense, "bm25": a32, "graph": ag})
+        m64 = fuse_dense("linear", w, 60.0, pool, nq, {"dense": dense, "bm25": a64, "graph": ag})
+        for x, y in zip(m32, m64):
+            assert np.array_equal(x, y, equal_nan=True)
+        for q in range(nq):
+            ok = ~np.isnan(v64[q])
+            e_ids, e_fin = ofu.fuse_arrays(n, (dense[q], (full[ok], v64[q][ok]), (np.arange(100_000, dtype=np.int64), g64[q]), None),
+                                           [1.0, 0.5, 0.3, 0.0], "linear", 60, pool)
+            assert m32[1][q].tolist() == e_fin.tolist()
+        ag.free()
+    a32.free()
+    a64.free()
