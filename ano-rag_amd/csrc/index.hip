@@ -859,11 +859,20 @@ int search_large_k(anr_index *h, const float *q, bool q_on_host, int64_t nq, int
 
 // Tiny corpus, host buffers, a handful of queries: ONE kernel launch, completion by a word in pinned memory
 // (tiny_kernels.hpp).  Exact by construction (f32 rows, f64 accumulation): no certificate, no fallback.
+// workgroups of the single-launch search: few enough that the last one merges <= kTinyMaxMerge entries, enough that
+// every CU's slice is short — 128 up to 64 K rows, 256 beyond (measured, k = 10, bare C ABI: 10 k x 384 33 us with 128
+// vs 37 with 204 workgroups — the merge grows; 100 k x 768 85 vs 101)
+int64_t tiny_workgroups(const anr_index *h, int32_t k) {
+  const int64_t cap = h->ntotal > 65536 ? kTinyMaxWG : kTinyMaxWG / 2;
+  return std::max<int64_t>(1, std::min<int64_t>(cap, kTinyMaxMerge / k));
+}
+
+// Where the single launch beats the five-kernel pipeline for batches of <= 4 queries (tools/tiny_perf.py, k = 10):
+// 20 k x 768 41 vs 83 us, 50 k x 768 58 vs 86, 100 k x 768 85 vs 93; from ~120 k x 768 the pipeline's f16 scan wins.
 bool tiny_applies(const anr_index *h, int64_t nq, int32_t k) {
   if (!h->tiny || h->force_exact || nq < 1 || nq > kTinyMaxQ || k > kTinyMaxK) return false;
-  if (h->ntotal < 1 || h->ntotal * (int64_t)h->dim * 4 > ((int64_t)32 << 20)) return false;
-  const int64_t n_wg = std::max<int64_t>(1, std::min<int64_t>(kTinyMaxWG, kTinyMaxMerge / k));
-  return ceil_div(h->ntotal, n_wg) <= kTinyRowsPerWG;
+  if (h->ntotal < 1 || h->ntotal * (int64_t)h->dim * 4 > ((int64_t)352 << 20)) return false;
+  return ceil_div(h->ntotal, tiny_workgroups(h, k)) <= kTinyRowsPerWG;
 }
 
 int search_tiny(anr_index *h, const float *q, int64_t nq, int32_t k, float *D, int64_t *I) {
@@ -889,7 +898,7 @@ int search_tiny(anr_index *h, const float *q, int64_t nq, int32_t k, float *D, i
   tp.k = k;
   tp.n_rows = h->ntotal;
   // few enough workgroups that the last one merges <= kTinyMaxMerge entries, enough that every CU slice is short
-  int n_wg = (int)std::max<int64_t>(1, std::min<int64_t>(kTinyMaxWG, kTinyMaxMerge / k));
+  int n_wg = (int)tiny_workgroups(h, k);
   n_wg = (int)std::min<int64_t>(n_wg, ceil_div(h->ntotal, 16));
   tp.rows_per_wg = (int)ceil_div(h->ntotal, n_wg);
   tp.n_wg = (int)ceil_div(h->ntotal, tp.rows_per_wg);

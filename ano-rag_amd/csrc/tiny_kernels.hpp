@@ -14,7 +14,7 @@
 namespace anr {
 
 constexpr int kTinyThreads = 1024;
-constexpr int kTinyMaxWG = 128;
+constexpr int kTinyMaxWG = 256;       // (128 up to 64 K rows: see tiny_workgroups)
 constexpr int kTinyMaxK = 128;
 constexpr int kTinyMaxQ = 4;
 constexpr int kTinyRowsPerWG = 1024;   // rows a workgroup ranks among themselves

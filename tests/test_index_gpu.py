@@ -507,13 +507,14 @@ def test_candidate_list_overflow_falls_back_to_the_dense_exact_path():
 
 
 def test_tiny_corpus_single_launch_path_equals_the_pipeline_and_the_oracle():
-    """C1's regime (a few queries, host buffers, a corpus of a few MB): ONE kernel per call (tiny_kernels.hpp).  Same
+    """C1's regime (a few queries, host buffers, a corpus of up to ~350 MB): ONE kernel per call (tiny_kernels.hpp).  Same
     bits as the five-kernel pipeline (ANR_OPT_TINY = 0) and the oracle's ids — cosine and L2, a dimension that is not
     a multiple of 4, k larger than the corpus, an id offset, 1 to 4 queries, repeated calls (completion words)."""
     from anorag_hip import FlatIndex, METRIC_IP, METRIC_L2
     from anorag_hip._lib import OPT_ID_OFFSET, OPT_TINY
     for (n, d, k, metric, name, norm) in ((10_000, 384, 10, METRIC_IP, "ip", True), (7_777, 130, 100, METRIC_L2, "l2", False),
-                                          (37, 64, 50, METRIC_IP, "ip", True), (16_001, 96, 128, METRIC_IP, "ip", False)):
+                                          (37, 64, 50, METRIC_IP, "ip", True), (16_001, 96, 128, METRIC_IP, "ip", False),
+                                          (80_000, 768, 10, METRIC_IP, "ip", True)):  # > 64 K rows: 204 workgroups
         x, q = _data(n, d, 4, seed=n, qseed=n + 1)
         idx = FlatIndex(d, metric, normalize=norm)
         idx.add(x)
@@ -531,14 +532,17 @@ def test_tiny_corpus_single_launch_path_equals_the_pipeline_and_the_oracle():
         D1, I1 = idx.search(q[:1], k)
         assert np.array_equal(np.where(I1 >= 0, I1 - 5_000_000, -1), I[:1]) and np.array_equal(D1, D[:1])
         idx.close()
-    # beyond the path's limits the pipeline answers (5 queries; a 40 MB corpus)
+    # beyond the path's limits the pipeline answers (5 queries; more rows per workgroup than it ranks: 30 000 rows at
+    # k = 100 are 20 partial lists of 1500 rows)
     x, q = _data(30_000, 384, 5)
     idx = FlatIndex(384, METRIC_IP, normalize=True)
     idx.add(x)
     idx.search(q, 10)
     assert idx.last_stats()["n_dense_exact"] == 0
-    idx.search(q[:1], 10)
+    idx.search(q[:1], 100)
     assert idx.last_stats()["n_dense_exact"] == 0
+    idx.search(q[:1], 10)
+    assert idx.last_stats()["n_dense_exact"] == 1   # (and 46 MB at k = 10 is inside them)
     idx.close()
 
 
