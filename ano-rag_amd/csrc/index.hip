@@ -869,10 +869,17 @@ int64_t tiny_workgroups(const anr_index *h, int32_t k) {
 
 // Where the single launch beats the five-kernel pipeline for batches of <= 4 queries (tools/tiny_perf.py, k = 10):
 // 20 k x 768 41 vs 83 us, 50 k x 768 58 vs 86, 100 k x 768 85 vs 93; from ~120 k x 768 the pipeline's f16 scan wins.
+// Its cost grows with k (fewer, longer partial lists to rank and merge) and with the bytes a workgroup streams, the
+// pipeline's barely: at k = 100 it LOSES even on 10 k x 384 (97 vs 69 us), at k = 32 it wins up to ~1.6 MB per workgroup
+// (20 k x 768: 59 vs 81; 50 k x 768: 92 vs 82), at k = 50 it is level (10 k x 768: 63 vs 72; 40 k x 768: 113 vs 119).
 bool tiny_applies(const anr_index *h, int64_t nq, int32_t k) {
-  if (!h->tiny || h->force_exact || nq < 1 || nq > kTinyMaxQ || k > kTinyMaxK) return false;
-  if (h->ntotal < 1 || h->ntotal * (int64_t)h->dim * 4 > ((int64_t)352 << 20)) return false;
-  return ceil_div(h->ntotal, tiny_workgroups(h, k)) <= kTinyRowsPerWG;
+  if (!h->tiny || h->force_exact || nq < 1 || nq > kTinyMaxQ || k > kTinyMaxK || h->ntotal < 1) return false;
+  const int64_t rows_per_wg = ceil_div(h->ntotal, tiny_workgroups(h, k));
+  if (rows_per_wg > kTinyRowsPerWG) return false;
+  if (h->tiny >= 2) return true;  // forced (tests): structural limits only
+  if (k > 64) return false;
+  const int64_t slice_bytes = rows_per_wg * h->dim * 4;
+  return slice_bytes <= (k <= 32 ? (int64_t)1600 << 10 : (int64_t)800 << 10);
 }
 
 int search_tiny(anr_index *h, const float *q, int64_t nq, int32_t k, float *D, int64_t *I) {
@@ -1462,7 +1469,7 @@ int anr_index_set_option(anr_index *h, int32_t opt, int64_t value) {
       if (value < 0) return fail(ANR_EINVAL, "id offset must be >= 0");
       h->id_offset = value;
       break;
-    case ANR_OPT_TINY: h->tiny = value != 0; break;
+    case ANR_OPT_TINY: h->tiny = value < 0 ? 0 : (value > 2 ? 2 : (int)value); break;
     case ANR_OPT_FUSED_POST: h->fused_post = value != 0; break;
     case ANR_OPT_STREAMS:
       if (value < 1 || value > kWorkspaces) return fail(ANR_EINVAL, "streams must be in 1..%d", kWorkspaces);

@@ -119,8 +119,11 @@ int anr_index_self_join(anr_index *h, float threshold, int64_t cap, int64_t *I_h
 #define ANR_OPT_ADD_RAW 6         /* 1: adds store rows as given (already normalised: reloading a saved index) */
 #define ANR_OPT_STREAMS 7         /* streams the in-flight batches rotate over, 1..3 (default 3; 1 = one batch strictly after the other) */
 #define ANR_OPT_ID_OFFSET 8       /* added to every returned id: the first global row of this shard (default 0) */
-#define ANR_OPT_TINY 9            /* 1 (default): host-buffer searches of <= 4 queries, k <= 128, over a corpus of <= 32 MB run as ONE
-                                     kernel launch (exact f32 rows / f64 accumulate; completion by a word in pinned memory) */
+#define ANR_OPT_TINY 9            /* 1 (default): host-buffer searches of <= 4 queries run as ONE kernel launch (exact f32 rows / f64
+                                     accumulate; completion by a word in pinned memory) where that is measured faster than the
+                                     pipeline: k <= 64 and a short slice of rows per workgroup (e.g. k = 10 up to ~120 k x 768);
+                                     2: wherever the path is structurally able (k <= 128, <= 1024 rows per workgroup; for tests);
+                                     0: never.  Identical results either way */
 #define ANR_OPT_FUSED_POST 10     /* 1 (default): candidate select + exact re-score + finalize run as ONE kernel per batch; 0: the
                                      three separate launches (developer A/B switch, identical results) */
 int anr_index_set_option(anr_index *h, int32_t opt, int64_t value);

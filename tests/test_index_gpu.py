@@ -518,6 +518,7 @@ def test_tiny_corpus_single_launch_path_equals_the_pipeline_and_the_oracle():
         x, q = _data(n, d, 4, seed=n, qseed=n + 1)
         idx = FlatIndex(d, metric, normalize=norm)
         idx.add(x)
+        idx.set_option(OPT_TINY, 2)   # wherever the path is able, also where the pipeline is measured faster (k > 64)
         for nq in (1, 3, 4):
             for rep in range(3):
                 D, I = idx.search(q[:nq], k)
@@ -525,7 +526,7 @@ def test_tiny_corpus_single_launch_path_equals_the_pipeline_and_the_oracle():
                 assert st["n_dense_exact"] == nq and st["n_candidates"] == 0, st   # the single-launch path ran
             idx.set_option(OPT_TINY, 0)
             D0, I0 = idx.search(q[:nq], k)
-            idx.set_option(OPT_TINY, 1)
+            idx.set_option(OPT_TINY, 2)
             assert np.array_equal(I, I0) and np.array_equal(D, D0)
             _check(idx, x, q[:nq], k, name, norm)
         idx.set_option(OPT_ID_OFFSET, 5_000_000)
@@ -542,7 +543,9 @@ def test_tiny_corpus_single_launch_path_equals_the_pipeline_and_the_oracle():
     idx.search(q[:1], 100)
     assert idx.last_stats()["n_dense_exact"] == 0
     idx.search(q[:1], 10)
-    assert idx.last_stats()["n_dense_exact"] == 1   # (and 46 MB at k = 10 is inside them)
+    assert idx.last_stats()["n_dense_exact"] == 1   # (46 MB at k = 10 is inside them)
+    idx.search(q[:1], 80)                           # (default mode: k > 64 goes to the pipeline, measured faster there)
+    assert idx.last_stats()["n_dense_exact"] == 0
     idx.close()
 
 
