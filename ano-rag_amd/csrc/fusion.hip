@@ -1,4 +1,6 @@
 // Host side of anr_fuse_lists (include/anorag.h); the kernel lives in fusion_kernels.hpp.
+#include <cstring>
+
 #include "fusion_kernels.hpp"
 
 using namespace anr;
@@ -21,65 +23,52 @@ extern "C" int anr_fuse_lists(int32_t device, int32_t method, int64_t nq, const 
       if (o[s + 1] < o[s]) return fail(ANR_EINVAL, "offsets must be non-decreasing");
   }
   if (total > 0 && (!ids_host || !scores_host)) return fail(ANR_EINVAL, "null list pointers");
+  if (device < 0 || device >= kFuseMaxDevices) return fail(ANR_EINVAL, "device %d out of range", device);
   DeviceGuard g(device);
   if (!g.ok) return fail(ANR_EHIP, "hipSetDevice(%d) failed", device);
-  int64_t *d_ids = nullptr, *d_offs = nullptr, *d_oid = nullptr;
-  double *d_sc = nullptr, *d_of = nullptr, *d_os = nullptr;
-  int *d_cnt = nullptr;
-  int rc = ANR_OK;
-  auto cleanup = [&]() {
-    if (d_ids) (void)hipFree(d_ids);
-    if (d_offs) (void)hipFree(d_offs);
-    if (d_oid) (void)hipFree(d_oid);
-    if (d_sc) (void)hipFree(d_sc);
-    if (d_of) (void)hipFree(d_of);
-    if (d_os) (void)hipFree(d_os);
-    if (d_cnt) (void)hipFree(d_cnt);
-  };
-#define FUSE_HIP(x)                                                          \
-  do {                                                                       \
-    hipError_t _e = (x);                                                     \
-    if (_e != hipSuccess) {                                                  \
-      rc = fail(ANR_EHIP, "%s failed: %s", #x, hipGetErrorString(_e));      \
-      cleanup();                                                             \
-      return rc;                                                             \
-    }                                                                        \
-  } while (0)
-  const size_t nt = (size_t)(total > 0 ? total : 1);
-  FUSE_HIP(hipMalloc((void **)&d_ids, nt * 8));
-  FUSE_HIP(hipMalloc((void **)&d_sc, nt * 8));
-  FUSE_HIP(hipMalloc((void **)&d_offs, (size_t)nq * 5 * 8));
-  FUSE_HIP(hipMalloc((void **)&d_oid, (size_t)nq * pool * 8));
-  FUSE_HIP(hipMalloc((void **)&d_of, (size_t)nq * pool * 8));
-  FUSE_HIP(hipMalloc((void **)&d_os, (size_t)nq * pool * 4 * 8));
-  FUSE_HIP(hipMalloc((void **)&d_cnt, (size_t)nq * 4));
-  if (total > 0) {
-    FUSE_HIP(hipMemcpy(d_ids, ids_host, (size_t)total * 8, hipMemcpyHostToDevice));
-    FUSE_HIP(hipMemcpy(d_sc, scores_host, (size_t)total * 8, hipMemcpyHostToDevice));
+  // One device block and one pinned block, kept across calls; ONE upload [ids | scores | offsets], ONE download
+  // [ids | final | per-source | count].  (Seven hipMalloc / hipFree pairs and seven synchronous pageable copies per
+  // call were most of a single query's 480 us through HybridSearcher.fuse.)
+  static FuseArena arenas[kFuseMaxDevices];
+  FuseArena &ar = arenas[device];
+  std::lock_guard<std::mutex> lock(ar.mu);
+  Carve dc, hc;
+  const size_t nt = (size_t)total;
+  const size_t up_bytes = nt * 16 + (size_t)nq * 5 * 8;
+  const size_t o_fin = (size_t)nq * pool * 8, o_src = 2 * o_fin, o_cnt = o_src + (size_t)nq * pool * 32,
+               out_bytes = o_cnt + (size_t)nq * 4;
+  const size_t d_up = dc.take(up_bytes), d_out = dc.take(out_bytes);
+  const size_t h_up = hc.take(up_bytes), h_out = hc.take(out_bytes);
+  ANR_TRY(ar.reserve(dc.off, hc.off));
+  char *D = ar.dev, *H = ar.host;
+  if (nt) {
+    std::memcpy(H + h_up, ids_host, nt * 8);
+    std::memcpy(H + h_up + nt * 8, scores_host, nt * 8);
   }
-  FUSE_HIP(hipMemcpy(d_offs, offs_host, (size_t)nq * 5 * 8, hipMemcpyHostToDevice));
+  std::memcpy(H + h_up + nt * 16, offs_host, (size_t)nq * 5 * 8);
+  hipStream_t st = nullptr;
+  ANR_HIP(hipMemcpyAsync(D + d_up, H + h_up, up_bytes, hipMemcpyHostToDevice, st));
   FuseParams p{};
   p.method = method;
-  p.ids = d_ids;
-  p.scores = d_sc;
-  p.offs = d_offs;
+  p.ids = reinterpret_cast<const int64_t *>(D + d_up);
+  p.scores = reinterpret_cast<const double *>(D + d_up + nt * 8);
+  p.offs = reinterpret_cast<const int64_t *>(D + d_up + nt * 16);
   for (int s = 0; s < 4; ++s) p.w[s] = weights[s];
   p.rrf_k = rrf_k;
   p.pool = pool;
-  p.out_ids = d_oid;
-  p.out_final = d_of;
-  p.out_src = d_os;
-  p.out_count = d_cnt;
-  FUSE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fuse<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)sizeof(FuseShared)));
-  hipLaunchKernelGGL(k_fuse<false>, dim3((unsigned)nq), dim3(1024), sizeof(FuseShared), 0, p);
-  FUSE_HIP(hipGetLastError());
-  FUSE_HIP(hipMemcpy(out_ids, d_oid, (size_t)nq * pool * 8, hipMemcpyDeviceToHost));
-  FUSE_HIP(hipMemcpy(out_final, d_of, (size_t)nq * pool * 8, hipMemcpyDeviceToHost));
-  FUSE_HIP(hipMemcpy(out_src, d_os, (size_t)nq * pool * 4 * 8, hipMemcpyDeviceToHost));
-  FUSE_HIP(hipMemcpy(out_count, d_cnt, (size_t)nq * 4, hipMemcpyDeviceToHost));
-#undef FUSE_HIP
-  cleanup();
+  p.out_ids = reinterpret_cast<int64_t *>(D + d_out);
+  p.out_final = reinterpret_cast<double *>(D + d_out + o_fin);
+  p.out_src = reinterpret_cast<double *>(D + d_out + o_src);
+  p.out_count = reinterpret_cast<int *>(D + d_out + o_cnt);
+  ANR_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_fuse<false>), (int)sizeof(FuseShared)));
+  hipLaunchKernelGGL(k_fuse<false>, dim3((unsigned)nq), dim3(1024), sizeof(FuseShared), st, p);
+  ANR_HIP(hipGetLastError());
+  ANR_HIP(hipMemcpyAsync(H + h_out, D + d_out, out_bytes, hipMemcpyDeviceToHost, st));
+  ANR_HIP(hipStreamSynchronize(st));
+  std::memcpy(out_ids, H + h_out, o_fin);
+  std::memcpy(out_final, H + h_out + o_fin, o_fin);
+  std::memcpy(out_src, H + h_out + o_src, (size_t)nq * pool * 32);
+  std::memcpy(out_count, H + h_out + o_cnt, (size_t)nq * 4);
   return ANR_OK;
 }
 

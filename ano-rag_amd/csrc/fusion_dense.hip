@@ -1121,46 +1121,7 @@ __global__ __launch_bounds__(kFdThreads) void k_fd_build(FdParams p) {
 using namespace anr;
 
 namespace {
-// Work space of anr_fuse_dense: ONE device block and one pinned host block per device, grown on demand and kept for
-// the life of the process (25 hipMalloc/hipFree pairs and pageable copies were ~1.4 ms of a 2.6 ms call).  A call holds
-// the device's arena lock from start to finish, so concurrent calls on one device run one after the other.
-struct FdArena {
-  std::mutex mu;
-  char *dev = nullptr;
-  size_t dev_cap = 0;
-  char *host = nullptr;
-  size_t host_cap = 0;
-  int reserve(size_t dev_bytes, size_t host_bytes) {
-    if (dev_bytes > dev_cap) {
-      if (dev) (void)hipFree(dev);
-      dev = nullptr;
-      dev_cap = 0;
-      const size_t want = dev_bytes + dev_bytes / 4;
-      if (hipMalloc(reinterpret_cast<void **>(&dev), want) != hipSuccess) return fail(ANR_EHIP, "hipMalloc(%zu) failed", want);
-      dev_cap = want;
-    }
-    if (host_bytes > host_cap) {
-      if (host) (void)hipHostFree(host);
-      host = nullptr;
-      host_cap = 0;
-      const size_t want = host_bytes + host_bytes / 4;
-      if (hipHostMalloc(reinterpret_cast<void **>(&host), want, hipHostMallocDefault) != hipSuccess)
-        return fail(ANR_EHIP, "hipHostMalloc(%zu) failed", want);
-      host_cap = want;
-    }
-    return ANR_OK;
-  }
-};
-constexpr int kFdMaxDevices = 64;
-FdArena g_fd_arena[kFdMaxDevices];
-struct Carve {  // bump allocation inside a block (256-byte aligned pieces)
-  size_t off = 0;
-  size_t take(size_t bytes) {
-    const size_t at = off;
-    off += (bytes + 255) & ~(size_t)255;
-    return at;
-  }
-};
+FuseArena g_fd_arena[kFuseMaxDevices];
 void launch_scan(int method, unsigned grid, hipStream_t st, const FdParams &p, int64_t n_items) {
   // the prefetched source, as the kernel picks it
   const int s0 = method == 1 ? p.r1_src : (p.src[0].arr ? 0 : p.src[1].arr ? 1 : p.src[2].arr ? 2 : 3);
@@ -1228,7 +1189,7 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
       return fail(ANR_EINVAL, "query %lld: pool %d with %lld short-list entries and %d arrays exceeds the fused kernel's %d entries",
                   (long long)q, pool, (long long)m, n_arr, kFuseMax);
   }
-  if (device < 0 || device >= kFdMaxDevices) return fail(ANR_EINVAL, "device %d out of range", device);
+  if (device < 0 || device >= kFuseMaxDevices) return fail(ANR_EINVAL, "device %d out of range", device);
   DeviceGuard g(device);
   if (!g.ok) return fail(ANR_EHIP, "hipSetDevice(%d) failed", device);
   const int n_chunks = (int)ceil_div(U, kFsChunk);
@@ -1255,7 +1216,7 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
   const size_t out_bytes = (size_t)QB * ((size_t)pool * 48 + 4);
   const size_t d_out = dc.take(out_bytes);
   const size_t h_up = hc.take(n_ent * 16 + (size_t)nq * 5 * 8), h_out = hc.take(out_bytes);
-  FdArena &ar = g_fd_arena[device];
+  FuseArena &ar = g_fd_arena[device];
   std::lock_guard<std::mutex> lock(ar.mu);
   ANR_TRY(ar.reserve(dc.off, hc.off));
   char *D = ar.dev, *Hs = ar.host;

@@ -1,4 +1,5 @@
 #pragma once
+#include <mutex>
 // Device score fusion behind anr_fuse_lists (include/anorag.h): the arithmetic of the reference's
 // HybridSearcher.fuse (retrieval/hybrid_search.py:34-103) for a batch of queries, one workgroup per query,
 // everything LDS-resident.  All arithmetic is float64 in the reference's own order of operations, so the
@@ -92,36 +93,64 @@ __global__ __launch_bounds__(1024) void k_fuse(FuseParams p) {
     }
     __syncthreads();
   }
-  // 2) contribution of every entry
-  for (int e = tid; e < T; e += 1024) {
-    const int64_t g = base + e;
-    int s = 0;
-    while (s < 3 && g >= off[s + 1]) ++s;
-    const double sc = p.scores[g];
-    sh.key[e] = ((unsigned long long)p.ids[g] << 2) | (unsigned long long)s;
-    double c;
-    unsigned tie = INVALID;
-    if (s == 3) {
-      c = p.w[3] * sc;
-    } else if (p.method == 0) {
-      const double m = sh.smax[s];
-      c = p.w[s] * (m == 0.0 ? 0.0 : sc / m);
-    } else {
-      // rank = 1 + entries of this source ordered before e in a stable descending sort (:66-67)
-      int rank = (OVR && p.rank_ovr) ? p.rank_ovr[g] : 0;
-      if (rank == 0) {
-        rank = 1;
-        for (int64_t o = off[s]; o < off[s + 1]; ++o) {
-          const double so = p.scores[o];
-          rank += (so > sc || (so == sc && o < g)) ? 1 : 0;
+  // 2) contribution of every entry.  rrf ranks count inside the source's list: the raw scores are staged in LDS first
+  //    (the count loop read them from global memory) and read eight per round
+  constexpr int PER = (kFuseMax + 1023) / 1024;
+  if (p.method == 1) {
+    for (int e = tid; e < T; e += 1024) sh.val[e] = p.scores[base + e];
+    __syncthreads();
+  }
+  double c_mine[PER];
+  unsigned tie_mine[PER];
+  {
+    int k = 0;
+    for (int e = tid; e < T; e += 1024, ++k) {
+      const int64_t g = base + e;
+      int s = 0;
+      while (s < 3 && g >= off[s + 1]) ++s;
+      const double sc = p.scores[g];
+      sh.key[e] = ((unsigned long long)p.ids[g] << 2) | (unsigned long long)s;
+      double c;
+      unsigned tie = INVALID;
+      if (s == 3) {
+        c = p.w[3] * sc;
+      } else if (p.method == 0) {
+        const double m = sh.smax[s];
+        c = p.w[s] * (m == 0.0 ? 0.0 : sc / m);
+      } else {
+        // rank = 1 + entries of this source ordered before e in a stable descending sort (:66-67)
+        int rank = (OVR && p.rank_ovr) ? p.rank_ovr[g] : 0;
+        if (rank == 0) {
+          rank = 1;
+          const int o0 = (int)(off[s] - base), o1 = (int)(off[s + 1] - base);
+          int o = o0;
+          for (; o + 8 <= o1; o += 8) {  // eight independent LDS reads per round
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = sh.val[o + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) rank += (v[u] > sc || (v[u] == sc && o + u < e)) ? 1 : 0;
+          }
+          for (; o < o1; ++o) {
+            const double so = sh.val[o];
+            rank += (so > sc || (so == sc && o < e)) ? 1 : 0;
+          }
         }
+        c = p.w[s] / (p.rrf_k + (double)rank);
+        tie = ((unsigned)s << 28) | (unsigned)rank;
       }
-      c = p.w[s] / (p.rrf_k + (double)rank);
-      tie = ((unsigned)s << 28) | (unsigned)rank;
+      c_mine[k] = c;
+      tie_mine[k] = tie;
     }
-    sh.val[e] = c;
-    sh.tie[e] = tie;
-    sh.keep[e] = 0;
+  }
+  if (p.method == 1) __syncthreads();  // every rank loop has read the raw scores
+  {
+    int k = 0;
+    for (int e = tid; e < T; e += 1024, ++k) {
+      sh.val[e] = c_mine[k];
+      sh.tie[e] = tie_mine[k];
+      sh.keep[e] = 0;
+    }
   }
   int Tp = 1;
   while (Tp < T) Tp <<= 1;
@@ -227,5 +256,46 @@ __global__ __launch_bounds__(1024) void k_fuse(FuseParams p) {
     }
   }
 }
+
+// Work space of anr_fuse_dense / anr_fuse_lists: ONE device block and one pinned host block per device (each entry
+// point owns an array of these), grown on demand and kept for
+// the life of the process (25 hipMalloc/hipFree pairs and pageable copies were ~1.4 ms of a 2.6 ms call).  A call holds
+// the device's arena lock from start to finish, so concurrent calls on one device run one after the other.
+struct FuseArena {
+  std::mutex mu;
+  char *dev = nullptr;
+  size_t dev_cap = 0;
+  char *host = nullptr;
+  size_t host_cap = 0;
+  int reserve(size_t dev_bytes, size_t host_bytes) {
+    if (dev_bytes > dev_cap) {
+      if (dev) (void)hipFree(dev);
+      dev = nullptr;
+      dev_cap = 0;
+      const size_t want = dev_bytes + dev_bytes / 4;
+      if (hipMalloc(reinterpret_cast<void **>(&dev), want) != hipSuccess) return fail(ANR_EHIP, "hipMalloc(%zu) failed", want);
+      dev_cap = want;
+    }
+    if (host_bytes > host_cap) {
+      if (host) (void)hipHostFree(host);
+      host = nullptr;
+      host_cap = 0;
+      const size_t want = host_bytes + host_bytes / 4;
+      if (hipHostMalloc(reinterpret_cast<void **>(&host), want, hipHostMallocDefault) != hipSuccess)
+        return fail(ANR_EHIP, "hipHostMalloc(%zu) failed", want);
+      host_cap = want;
+    }
+    return ANR_OK;
+  }
+};
+constexpr int kFuseMaxDevices = 64;
+struct Carve {  // bump allocation inside a block (256-byte aligned pieces)
+  size_t off = 0;
+  size_t take(size_t bytes) {
+    const size_t at = off;
+    off += (bytes + 255) & ~(size_t)255;
+    return at;
+  }
+};
 
 }  // namespace anr

@@ -90,30 +90,24 @@ class HybridSearcher:
                 results[qi] = r
             return results
         all_ids: List[int] = []
-        all_sc: List[float] = []
+        all_sc: List[Any] = []
         offs = np.zeros((nq, 5), dtype=np.int64)
         id_maps: List[List[Any]] = []
         src_dicts: List[List[Dict[Any, float]]] = []
         for qi, lists in enumerate(queries):
             # sources as dicts: later duplicates overwrite, first position kept (hybrid_search.py:54-59)
-            dicts = [{nid: s for nid, s in (lst or [])} for lst in lists]
+            dicts = [dict(lst) if lst else {} for lst in lists]
             src_dicts.append(dicts)
             to_int: Dict[Any, int] = {}
-            names: List[Any] = []
+            intern = to_int.setdefault  # id -> dense integer, in order of first appearance
             for si, d in enumerate(dicts):
                 offs[qi, si] = len(all_ids)
-                for nid, s in d.items():
-                    k = to_int.get(nid)
-                    if k is None:
-                        k = len(names)
-                        to_int[nid] = k
-                        names.append(nid)
-                    all_ids.append(k)
-                    all_sc.append(float(s))
+                all_ids += [intern(nid, len(to_int)) for nid in d]
+                all_sc += d.values()
             offs[qi, 4] = len(all_ids)
-            id_maps.append(names)
-        ids = np.asarray(all_ids, dtype=np.int64)
-        sc = np.asarray(all_sc, dtype=np.float64)
+            id_maps.append(list(to_int))
+        ids = np.fromiter(all_ids, dtype=np.int64, count=len(all_ids))
+        sc = np.fromiter(all_sc, dtype=np.float64, count=len(all_sc))
         w = np.asarray([float(self.weights.get(k, 0.0)) for k in _SOURCES], dtype=np.float64)
         method = 1 if self.fusion_method == "rrf" else 0
         o_ids = np.empty((nq, pool), dtype=np.int64)
@@ -129,21 +123,21 @@ class HybridSearcher:
             "anr_fuse_lists",
         )
         results: List[List[Dict[str, Any]]] = []
+        ids_l, fin_l, cnt_l = o_ids.tolist(), o_fin.tolist(), o_cnt.tolist()
         for qi in range(nq):
             names = id_maps[qi]
-            dicts = src_dicts[qi]
+            d0, d1, d2, d3 = src_dicts[qi]
+            g0, g1, g2, g3 = d0.get, d1.get, d2.get, d3.get
+            fin_q = fin_l[qi]
             res = []
-            for j in range(int(o_cnt[qi])):
-                nid = names[int(o_ids[qi, j])]
+            for j, k in enumerate(ids_l[qi][:cnt_l[qi]]):
+                nid = names[k]
                 res.append({
                     "note_id": nid,
                     # the caller's own score objects (ints stay ints), None when absent (hybrid_search.py:74)
-                    "scores": {k: dicts[si].get(nid) for si, k in enumerate(_SOURCES)},
-                    "final_similarity": float(o_fin[qi, j]),
-                    "tags": {
-                        "source": "graph" if nid in dicts[2] else "semantic",
-                        "is_bridge": nid in dicts[3],
-                    },
+                    "scores": {"dense": g0(nid), "bm25": g1(nid), "graph": g2(nid), "path": g3(nid)},
+                    "final_similarity": fin_q[j],
+                    "tags": {"source": "graph" if nid in d2 else "semantic", "is_bridge": nid in d3},
                 })
             results.append(res)
         return results
