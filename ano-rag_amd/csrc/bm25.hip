@@ -168,6 +168,12 @@ struct anr_bm25 {
   double *weights = nullptr;
   hipStream_t stream = nullptr;
   std::mutex mu;
+  // per-handle work space, grown on demand and kept (three hipMalloc / hipFree pairs per call were most of a
+  // single-query bm25_scores): query offsets + terms, and the score rows of the host-output entry points
+  char *q_buf = nullptr;
+  int64_t q_cap = 0;
+  double *score_buf = nullptr;
+  int64_t score_cap = 0;
 };
 
 namespace {
@@ -194,37 +200,43 @@ int validate_queries(const anr_bm25 *h, int64_t nq, const int64_t *q_indptr, con
   return ANR_OK;
 }
 
-// runs the scoring of one chunk of queries into a fresh device buffer (caller frees *d_scores) or, when `into` is
-// given, into that caller-owned device buffer
+// runs the scoring of one chunk of queries into the handle's score buffer (*d_scores points into it: valid until the
+// next call on the handle) or, when `into` is given, into that caller-owned device buffer
 int score_chunk(anr_bm25 *h, int64_t nq, const int64_t *q_indptr, const int32_t *q_terms, int normalize,
                 double **d_scores, double *into = nullptr, double *max_into = nullptr) {
-  int64_t *dq = nullptr;
-  int32_t *dt = nullptr;
   const int64_t nt = q_indptr[nq] - q_indptr[0];
   std::vector<int64_t> rel(nq + 1);
   for (int64_t i = 0; i <= nq; ++i) rel[i] = q_indptr[i] - q_indptr[0];
-  ANR_TRY(b_alloc(&dq, nq + 1));
-  int rc = b_alloc(&dt, nt);
-  if (rc == ANR_OK) {
-    if (into) *d_scores = into;
-    else rc = b_alloc(d_scores, nq * h->n_docs);
+  const int64_t q_bytes = (nq + 1) * 8 + (nt > 0 ? nt : 1) * 4;
+  if (q_bytes > h->q_cap) {
+    b_free(h->q_buf);
+    h->q_cap = 0;
+    ANR_TRY(b_alloc(&h->q_buf, q_bytes + q_bytes / 2));
+    h->q_cap = q_bytes + q_bytes / 2;
   }
-  hipError_t e = hipSuccess;
-  if (rc == ANR_OK) {
-    e = hipMemcpyAsync(dq, rel.data(), (size_t)(nq + 1) * 8, hipMemcpyHostToDevice, h->stream);
-    if (e == hipSuccess && nt > 0)
-      e = hipMemcpyAsync(dt, q_terms + q_indptr[0], (size_t)nt * 4, hipMemcpyHostToDevice, h->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(*d_scores, 0, (size_t)nq * h->n_docs * 8, h->stream);
-    if (e == hipSuccess) {
-      Bm25Params p{h->indptr, h->docs, h->weights, h->n_docs, dq, dt, *d_scores, normalize, max_into};
-      hipLaunchKernelGGL(k_bm25, dim3((unsigned)nq), dim3(1024), 0, h->stream, p);
-      e = hipGetLastError();
+  int64_t *dq = reinterpret_cast<int64_t *>(h->q_buf);
+  int32_t *dt = reinterpret_cast<int32_t *>(h->q_buf + (nq + 1) * 8);
+  if (into) {
+    *d_scores = into;
+  } else {
+    if (nq * h->n_docs > h->score_cap) {
+      b_free(h->score_buf);
+      h->score_cap = 0;
+      ANR_TRY(b_alloc(&h->score_buf, nq * h->n_docs));
+      h->score_cap = nq * h->n_docs;
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    *d_scores = h->score_buf;
   }
-  b_free(dq);
-  b_free(dt);
-  if (rc != ANR_OK) return rc;
+  hipError_t e = hipMemcpyAsync(dq, rel.data(), (size_t)(nq + 1) * 8, hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess && nt > 0)
+    e = hipMemcpyAsync(dt, q_terms + q_indptr[0], (size_t)nt * 4, hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(*d_scores, 0, (size_t)nq * h->n_docs * 8, h->stream);
+  if (e == hipSuccess) {
+    Bm25Params p{h->indptr, h->docs, h->weights, h->n_docs, dq, dt, *d_scores, normalize, max_into};
+    hipLaunchKernelGGL(k_bm25, dim3((unsigned)nq), dim3(1024), 0, h->stream, p);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);  // (also: `rel` may go out of scope)
   if (e != hipSuccess) return fail(ANR_EHIP, "bm25 scoring failed: %s", hipGetErrorString(e));
   return ANR_OK;
 }
@@ -279,6 +291,8 @@ int anr_bm25_destroy(anr_bm25 *h) {
   b_free(h->indptr);
   b_free(h->docs);
   b_free(h->weights);
+  b_free(h->q_buf);
+  b_free(h->score_buf);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return ANR_OK;
@@ -300,7 +314,6 @@ int anr_bm25_scores(anr_bm25 *h, int64_t nq, const int64_t *q_indptr, const int3
       hipError_t e = hipMemcpy(out_host + q0 * h->n_docs, d, (size_t)m * h->n_docs * 8, hipMemcpyDeviceToHost);
       if (e != hipSuccess) rc = fail(ANR_EHIP, "download failed: %s", hipGetErrorString(e));
     }
-    b_free(d);
     if (rc != ANR_OK) return rc;
   }
   return ANR_OK;
@@ -372,8 +385,7 @@ int anr_bm25_nonzero(anr_bm25 *h, int64_t nq, const int64_t *q_indptr, const int
       if (e == hipSuccess) e = hipMemcpy(out_count + q0, dcnt, (size_t)m * 4, hipMemcpyDeviceToHost);
       if (e != hipSuccess) rc = fail(ANR_EHIP, "bm25 nonzero failed: %s", hipGetErrorString(e));
     }
-    b_free(d);
-    b_free(ddoc);
+    b_free(ddoc);  // (d points into the handle's score buffer)
     b_free(dsc);
     b_free(dcnt);
     if (rc != ANR_OK) return rc;
