@@ -529,11 +529,10 @@ __global__ __launch_bounds__(256) void k_gemm(GemmParams p) {
 // weight block straight from global memory (deep unroll, no LDS on the operand path), and the four partial
 // accumulators meet in LDS: N/32 x ceil(TB/2) workgroups, K/64 MFMA steps each.
 template <int EPI>
-__global__ __launch_bounds__(256) void k_gemm_skinny(GemmParams p) {
-  __shared__ float red[4][2][64][17];  // [wave][token block][lane][16 (+1: bank spread)]
+__device__ __forceinline__ void gemm_skinny_body(const GemmParams &p, const int block, float (&red)[4][2][64][17]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nb = blockIdx.x % p.NB;
-  const int64_t tb0 = (int64_t)(blockIdx.x / p.NB) * 2;
+  const int nb = block % p.NB;
+  const int64_t tb0 = (int64_t)(block / p.NB) * 2;
   const bool two = tb0 + 1 < p.TB;
   const int kq = p.KB / 4, k0 = wave * kq;
   const uint4 *wp = p.w + ((int64_t)nb * p.KB + k0) * 64 + lane;
@@ -584,6 +583,21 @@ __global__ __launch_bounds__(256) void k_gemm_skinny(GemmParams p) {
       c[r] = (red[0][wave][lane][r] + red[1][wave][lane][r]) + (red[2][wave][lane][r] + red[3][wave][lane][r]);
     gemm_store_tile<EPI>(p, c, tb0 + wave, nb, lane);
   }
+}
+
+
+template <int EPI>
+__global__ __launch_bounds__(256) void k_gemm_skinny(GemmParams p) {
+  __shared__ float red[4][2][64][17];  // [wave][token block][lane][16 (+1: bank spread)]
+  gemm_skinny_body<EPI>(p, (int)blockIdx.x, red);
+}
+
+// the Q/K projection and the V projection of a layer in ONE launch (small inputs are a chain of ~100 dependent launches of
+// 4-6 us: one fewer per layer); blocks [0, n_qk) run the first problem, the rest the second — same arithmetic per block
+__global__ __launch_bounds__(256) void k_gemm_skinny_qkv(GemmParams pq, GemmParams pv, int n_qk) {
+  __shared__ float red[4][2][64][17];
+  if ((int)blockIdx.x < n_qk) gemm_skinny_body<EPI_ACT>(pq, (int)blockIdx.x, red);
+  else gemm_skinny_body<EPI_VT>(pv, (int)blockIdx.x - n_qk, red);
 }
 
 // LDS-staged GEMM: a workgroup (4 waves, 2 x 2) owns 128 tokens x 256 features; per stage of two k-steps the
@@ -1186,6 +1200,16 @@ void launch_gemm8(anr_encoder *e, GemmParams &g, int64_t blocks) {
   }
 }
 
+// small inputs: one workgroup per (feature block, two token blocks), K split over its four waves
+bool use_skinny(const GemmParams &g) {
+  static const bool simple = getenv("ANORAG_GEMM_SIMPLE") != nullptr;
+  static const bool no_skinny = getenv("ANORAG_GEMM_NOSKINNY") != nullptr;  // developer switches
+  // measured crossover with the tile kernels at the bge-base shape (tools/enc_perf.py): 3072 tokens 1.80 ms skinny vs
+  // 2.25 tiled, 4096 tokens 2.16 vs 2.07
+  static const int skinny_max = getenv("ANORAG_SKINNY_MAX") ? atoi(getenv("ANORAG_SKINNY_MAX")) : 120;
+  return !simple && g.KB % ANR_GEMM_S == 0 && !no_skinny && g.TB <= skinny_max && g.KB % 4 == 0;
+}
+
 template <int EPI>
 void launch_gemm(anr_encoder *e, GemmParams &g) {
   static const bool simple = getenv("ANORAG_GEMM_SIMPLE") != nullptr;  // developer switch: the LDS-free kernel
@@ -1195,11 +1219,7 @@ void launch_gemm(anr_encoder *e, GemmParams &g) {
     hipLaunchKernelGGL((k_gemm<MT, NT, EPI>), dim3((unsigned)ceil_div(waves, 4)), dim3(256), 0, e->stream, g);
     return;
   }
-  static const bool no_skinny = getenv("ANORAG_GEMM_NOSKINNY") != nullptr;  // developer switch
-  // measured crossover with the tile kernels at the bge-base shape (tools/enc_perf.py): 3072 tokens 1.80 ms skinny vs
-  // 2.25 tiled, 4096 tokens 2.16 vs 2.07
-  static const int skinny_max = getenv("ANORAG_SKINNY_MAX") ? atoi(getenv("ANORAG_SKINNY_MAX")) : 120;
-  if (!no_skinny && g.TB <= skinny_max && g.KB % 4 == 0) {
+  if (use_skinny(g)) {
     const int64_t blocks = (int64_t)g.NB * ceil_div(g.TB, 2);
     hipLaunchKernelGGL((k_gemm_skinny<EPI>), dim3((unsigned)blocks), dim3(256), 0, e->stream, g);
     return;
@@ -1405,11 +1425,16 @@ void enqueue_forward(anr_encoder *e, int B, int L, int Lp, bool use_types, int n
     GemmParams gq{};
     gq.act = reinterpret_cast<const uint4 *>(e->act); gq.w = reinterpret_cast<const uint4 *>(l.wqk);
     gq.TB = TB; gq.NB = 2 * H / 32; gq.KB = KB; gq.bias_acc = l.bqk; gq.out = e->qk;
-    launch_gemm<EPI_ACT>(e, gq);
     GemmParams gv{};
     gv.act = reinterpret_cast<const uint4 *>(e->act); gv.w = reinterpret_cast<const uint4 *>(l.wv);
     gv.TB = TB; gv.NB = H / 32; gv.KB = KB; gv.bias = l.bv; gv.out = e->vt;
-    launch_gemm<EPI_VT>(e, gv);
+    if (use_skinny(gq) && use_skinny(gv)) {  // small inputs: both projections in one launch
+      const int n_qk = (int)((int64_t)gq.NB * ceil_div(gq.TB, 2)), n_v = (int)((int64_t)gv.NB * ceil_div(gv.TB, 2));
+      hipLaunchKernelGGL(k_gemm_skinny_qkv, dim3((unsigned)(n_qk + n_v)), dim3(256), 0, st, gq, gv, n_qk);
+    } else {
+      launch_gemm<EPI_ACT>(e, gq);
+      launch_gemm<EPI_VT>(e, gv);
+    }
     AttnParams ap{};
     ap.qk = reinterpret_cast<const uint4 *>(e->qk); ap.vt = reinterpret_cast<const uint4 *>(e->vt);
     ap.lens = e->d_lens; ap.B = B; ap.Lp = Lp; ap.H = H; ap.heads = c.n_heads; ap.dh = dh;
