@@ -162,19 +162,28 @@ extern "C" int anr_fuse_candidates(int32_t device, int32_t mode, int64_t nq, con
   if (mode == 2 && !mult_host) return fail(ANR_EINVAL, "mode 2 needs the multiplier array");
   DeviceGuard g(device);
   if (!g.ok) return fail(ANR_EHIP, "hipSetDevice(%d) failed", device);
-  // one allocation: offs | a | b | mult | score | flags | n_ent | n_pred | order
+  if (device < 0 || device >= kFuseMaxDevices) return fail(ANR_EINVAL, "device %d out of range", device);
+  // inputs [offs | a | b | mult | flags | n_ent | n_pred] then outputs [score | order], the same layout in one pinned
+  // host block and one device block kept per device: one upload, one download (it was a hipMalloc / hipFree pair, up
+  // to seven synchronous pageable uploads and two downloads per call — for ~100 candidates of one query)
   const size_t o_offs = 0, o_a = round_up((nq + 1) * 8, 16), o_b = o_a + total * 8, o_m = o_b + total * 8;
-  const size_t o_s = o_m + (mode == 2 ? total * 32 : 0), o_f = o_s + total * 8, o_e = o_f + total * 4;
-  const size_t o_p = o_e + total * 4, o_o = o_p + total * 4, bytes = o_o + total * 4;
-  unsigned char *d = nullptr;
-  ANR_HIP(hipMalloc(reinterpret_cast<void **>(&d), bytes));
-  hipError_t e = hipMemcpy(d + o_offs, offs_host, (nq + 1) * 8, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(d + o_a, a_host, total * 8, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(d + o_b, b_host, total * 8, hipMemcpyHostToDevice);
-  if (e == hipSuccess && mode == 2) e = hipMemcpy(d + o_m, mult_host, total * 32, hipMemcpyHostToDevice);
-  if (e == hipSuccess && flags_host) e = hipMemcpy(d + o_f, flags_host, total * 4, hipMemcpyHostToDevice);
-  if (e == hipSuccess && n_ent_host) e = hipMemcpy(d + o_e, n_ent_host, total * 4, hipMemcpyHostToDevice);
-  if (e == hipSuccess && n_pred_host) e = hipMemcpy(d + o_p, n_pred_host, total * 4, hipMemcpyHostToDevice);
+  const size_t o_f = o_m + (mode == 2 ? total * 32 : 0), o_e = o_f + total * 4, o_p = o_e + total * 4;
+  const size_t in_bytes = round_up((int64_t)(o_p + total * 4), 16);
+  const size_t o_s = in_bytes, o_o = o_s + total * 8, bytes = o_o + total * 4;
+  static FuseArena arenas[kFuseMaxDevices];
+  FuseArena &ar = arenas[device];
+  std::lock_guard<std::mutex> lock(ar.mu);
+  ANR_TRY(ar.reserve(bytes, bytes));
+  unsigned char *d = reinterpret_cast<unsigned char *>(ar.dev), *hp = reinterpret_cast<unsigned char *>(ar.host);
+  std::memcpy(hp + o_offs, offs_host, (nq + 1) * 8);
+  std::memcpy(hp + o_a, a_host, total * 8);
+  std::memcpy(hp + o_b, b_host, total * 8);
+  if (mode == 2) std::memcpy(hp + o_m, mult_host, total * 32);
+  if (flags_host) std::memcpy(hp + o_f, flags_host, total * 4);
+  if (n_ent_host) std::memcpy(hp + o_e, n_ent_host, total * 4);
+  if (n_pred_host) std::memcpy(hp + o_p, n_pred_host, total * 4);
+  hipStream_t st = nullptr;
+  hipError_t e = hipMemcpyAsync(d, hp, in_bytes, hipMemcpyHostToDevice, st);
   if (e == hipSuccess) {
     CandParams p{};
     p.mode = mode;
@@ -188,12 +197,15 @@ extern "C" int anr_fuse_candidates(int32_t device, int32_t mode, int64_t nq, con
     p.wa = wa; p.wb = wb; p.rrf_k = rrf_k; p.noise = noise;
     p.score = reinterpret_cast<double *>(d + o_s);
     p.order = reinterpret_cast<int32_t *>(d + o_o);
-    hipLaunchKernelGGL(k_fuse_candidates, dim3((unsigned)nq), dim3(256), 0, 0, p);
+    hipLaunchKernelGGL(k_fuse_candidates, dim3((unsigned)nq), dim3(256), 0, st, p);
     e = hipGetLastError();
   }
-  if (e == hipSuccess) e = hipMemcpy(score_host, d + o_s, total * 8, hipMemcpyDeviceToHost);
-  if (e == hipSuccess) e = hipMemcpy(order_host, d + o_o, total * 4, hipMemcpyDeviceToHost);
-  (void)hipFree(d);
+  if (e == hipSuccess) e = hipMemcpyAsync(hp + o_s, d + o_s, total * 12, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e == hipSuccess) {
+    std::memcpy(score_host, hp + o_s, total * 8);
+    std::memcpy(order_host, hp + o_o, total * 4);
+  }
   if (e != hipSuccess) return fail(ANR_EHIP, "candidate fusion failed: %s", hipGetErrorString(e));
   return ANR_OK;
 }
