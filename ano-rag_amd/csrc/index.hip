@@ -108,6 +108,8 @@ struct anr_index {
   int fused_post = 1;                             // ANR_OPT_FUSED_POST
   int tiny = 1;                                   // ANR_OPT_TINY
   unsigned char *tiny_pin = nullptr, *tiny_pin_dev = nullptr;  // pinned: queries | D | I | completion words
+  unsigned char *sr_buf = nullptr;                // anr_index_score_rows scratch
+  int64_t sr_cap = 0;
   unsigned long long *tiny_cand = nullptr;        // [kTinyMaxQ][kTinyMaxWG][kTinyMaxK]
   unsigned *tiny_ticket = nullptr;                // [kTinyMaxQ]
   unsigned tiny_seq = 0;
@@ -1154,6 +1156,7 @@ int anr_index_destroy(anr_index *h) {
   if (h->out_pin) (void)hipHostFree(h->out_pin);
   if (h->tiny_pin) (void)hipHostFree(h->tiny_pin);
   dev_free(h->tiny_cand);
+  dev_free(h->sr_buf);
   dev_free(h->tiny_ticket);
   dev_free(h->tiny_stamps);
   for (auto &e : h->ev_call)
@@ -1302,27 +1305,28 @@ int anr_index_score_rows(anr_index *h, const float *q_host, int64_t nq, const in
   if (!g.ok) return fail(ANR_EHIP, "hipSetDevice(%d) failed", h->device);
   std::lock_guard<std::mutex> lk(h->mu);
   ANR_TRY(drain(h));
-  float *dq = nullptr, *dout = nullptr, *dqn = nullptr;
-  int64_t *dids = nullptr;
-  _Float16 *dq16 = nullptr;
-  float *dqs = nullptr;
-  int rc = ANR_OK;
-  auto cleanup = [&]() {
-    dev_free(dq); dev_free(dout); dev_free(dqn); dev_free(dids); dev_free(dq16); dev_free(dqs);
-  };
-  // queries go through the same preprocessing as searches (normalisation for cosine) in blocks of 64
-  if ((rc = dev_alloc(&dq, nq * h->dim, false)) || (rc = dev_alloc(&dout, total, false)) ||
-      (rc = dev_alloc(&dids, total, false)) || (rc = dev_alloc(&dqn, (int64_t)round_up(nq, kQB) * h->dim, false)) ||
-      (rc = dev_alloc(&dq16, (int64_t)kQB * h->dimp, false)) || (rc = dev_alloc(&dqs, kQB * 4, false))) {
-    cleanup();
-    return rc;
+  // one scratch block per handle, grown on demand and kept (seven hipMalloc / hipFree pairs per call were most of the
+  // time of a ~100-candidate call); queries go through the same preprocessing as searches, in blocks of 64
+  auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const size_t b_q = al((size_t)nq * h->dim * 4), b_out = al((size_t)total * 4), b_ids = al((size_t)total * 8),
+               b_qn = al((size_t)round_up(nq, kQB) * h->dim * 4), b_q16 = al((size_t)kQB * h->dimp * 2),
+               b_qs = al((size_t)kQB * 4 * 4), b_q32 = al((size_t)kQB * h->dimp * 4);
+  const size_t need = b_q + b_out + b_ids + b_qn + b_q16 + b_qs + b_q32;
+  if ((int64_t)need > h->sr_cap) {
+    dev_free(h->sr_buf);
+    h->sr_cap = 0;
+    ANR_TRY(dev_alloc(&h->sr_buf, (int64_t)(need + need / 2), false));
+    h->sr_cap = (int64_t)(need + need / 2);
   }
+  unsigned char *base = h->sr_buf;
+  float *dq = reinterpret_cast<float *>(base);
+  float *dout = reinterpret_cast<float *>(base + b_q);
+  int64_t *dids = reinterpret_cast<int64_t *>(base + b_q + b_out);
+  float *dqn = reinterpret_cast<float *>(base + b_q + b_out + b_ids);
+  _Float16 *dq16 = reinterpret_cast<_Float16 *>(base + b_q + b_out + b_ids + b_qn);
+  float *dqs = reinterpret_cast<float *>(base + b_q + b_out + b_ids + b_qn + b_q16);
+  float *dq32 = reinterpret_cast<float *>(base + b_q + b_out + b_ids + b_qn + b_q16 + b_qs);
   hipStream_t st = h->stream;
-  float *dq32 = nullptr;
-  if ((rc = dev_alloc(&dq32, (int64_t)kQB * h->dimp, false))) {
-    cleanup();
-    return rc;
-  }
   hipError_t e = hipMemcpyAsync(dq, q_host, (size_t)nq * h->dim * sizeof(float), hipMemcpyHostToDevice, st);
   if (e == hipSuccess) e = hipMemcpyAsync(dids, ids_host, (size_t)total * sizeof(int64_t), hipMemcpyHostToDevice, st);
   for (int64_t q0 = 0; q0 < nq && e == hipSuccess; q0 += kQB) {
@@ -1349,8 +1353,6 @@ int anr_index_score_rows(anr_index *h, const float *q_host, int64_t nq, const in
   }
   if (e == hipSuccess) e = hipMemcpyAsync(out_host, dout, (size_t)total * sizeof(float), hipMemcpyDeviceToHost, st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
-  dev_free(dq32);
-  cleanup();
   if (e != hipSuccess) return fail(ANR_EHIP, "score_rows failed: %s", hipGetErrorString(e));
   return ANR_OK;
 }
