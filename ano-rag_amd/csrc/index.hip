@@ -600,6 +600,9 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
   if (sample_tiles < 2 * M) sample_tiles = 2 * M;  // tile maxima: the M-th largest is backed by M distinct rows
   const bool sparse = full_tiles >= 8 * sample_tiles;
   w.sparse = sparse;
+  // k_post runs ONE workgroup per query: a batch of a few queries leaves its select and re-score to a handful of CUs
+  // (batch 1, k = 100, 20 k x 768: 92 us fused vs 84 us as three grid-wide launches); from 5 queries up it wins
+  const bool fused_post = h->fused_post == 1 ? nq > 4 : h->fused_post != 0;
   const int side_grid = h->n_cu;
   // (Leaving 8-32 CUs out of the main scan's persistent grid so that the next batch's side kernels run beside it was
   // tried at the 1.25 M-row shard size: wall 0.347 -> 0.345-0.350 ms, and -2 % at 10 M rows.  The scan's 12-wave
@@ -636,7 +639,7 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
     sp.n = h->ntotal;
     sp.row0 = 0;
     sp.row_tile_stride = 1;
-    if (!h->fused_post) ANR_TRY(launch_select(nq, sp, bs));
+    if (!fused_post) ANR_TRY(launch_select(nq, sp, bs));
   } else {
     ANR_TRY(ensure_dense(w, sample_tiles * kTileRows));
     ANR_TRY(ensure_cand(h, w));
@@ -694,10 +697,10 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
     sp.capb = (unsigned)h->cand_cap;
     sp.overflow = w.ncand + kQB;
     sp.ncand = w.ncand;
-    if (!h->fused_post) ANR_TRY(launch_select(nq, sp, bs));
+    if (!fused_post) ANR_TRY(launch_select(nq, sp, bs));
   }
 
-  if (h->fused_post) {
+  if (fused_post) {
     // select + exact re-score + finalize in one launch per batch (k_post)
     PostParams pp{};
     pp.x32 = h->x32;
@@ -1472,7 +1475,7 @@ int anr_index_set_option(anr_index *h, int32_t opt, int64_t value) {
       h->id_offset = value;
       break;
     case ANR_OPT_TINY: h->tiny = value < 0 ? 0 : (value > 2 ? 2 : (int)value); break;
-    case ANR_OPT_FUSED_POST: h->fused_post = value != 0; break;
+    case ANR_OPT_FUSED_POST: h->fused_post = value < 0 ? 0 : (value > 2 ? 2 : (int)value); break;
     case ANR_OPT_STREAMS:
       if (value < 1 || value > kWorkspaces) return fail(ANR_EINVAL, "streams must be in 1..%d", kWorkspaces);
       h->n_streams = (int)value;

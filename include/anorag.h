@@ -124,8 +124,9 @@ int anr_index_self_join(anr_index *h, float threshold, int64_t cap, int64_t *I_h
                                      pipeline: k <= 64 and a short slice of rows per workgroup (e.g. k = 10 up to ~120 k x 768);
                                      2: wherever the path is structurally able (k <= 128, <= 1024 rows per workgroup; for tests);
                                      0: never.  Identical results either way */
-#define ANR_OPT_FUSED_POST 10     /* 1 (default): candidate select + exact re-score + finalize run as ONE kernel per batch; 0: the
-                                     three separate launches (developer A/B switch, identical results) */
+#define ANR_OPT_FUSED_POST 10     /* 1 (default): candidate select + exact re-score + finalize run as ONE kernel per batch of more than
+                                     4 queries (one workgroup per query); 2: for every batch; 0: always the three separate
+                                     launches (identical results) */
 int anr_index_set_option(anr_index *h, int32_t opt, int64_t value);
 
 typedef struct anr_search_stats {

@@ -560,10 +560,11 @@ def test_fused_post_kernel_equals_the_three_launch_pipeline():
     cl = (cent[rng.integers(0, 200, 120_000)] + 0.02 * rng.standard_normal((120_000, 256))).astype(np.float32)
     clq = (cent[rng.integers(0, 200, 64)] + 0.02 * rng.standard_normal((64, 256))).astype(np.float32)
     cases = [(_data(150_000, 768, 64), METRIC_IP, True, 100), (_data(3_000, 384, 17), METRIC_IP, True, 10),
-             (_data(90_000, 130, 33), METRIC_L2, False, 50), ((cl, clq), METRIC_IP, True, 50)]
+             (_data(90_000, 130, 33), METRIC_L2, False, 50), (_data(40_000, 768, 3), METRIC_IP, True, 20),
+             ((cl, clq), METRIC_IP, True, 50)]
     for (x, q), metric, norm, k in cases:
         res = []
-        for fused in (1, 0):
+        for fused in (2, 0):   # 2 = k_post for every batch (the default, 1, leaves batches of <= 4 queries to the launches)
             idx = FlatIndex(x.shape[1], metric, normalize=norm)
             idx.set_option(OPT_TINY, 0)
             idx.set_option(OPT_FUSED_POST, fused)
