@@ -142,6 +142,8 @@ SIGNATURES = {
         [C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
          C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p],
     ),
+    "anr_fuse_rrf_long": (C.c_int, [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                    C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "anr_bm25_scores_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                       C.c_void_p]),
     "anr_bm25_combine_fields": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32,

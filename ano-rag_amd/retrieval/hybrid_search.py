@@ -154,9 +154,7 @@ class HybridSearcher:
         arrays = [order[0]]
         if rrf:
             if sum(lens) - lens[arrays[0]] > _SHORT_MAX:
-                raise _lib.AnoragError(
-                    f"rrf fusion handles one long source per query (here {lens}); the others may hold {_SHORT_MAX} "
-                    "entries in all")
+                return self._fuse_rrf_long(dicts, pool)  # two or three long lists: every one ranked by a device sort
         else:
             for s in order[1:]:
                 if sum(lens[t] for t in range(4) if t not in arrays) <= _SHORT_MAX:
@@ -201,6 +199,44 @@ class HybridSearcher:
                 "final_similarity": float(o_fin[0, j]),
                 "tags": {"source": "graph" if nid in dicts[2] else "semantic", "is_bridge": nid in dicts[3]},
             })
+        return res
+
+    def _fuse_rrf_long(self, dicts, pool: int) -> List[Dict[str, Any]]:
+        """rrf over lists of any length (``anr_fuse_rrf_long``): each ranked list is sorted on the device in its own
+        order — the general form; one long list takes the streaming path above, short lists the LDS kernel"""
+        to_int: Dict[Any, int] = {}
+        intern = to_int.setdefault
+        all_ids: List[int] = []
+        all_sc: List[Any] = []
+        offs = np.zeros((1, 5), dtype=np.int64)
+        for si, d in enumerate(dicts):
+            offs[0, si] = len(all_ids)
+            all_ids += [intern(nid, len(to_int)) for nid in d]
+            all_sc += d.values()
+        offs[0, 4] = len(all_ids)
+        names = list(to_int)
+        if not names:
+            return []
+        ids = np.fromiter(all_ids, dtype=np.int64, count=len(all_ids))
+        sc = np.fromiter(all_sc, dtype=np.float64, count=len(all_sc))
+        w = np.asarray([float(self.weights.get(k, 0.0)) for k in _SOURCES], dtype=np.float64)
+        o_ids = np.empty((1, pool), dtype=np.int64)
+        o_fin = np.empty((1, pool), dtype=np.float64)
+        o_src = np.empty((1, pool, 4), dtype=np.float64)
+        o_cnt = np.empty((1,), dtype=np.int32)
+        _lib.check(_lib.load().anr_fuse_rrf_long(self.device, 1, ids.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p),
+                                                 offs.ctypes.data_as(C.c_void_p), len(names), w.ctypes.data_as(C.c_void_p),
+                                                 float(self.rrf_k), pool, o_ids.ctypes.data_as(C.c_void_p),
+                                                 o_fin.ctypes.data_as(C.c_void_p), o_src.ctypes.data_as(C.c_void_p),
+                                                 o_cnt.ctypes.data_as(C.c_void_p)), "anr_fuse_rrf_long")
+        d0, d1, d2, d3 = dicts
+        res = []
+        for j in range(int(o_cnt[0])):
+            nid = names[int(o_ids[0, j])]
+            res.append({"note_id": nid,
+                        "scores": {"dense": d0.get(nid), "bm25": d1.get(nid), "graph": d2.get(nid), "path": d3.get(nid)},
+                        "final_similarity": float(o_fin[0, j]),
+                        "tags": {"source": "graph" if nid in d2 else "semantic", "is_bridge": nid in d3}})
         return res
 
     def fuse_arrays(self, nq: int, dense=None, bm25=None, graph=None, path=None, note_ids: Sequence[Any] | None = None,

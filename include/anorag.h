@@ -213,6 +213,18 @@ int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const anr_fuse_so
                    const double *weights /*[4]*/, double rrf_k, int32_t pool, int64_t *out_ids, double *out_final,
                    double *out_src, int32_t *out_count, anr_fuse_dense_stats *stats /* may be NULL */);
 
+/* Weighted RRF over lists of ANY length (HybridSearcher.fuse, method rrf, when two or three lists are longer than
+ * anr_fuse_lists holds — e.g. a dense score and a bm25 score for every note; retrieval/hybrid_search.py:60-72 ranks each
+ * list by a stable descending sort).  Inputs as anr_fuse_lists (same offs layout, ids unique inside a list) with ids in
+ * [0, n).  Each ranked list is sorted on the device in its own order (stable radix sort: equal scores keep their list
+ * positions), the finals of all n ids are formed in the reference's order of operations and ordered by (final descending,
+ * the reference's ranks-dict insertion order); ids held by no dense / bm25 / graph list are dropped.  Outputs as
+ * anr_fuse_lists.  A correctness path (a handful of n-wide sorts per query): with ONE long list use anr_fuse_dense, which
+ * counts the ranks it needs in a single streaming pass. */
+int anr_fuse_rrf_long(int32_t device, int64_t nq, const int64_t *ids_host, const double *scores_host, const int64_t *offs_host,
+                      int64_t n, const double *weights /*[4]*/, double rrf_k, int32_t pool, int64_t *out_ids,
+                      double *out_final, double *out_src, int32_t *out_count);
+
 /* Candidate-level fusion of QueryProcessor (opt-in, the reference's own call path re-encodes
  * candidates instead): the scoring loops of _hybrid_search (query/query_processor.py:3703-3760) and of
  * _enhanced_hybrid_search_v2 (:1104-1143) for nq queries at once, candidates of query q = entries [offs[q], offs[q+1]).

@@ -8,6 +8,7 @@ Imports, by file path, the two reference files of the hot path that are importab
 stub, the same sys.modules technique the reference's own tests use for GPUtil).  Writes
   tests/golden/fusion_cases.json   inputs + the reference's HybridSearcher.fuse output
   tests/golden/bm25_cases.json     notes + queries + the reference's bm25_scores output (SimpleBM25 variant)
+  tests/golden/fusion_rrf_multi_long_cases.json   rrf with two or three FULL-corpus lists
   tests/golden/fusion_long_cases.json   HybridSearcher.fuse where bm25 (and, in some cases, dense) is a FULL-corpus
       list — one (id, score) entry per note, what zipping the note ids with bm25_scores() gives — with integer note
       ids; the long lists are stored sparsely (non-zero entries + the value every other entry has)
@@ -179,6 +180,50 @@ def fusion_long_cases(hs):
     n = 6_000
     add("linear_two_full_vectors", "linear", n, sparse_vec(n, 0.01), None, pairs(n, 12), pairs(n, 4),
         dense_vec=rng.uniform(-0.2, 0.9, n), pool=80)
+    return cases
+
+
+def fusion_rrf_multi_long_cases(hs):
+    """rrf where TWO or THREE sources are full-corpus lists (a dense score and a bm25 score for EVERY note): the
+    reference ranks each list by a stable descending sort, so every note has a rank in each of them"""
+    import numpy as np
+    rng = np.random.default_rng(20261007)
+    cases = []
+
+    def run(name, n, vecs, short, weights, pool, rrf_k=60):
+        cfg = {"retrieval": {"candidate_pool": pool,
+                             "hybrid": {"enabled": True, "fusion_method": "rrf", "weights": weights, "rrf_k": rrf_k}}}
+        searcher = hs.HybridSearcher(cfg)
+        lists = {}
+        for k in ("dense", "bm25", "graph", "path"):
+            if k in vecs:
+                lists[k] = [(i, float(vecs[k][i])) for i in range(n)]
+            else:
+                lists[k] = [tuple(x) for x in short.get(k, [])]
+        out = searcher.fuse(dense=lists["dense"], bm25=lists["bm25"], graph=lists["graph"], path=lists["path"])
+        cases.append({"name": name, "config": cfg, "n": int(n),
+                      "vectors": {k: [float(x) for x in v] for k, v in vecs.items()},
+                      "short": {k: [[int(i), float(sc)] for i, sc in v] for k, v in short.items()}, "expected": out})
+
+    def pairs(n_total, m):
+        ids = rng.choice(n_total, size=m, replace=False)
+        sc = np.sort(rng.uniform(0, 1, m))[::-1]
+        return [[int(i), float(x)] for i, x in zip(ids, sc)]
+
+    w = {"dense": 1.0, "bm25": 0.5, "graph": 0.5, "path": 0.1}
+    n = 6_000
+    bm = np.zeros(n); nz = rng.choice(n, 60, replace=False); bm[nz] = np.abs(rng.standard_normal(60))
+    run("rrf_two_full_vectors", n, {"dense": rng.uniform(-0.2, 0.9, n), "bm25": bm}, {"graph": pairs(n, 12), "path": pairs(n, 4)}, w, 80)
+    n = 5_000
+    run("rrf_two_full_ties", n, {"dense": np.round(rng.uniform(0, 1, n), 1), "bm25": np.round(np.abs(rng.standard_normal(n)), 1)},
+        {"graph": pairs(n, 20), "path": pairs(n, 6)}, w, 100, rrf_k=1)
+    # mirrored rankings with equal weights: notes i and n-1-i get exactly equal finals -> the tie rule decides
+    lin = np.linspace(1.0, 0.0, n)
+    run("rrf_two_full_mirrored", n, {"dense": lin, "bm25": lin[::-1].copy()}, {}, {"dense": 1.0, "bm25": 1.0, "graph": 0.5, "path": 0.1}, 40)
+    n = 4_500
+    g = np.zeros(n); g[rng.choice(n, 200, replace=False)] = rng.uniform(0.1, 1.0, 200)
+    run("rrf_three_full_vectors", n, {"dense": rng.standard_normal(n), "bm25": np.abs(rng.standard_normal(n)) * (rng.random(n) < 0.05), "graph": g},
+        {"path": pairs(n, 9)}, w, 64)
     return cases
 
 
@@ -420,6 +465,9 @@ def main():
     with open(os.path.join(HERE, "fusion_long_cases.json"), "w") as f:
         json.dump({"source": "reference retrieval/hybrid_search.py HybridSearcher.fuse, full-corpus bm25 lists",
                    "cases": fusion_long_cases(hs)}, f)
+    with open(os.path.join(HERE, "fusion_rrf_multi_long_cases.json"), "w") as f:
+        json.dump({"source": "reference retrieval/hybrid_search.py HybridSearcher.fuse (rrf), two or three full-corpus lists",
+                   "cases": fusion_rrf_multi_long_cases(hs)}, f)
     with open(os.path.join(HERE, "candidate_fusion_cases.json"), "w") as f:
         json.dump({"source": "reference query/query_processor.py QueryProcessor._hybrid_search / _enhanced_hybrid_search_v2 "
                              "(method bodies compiled from the reference source as they stand)",

@@ -292,3 +292,53 @@ def test_float32_score_arrays_equal_the_float64_arrays_of_the_same_values(method
         ag.free()
     a32.free()
     a64.free()
+
+
+def _rrf_multi_cases():
+    with open(os.path.join(GOLD, "fusion_rrf_multi_long_cases.json")) as f:
+        return json.load(f)["cases"]
+
+
+@pytest.mark.parametrize("case", _rrf_multi_cases(), ids=lambda c: c["name"])
+def test_rrf_with_two_or_three_full_corpus_lists_matches_reference_golden(case):
+    """HybridSearcher.fuse, method rrf, where two or three lists hold one entry per note (anr_fuse_rrf_long: every ranked
+    list sorted on the device in its own order) — the reference's own output on the same lists: ids, order, finals
+    bit for bit, per-source scores and tags"""
+    from retrieval.hybrid_search import HybridSearcher
+    hs = HybridSearcher(case["config"])
+    n = case["n"]
+    lists = {}
+    for k in ("dense", "bm25", "graph", "path"):
+        if k in case["vectors"]:
+            lists[k] = [(i, v) for i, v in enumerate(case["vectors"][k])]
+        else:
+            lists[k] = [tuple(p) for p in case["short"].get(k, [])]
+    got = hs.fuse(dense=lists["dense"], bm25=lists["bm25"], graph=lists["graph"], path=lists["path"])
+    exp = case["expected"]
+    assert [r["note_id"] for r in got] == [r["note_id"] for r in exp]
+    assert [r["final_similarity"] for r in got] == [r["final_similarity"] for r in exp]
+    assert [r["scores"] for r in got] == [r["scores"] for r in exp] and [r["tags"] for r in got] == [r["tags"] for r in exp]
+    assert len(got) <= hs.candidate_pool and n >= len(got)
+
+
+def test_rrf_long_lists_in_unrelated_orders_with_string_ids_and_heavy_ties():
+    """two long lists whose orders have nothing to do with each other (a stable sort keeps EACH list's own order among
+    equal scores), string ids, ids missing from one list or the other, a long graph list as well — against the oracle
+    restatement (pinned by the goldens above)"""
+    from retrieval.hybrid_search import HybridSearcher
+    rng = np.random.default_rng(17)
+    n = 9000
+    names = [f"n{i:05d}" for i in range(n)]
+    dense = [(names[i], float(s)) for i, s in zip(rng.permutation(n)[:8000], np.round(rng.uniform(0, 1, 8000), 2))]
+    bm25 = [(names[i], float(s)) for i, s in zip(rng.permutation(n)[:8500], np.round(np.abs(rng.standard_normal(8500)), 1))]
+    graph = [(names[i], float(s)) for i, s in zip(rng.permutation(n)[:5000], np.round(rng.uniform(0, 1, 5000), 1))]
+    path = [(names[i], float(s)) for i, s in zip(rng.choice(n, 12, replace=False), rng.uniform(0, 1, 12))] + [("only_in_path", 0.9)]
+    for w in ({"dense": 1.0, "bm25": 0.5, "graph": 0.5, "path": 0.1}, {"dense": 0.3, "bm25": 1.0, "graph": 0.0, "path": 2.0}):
+        cfg = {"retrieval": {"candidate_pool": 90, "hybrid": {"enabled": True, "fusion_method": "rrf", "rrf_k": 7, "weights": w}}}
+        hs = HybridSearcher(cfg)
+        got = hs.fuse(dense, bm25, graph, path)
+        exp = ofu.fuse(dense, bm25, graph, path, candidate_pool=90, fusion_method="rrf", weights=hs.weights, rrf_k=7)
+        assert [r["note_id"] for r in got] == [r["note_id"] for r in exp]
+        assert [r["final_similarity"] for r in got] == [r["final_similarity"] for r in exp]
+        assert [r["scores"] for r in got] == [r["scores"] for r in exp]
+    assert all(r["note_id"] != "only_in_path" for r in got)
