@@ -38,6 +38,7 @@ struct FuseShared {
   unsigned tie[kFuseMax];            // rrf: source << 28 | rank of the first source holding the id
   unsigned idx[kFuseMax];
   unsigned keep[kFuseMax];
+  unsigned long long xk[kFuseMax];  // bitonic_pairs: exchange buffer of the passes that cross waves
   double red[16];
   double smax[4];
   unsigned cnt;
@@ -63,6 +64,102 @@ __device__ void bitonic_idx(unsigned *idx, int n_pow2, F less) {
       __syncthreads();
     }
   }
+}
+
+// Orders n_pow2 (key, value) pairs ascending by key, `tie(va, vb)` deciding between equal keys (a strict order on the
+// values), and leaves the values in out[0..n_pow2).  The pairs live in REGISTERS, thread t holding elements t, t + 1024,
+// ...: a compare-exchange of stride j < 64 reaches its partner with shuffles inside the wave (no LDS, no barrier), a
+// stride >= 1024 pairs two registers of the same thread, and only the strides 64..512 go through LDS with barriers —
+// 14 of the 66 passes at 2048 elements.  (The index-array form above, one LDS gather and one barrier per pass, was 100
+// of the 113 us ONE ~1100-entry fuse call spent in k_fuse.)
+template <typename KeyFn, typename TieFn>
+__device__ void bitonic_pairs(unsigned long long *xk, unsigned *xv, int n_pow2, KeyFn key_of, TieFn tie, unsigned *out) {
+  constexpr int EMAX = kFuseMax / 1024;
+  const int tid = threadIdx.x;
+  const int E = n_pow2 >= 1024 ? n_pow2 / 1024 : 1;
+  const bool act = tid < n_pow2;  // (n_pow2 < 1024: the upper threads only join the barriers)
+  unsigned long long k[EMAX];
+  unsigned v[EMAX];
+#pragma unroll
+  for (int e = 0; e < EMAX; ++e)
+    if (e < E) {
+      const int i = tid + 1024 * e;
+      v[e] = act ? xv[i] : 0xffffffffu;
+      k[e] = act ? key_of(v[e]) : ~0ull;
+    }
+  auto before = [&](unsigned long long ka, unsigned va, unsigned long long kb, unsigned vb) {
+    return ka < kb || (ka == kb && tie(va, vb));
+  };
+  for (int k2 = 2; k2 <= n_pow2; k2 <<= 1) {
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+      if (j >= 1024) {  // partner = another register of this thread
+        const int je = j >> 10;
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e)
+          if (e < E && (e & je) == 0) {
+            const int f = e | je;  // (f < E: both are bits of the element number)
+            const int i = tid + 1024 * e;
+            const bool up = (i & k2) == 0;
+            // static indexing only: f ranges over the few set-bit patterns of EMAX
+#pragma unroll
+            for (int ff = 0; ff < EMAX; ++ff)
+              if (ff == f) {
+                const bool swap = up ? before(k[ff], v[ff], k[e], v[e]) : before(k[e], v[e], k[ff], v[ff]);
+                if (swap) {
+                  const unsigned long long tk = k[e];
+                  const unsigned tv = v[e];
+                  k[e] = k[ff];
+                  v[e] = v[ff];
+                  k[ff] = tk;
+                  v[ff] = tv;
+                }
+              }
+          }
+      } else if (j >= 64) {  // partner in another wave: through LDS
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e)
+          if (e < E && act) {
+            xk[tid + 1024 * e] = k[e];
+            xv[tid + 1024 * e] = v[e];
+          }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e)
+          if (e < E && act) {
+            const int i = tid + 1024 * e, pi = i ^ j;
+            const unsigned long long pk = xk[pi];
+            const unsigned pv = xv[pi];
+            const bool up = (i & k2) == 0, lower = (i & j) == 0;
+            const bool want_min = up == lower;
+            const bool mine_first = before(k[e], v[e], pk, pv);
+            if (want_min != mine_first) {
+              k[e] = pk;
+              v[e] = pv;
+            }
+          }
+        __syncthreads();
+      } else {  // partner lane in this wave
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e)
+          if (e < E) {
+            const int i = tid + 1024 * e;
+            const unsigned long long pk = __shfl_xor(k[e], j);
+            const unsigned pv = __shfl_xor(v[e], j);
+            const bool up = (i & k2) == 0, lower = (i & j) == 0;
+            const bool want_min = up == lower;
+            const bool mine_first = before(k[e], v[e], pk, pv);
+            if (act && want_min != mine_first) {
+              k[e] = pk;
+              v[e] = pv;
+            }
+          }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < EMAX; ++e)
+    if (e < E && act) out[tid + 1024 * e] = v[e];
+  __syncthreads();
 }
 
 template <bool OVR>  // OVR: FuseParams::smax_ovr / rank_ovr are honoured
@@ -93,12 +190,36 @@ __global__ __launch_bounds__(1024) void k_fuse(FuseParams p) {
     }
     __syncthreads();
   }
-  // 2) contribution of every entry.  rrf ranks count inside the source's list: the raw scores are staged in LDS first
-  //    (the count loop read them from global memory) and read eight per round
+  // 2) contribution of every entry.  rrf: the rank of an entry = its position in a stable descending sort of its
+  //    source's list (:66-67) — each list is ordered with bitonic_pairs (key = the score's inverted image, ties by list
+  //    position), 1-based positions land in sh.keep.  (Counting, per entry, the entries that come before it was an
+  //    O(n^2) loop on one CU: 90 us for a 1000-entry list.)
   constexpr int PER = (kFuseMax + 1023) / 1024;
   if (p.method == 1) {
     for (int e = tid; e < T; e += 1024) sh.val[e] = p.scores[base + e];
     __syncthreads();
+    const double *raw = sh.val;
+    for (int s = 0; s < 3; ++s) {
+      const int o0 = (int)(off[s] - base), ns = (int)(off[s + 1] - off[s]);
+      if (ns == 0) continue;
+      int np2 = 1;
+      while (np2 < ns) np2 <<= 1;
+      for (int i = tid; i < np2; i += 1024) sh.idx[i] = i < ns ? (unsigned)(o0 + i) : INVALID;
+      __syncthreads();
+      bitonic_pairs(
+          sh.xk, sh.idx, np2,
+          [raw](unsigned a) {
+            if (a == 0xffffffffu) return ~0ull;
+            double v = raw[a];
+            if (!(v == v)) return ~0ull - 1ull;  // NaN scores after every number (their rank is set below)
+            if (v == 0.0) v = 0.0;
+            const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+            return ~((u >> 63) ? ~u : (u | 0x8000000000000000ull));
+          },
+          [](unsigned a, unsigned b) { return a < b; }, sh.idx);
+      for (int r = tid; r < ns; r += 1024) sh.keep[sh.idx[r]] = (unsigned)(r + 1);
+      __syncthreads();
+    }
   }
   double c_mine[PER];
   unsigned tie_mine[PER];
@@ -118,24 +239,10 @@ __global__ __launch_bounds__(1024) void k_fuse(FuseParams p) {
         const double m = sh.smax[s];
         c = p.w[s] * (m == 0.0 ? 0.0 : sc / m);
       } else {
-        // rank = 1 + entries of this source ordered before e in a stable descending sort (:66-67)
+        // rank = 1 + entries of this source ordered before e in a stable descending sort (:66-67); a NaN score is
+        // beaten by nothing under the reference's comparisons
         int rank = (OVR && p.rank_ovr) ? p.rank_ovr[g] : 0;
-        if (rank == 0) {
-          rank = 1;
-          const int o0 = (int)(off[s] - base), o1 = (int)(off[s + 1] - base);
-          int o = o0;
-          for (; o + 8 <= o1; o += 8) {  // eight independent LDS reads per round
-            double v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = sh.val[o + u];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) rank += (v[u] > sc || (v[u] == sc && o + u < e)) ? 1 : 0;
-          }
-          for (; o < o1; ++o) {
-            const double so = sh.val[o];
-            rank += (so > sc || (so == sc && o < e)) ? 1 : 0;
-          }
-        }
+        if (rank == 0) rank = sc == sc ? (int)sh.keep[e] : 1;
         c = p.w[s] / (p.rrf_k + (double)rank);
         tie = ((unsigned)s << 28) | (unsigned)rank;
       }
@@ -143,7 +250,7 @@ __global__ __launch_bounds__(1024) void k_fuse(FuseParams p) {
       tie_mine[k] = tie;
     }
   }
-  if (p.method == 1) __syncthreads();  // every rank loop has read the raw scores
+  if (p.method == 1) __syncthreads();  // every entry has read its raw score and rank
   {
     int k = 0;
     for (int e = tid; e < T; e += 1024, ++k) {
@@ -161,11 +268,9 @@ __global__ __launch_bounds__(1024) void k_fuse(FuseParams p) {
   // 3) group by id: sort entry indices by (id, source)
   {
     const unsigned long long *key = sh.key;
-    bitonic_idx(sh.idx, Tp, [key](unsigned a, unsigned b) {
-      if (a == INVALID) return false;
-      if (b == INVALID) return true;
-      return key[a] < key[b];
-    });
+    // (an INVALID padding value sorts last: the maximal key; entry indices break a repeated id inside one source)
+    bitonic_pairs(sh.xk, sh.idx, Tp, [key](unsigned a) { return a == 0xffffffffu ? ~0ull : key[a]; },
+                  [](unsigned a, unsigned b) { return a < b; }, sh.idx);
   }
   // 4) each segment head sums its sources in the reference's order dense -> bm25 -> graph, then path
   for (int i = tid; i < T; i += 1024) {
@@ -218,13 +323,24 @@ __global__ __launch_bounds__(1024) void k_fuse(FuseParams p) {
     const unsigned *tie = sh.tie;
     const unsigned long long *key = sh.key;
     const int method = p.method;
-    bitonic_idx(sh.idx, Up, [val, tie, key, method](unsigned a, unsigned b) {
-      if (a == INVALID) return false;
-      if (b == INVALID) return true;
-      if (val[a] != val[b]) return val[a] > val[b];
-      if (method == 1 && tie[a] != tie[b]) return tie[a] < tie[b];
-      return key[a] < key[b];
-    });
+    // key: the final's order-preserving 64-bit image, inverted (ascending key = descending final; -0 == +0; NaN after
+    // every number; padding last); equal finals: the reference's tie rules
+    bitonic_pairs(
+        sh.xk, sh.idx, Up,
+        [val](unsigned a) {
+          if (a == 0xffffffffu) return ~0ull;
+          double v = val[a];
+          if (!(v == v)) return ~0ull - 1ull;
+          if (v == 0.0) v = 0.0;
+          const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+          return ~((u >> 63) ? ~u : (u | 0x8000000000000000ull));
+        },
+        [tie, key, method](unsigned a, unsigned b) {
+          if (a == 0xffffffffu || b == 0xffffffffu) return a < b;
+          if (method == 1 && tie[a] != tie[b]) return tie[a] < tie[b];
+          return key[a] < key[b] || (key[a] == key[b] && a < b);
+        },
+        sh.idx);
   }
   // 6) emit
   const int n_out = U < p.pool ? U : p.pool;
