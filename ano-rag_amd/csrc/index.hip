@@ -874,17 +874,18 @@ int64_t tiny_workgroups(const anr_index *h, int32_t k) {
 
 // Where the single launch beats the five-kernel pipeline for batches of <= 4 queries (tools/tiny_perf.py, k = 10):
 // 20 k x 768 41 vs 83 us, 50 k x 768 58 vs 86, 100 k x 768 85 vs 93; from ~120 k x 768 the pipeline's f16 scan wins.
-// Its cost grows with k (fewer, longer partial lists to rank and merge) and with the bytes a workgroup streams, the
-// pipeline's barely: at k = 100 it LOSES even on 10 k x 384 (97 vs 69 us), at k = 32 it wins up to ~1.6 MB per workgroup
-// (20 k x 768: 59 vs 81; 50 k x 768: 92 vs 82), at k = 50 it is level (10 k x 768: 63 vs 72; 40 k x 768: 113 vs 119).
+// Its cost grows with k (fewer, longer partial lists: 2048 / k workgroups, each streaming more f32 rows at one CU's
+// ~25 GB/s) while the pipeline's barely does.  Measured, batch 1, bare C ABI, this path vs the pipeline: k = 10: 10 k x 384
+// 33 vs 58 us, 20 k x 768 39 vs 79, 100 k x 768 88 vs 94; k = 50: 10 k x 768 63 vs 72, 20 k x 768 68 vs 83 (1.5 MB per
+// workgroup), 40 k x 768 level; k = 32 at 50 k x 768 (2.4 MB) 86 vs 80; k = 20 at 100 k x 768 (3 MB) 115 vs 94;
+// k = 100: 10 k x 384 63 vs 60, 20 k x 768 93 vs 85.  Hence: k <= 64 and at most 1.6 MB of rows per workgroup.
 bool tiny_applies(const anr_index *h, int64_t nq, int32_t k) {
   if (!h->tiny || h->force_exact || nq < 1 || nq > kTinyMaxQ || k > kTinyMaxK || h->ntotal < 1) return false;
   const int64_t rows_per_wg = ceil_div(h->ntotal, tiny_workgroups(h, k));
   if (rows_per_wg > kTinyRowsPerWG) return false;
   if (h->tiny >= 2) return true;  // forced (tests): structural limits only
   if (k > 64) return false;
-  const int64_t slice_bytes = rows_per_wg * h->dim * 4;
-  return slice_bytes <= (k <= 32 ? (int64_t)1600 << 10 : (int64_t)800 << 10);
+  return rows_per_wg * h->dim * 4 <= ((int64_t)1600 << 10);
 }
 
 int search_tiny(anr_index *h, const float *q, int64_t nq, int32_t k, float *D, int64_t *I) {

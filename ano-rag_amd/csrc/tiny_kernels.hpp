@@ -19,6 +19,8 @@ constexpr int kTinyMaxK = 128;
 constexpr int kTinyMaxQ = 4;
 constexpr int kTinyRowsPerWG = 1024;   // rows a workgroup ranks among themselves
 constexpr int kTinyMaxMerge = 2048;    // partial-list entries the last workgroup merges
+constexpr int kTinySortRows = 192;     // slices longer than this are ordered by the bitonic network instead of rank counting
+constexpr int kTinySortK = 32;         // merges for k beyond this likewise (the second rank-counting level grows as (16 k)^2)
 
 struct TinyParams {
   const float *x32;      // stored rows [n_rows][dim]
@@ -37,6 +39,67 @@ struct TinyParams {
 };
 
 #define TINY_STAMP(slot, cond) do { if (p.stamps && (cond) && threadIdx.x == 0) p.stamps[slot] = wall_clock64(); } while (0)
+
+// buf[0..n_pow2) (n_pow2 a power of two <= 2048, padded with 0 = below every key) sorted DESCENDING in place by a
+// bitonic network over keys held in registers (thread t: elements t and t + 1024): strides below 64 exchange through wave
+// shuffles, 64..512 through LDS with barriers, 1024 inside the thread.  Replaces rank counting ("how many keys beat
+// mine": a dependent-LDS loop of n iterations per thread — 30 us for a workgroup's 1000 rows, 75 us for the last
+// workgroup's 1600-entry second merge level at k = 100).  Keys are distinct (the row id is part of them), so the
+// result is the same order.  All kTinyThreads threads call.
+__device__ __forceinline__ void tiny_sort_desc(unsigned long long *buf, int n_pow2) {
+  const int tid = threadIdx.x;
+  const bool two = n_pow2 > kTinyThreads;
+  const bool act = tid < n_pow2;
+  unsigned long long k0 = act ? buf[tid] : 0ull, k1 = two ? buf[tid + kTinyThreads] : 0ull;
+  for (int k2 = 2; k2 <= n_pow2; k2 <<= 1) {
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+      if (j >= kTinyThreads) {  // (only j == 1024 at n_pow2 == 2048: the thread's own two keys, whole range one run)
+        if (k0 < k1) {
+          const unsigned long long t = k0;
+          k0 = k1;
+          k1 = t;
+        }
+      } else if (j >= 64) {
+        if (act) buf[tid] = k0;
+        if (two) buf[tid + kTinyThreads] = k1;
+        __syncthreads();
+        {
+          const int i = tid, pi = i ^ j;
+          const unsigned long long pk = act ? buf[pi] : 0ull;
+          const bool first_wanted = ((i & k2) == 0) == ((i & j) == 0);  // this slot takes the one that sorts first (larger)
+          const bool mine_first = k0 > pk;
+          if (act && first_wanted != mine_first) k0 = pk;
+        }
+        if (two) {
+          const int i = tid + kTinyThreads, pi = i ^ j;
+          const unsigned long long pk = buf[pi];
+          const bool first_wanted = ((i & k2) == 0) == ((i & j) == 0);
+          const bool mine_first = k1 > pk;
+          if (first_wanted != mine_first) k1 = pk;
+        }
+        __syncthreads();
+      } else {
+        {
+          const int i = tid;
+          const unsigned long long pk = __shfl_xor(k0, j);
+          const bool first_wanted = ((i & k2) == 0) == ((i & j) == 0);
+          const bool mine_first = k0 > pk;
+          if (act && first_wanted != mine_first) k0 = pk;
+        }
+        if (two) {
+          const int i = tid + kTinyThreads;
+          const unsigned long long pk = __shfl_xor(k1, j);
+          const bool first_wanted = ((i & k2) == 0) == ((i & j) == 0);
+          const bool mine_first = k1 > pk;
+          if (first_wanted != mine_first) k1 = pk;
+        }
+      }
+    }
+  }
+  if (act) buf[tid] = k0;
+  if (two) buf[tid + kTinyThreads] = k1;
+  __syncthreads();
+}
 
 // KC: 16-byte chunks per lane of one row (dim / 4 <= 64 KC), 0 = generic path (dim not a multiple of 4, or > 1024)
 template <int KC>
@@ -156,17 +219,27 @@ __global__ __launch_bounds__(kTinyThreads) void k_tiny_search(TinyParams p) {
   TINY_STAMP(3, w0);
   // --- the workgroup's k best (rank counting among its rows), published as its partial list --------------------
   unsigned long long *mine = p.cand + ((int64_t)q * p.n_wg + wg) * p.k;
-  unsigned long long mykey = 0ull;
-  int myrank = p.k;
-  if (tid < rows) {
-    mykey = s_rowkey[tid];
-    int rank = 0;
-    for (int j = 0; j < rows; ++j) rank += (s_rowkey[j] > mykey) ? 1 : 0;
-    myrank = rank;
+  if (rows > kTinySortRows) {  // a long slice: order it (see tiny_sort_desc), the first k are the list
+    int rp = 2;
+    while (rp < rows) rp <<= 1;  // rows <= kTinyRowsPerWG = 1024
+    for (int i = rows + tid; i < rp; i += kTinyThreads) s_rowkey[i] = 0ull;
+    __syncthreads();
+    tiny_sort_desc(s_rowkey, rp);
+    for (int i = tid; i < p.k; i += kTinyThreads)
+      __hip_atomic_store(mine + i, i < rows ? s_rowkey[i] : 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {  // a short slice: every row counts the rows that beat it (a loop of `rows` LDS reads)
+    unsigned long long mykey = 0ull;
+    int myrank = p.k;
+    if (tid < rows) {
+      mykey = s_rowkey[tid];
+      int rank = 0;
+      for (int j = 0; j < rows; ++j) rank += (s_rowkey[j] > mykey) ? 1 : 0;
+      myrank = rank;
+    }
+    if (myrank < p.k) __hip_atomic_store(mine + myrank, mykey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = rows + tid; i < p.k; i += kTinyThreads)
+      __hip_atomic_store(mine + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (myrank < p.k) __hip_atomic_store(mine + myrank, mykey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  for (int i = rows + tid; i < p.k; i += kTinyThreads)
-    __hip_atomic_store(mine + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains before the ticket
   __syncthreads();
   TINY_STAMP(4, w0);
@@ -191,33 +264,48 @@ __global__ __launch_bounds__(kTinyThreads) void k_tiny_search(TinyParams p) {
   float *D = p.D + (int64_t)q * p.k;
   int64_t *I = p.I + (int64_t)q * p.k;
   const int64_t found = p.n_rows < p.k ? p.n_rows : p.k;
-  // two-level merge with INDEPENDENT LDS reads (binary searches across the sorted lists were tried: ~1000 dependent LDS
-  // round trips per entry, 100 us): level 1 — each of the 16 waves ranks the entries of its share of the lists among
-  // themselves and keeps the k best; level 2 — the 16 k survivors are ranked among themselves
-  unsigned long long *s_l2 = s_keys + kTinyMaxMerge;  // [16][k]
-  const int G = (p.n_wg + 15) / 16;                    // lists per level-1 group
-  const int GE = G * p.k;                              // entries per group
-  for (int i = tid; i < 16 * p.k; i += kTinyThreads) s_l2[i] = 0ull;
-  __syncthreads();
-  for (int i = tid; i < M; i += kTinyThreads) {
-    const unsigned long long key = s_keys[i];
-    if (key == 0ull) continue;
-    const int g = i / GE;
-    const int e0 = g * GE, e1 = e0 + GE < M ? e0 + GE : M;
-    int rank = 0;
-    for (int j = e0; j < e1; ++j) rank += (s_keys[j] > key) ? 1 : 0;
-    if (rank < p.k) s_l2[g * p.k + rank] = key;
+  if (p.k > kTinySortK) {
+    // the n_wg * k <= 2048 keys of all partial lists, ordered by the register bitonic network (binary searches across the
+    // sorted lists were tried first: ~1000 dependent LDS round trips per entry, 100 us; then two levels of rank counting:
+    // 11 us at k = 10 but 75 us at k = 100)
+    {
+      int mp = 2;
+      while (mp < M) mp <<= 1;
+      for (int i = M + tid; i < mp; i += kTinyThreads) s_keys[i] = 0ull;
+      __syncthreads();
+      tiny_sort_desc(s_keys, mp);
+      for (int i = tid; i < p.k; i += kTinyThreads) s_rank[i] = i < M ? s_keys[i] : 0ull;
+      __syncthreads();
+    }
+  } else {
+    // two-level merge with INDEPENDENT LDS reads (binary searches across the sorted lists were tried: ~1000 dependent LDS
+    // round trips per entry, 100 us): level 1 — each of the 16 waves ranks the entries of its share of the lists among
+    // themselves and keeps the k best; level 2 — the 16 k survivors are ranked among themselves
+    unsigned long long *s_l2 = s_keys + kTinyMaxMerge;  // [16][k]
+    const int G = (p.n_wg + 15) / 16;                    // lists per level-1 group
+    const int GE = G * p.k;                              // entries per group
+    for (int i = tid; i < 16 * p.k; i += kTinyThreads) s_l2[i] = 0ull;
+    __syncthreads();
+    for (int i = tid; i < M; i += kTinyThreads) {
+      const unsigned long long key = s_keys[i];
+      if (key == 0ull) continue;
+      const int g = i / GE;
+      const int e0 = g * GE, e1 = e0 + GE < M ? e0 + GE : M;
+      int rank = 0;
+      for (int j = e0; j < e1; ++j) rank += (s_keys[j] > key) ? 1 : 0;
+      if (rank < p.k) s_l2[g * p.k + rank] = key;
+    }
+    __syncthreads();
+    const int M2 = 16 * p.k;
+    for (int i = tid; i < M2; i += kTinyThreads) {
+      const unsigned long long key = s_l2[i];
+      if (key == 0ull) continue;
+      int rank = 0;
+      for (int j = 0; j < M2; ++j) rank += (s_l2[j] > key) ? 1 : 0;
+      if (rank < p.k) s_rank[rank] = key;  // ranks are distinct: one writer per slot
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  const int M2 = 16 * p.k;
-  for (int i = tid; i < M2; i += kTinyThreads) {
-    const unsigned long long key = s_l2[i];
-    if (key == 0ull) continue;
-    int rank = 0;
-    for (int j = 0; j < M2; ++j) rank += (s_l2[j] > key) ? 1 : 0;
-    if (rank < p.k) s_rank[rank] = key;  // ranks are distinct: one writer per slot
-  }
-  __syncthreads();
   // one wave writes the k results into pinned host memory and fences them ONCE at system scope (a fence per writing
   // thread, or system-scope atomic stores, cost 5-10 us apiece here)
   if (wave == 0) {

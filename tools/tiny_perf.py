@@ -31,13 +31,13 @@ def timeit(f, reps=400):
 res = {}
 # the first few hundred calls of a process are 4-5x slower (cold clocks / first touches): 171 us per call over the first
 # 400 vs 36 us afterwards — warm up before timing anything
-idx.set_option(OPT_TINY, 1)
+idx.set_option(OPT_TINY, int(os.environ.get("TINY_MODE", "1")))  # 2 = wherever the path is able
 t0 = time.perf_counter()
 for i in range(400): wrapper(i % 512)
 res["first 400 calls of the process, wrapper_us"] = (time.perf_counter() - t0) / 400 * 1e6
 for i in range(1200): bare(i % 512)
 for tiny in (1, 0):
-    idx.set_option(OPT_TINY, tiny)
+    idx.set_option(OPT_TINY, int(os.environ.get("TINY_MODE", "1")) if tiny else 0)
     res[f"tiny={tiny} wrapper_us"] = timeit(wrapper)
     res[f"tiny={tiny} bare_ctypes_us"] = timeit(bare)
 xn = x / np.linalg.norm(x, axis=1, keepdims=True)
