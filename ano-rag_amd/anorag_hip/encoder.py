@@ -268,6 +268,9 @@ class SentenceEncoder:
         self._pad = info["pad_token_id"]
         self.device = device
         self._pool = None  # tokeniser worker (created on first multi-batch encode)
+        # padded tokens (sequences x padded length) one forward may hold: the workspace is 16 H + 2 I bytes per token
+        # (6.4 GB at this budget for XLM-R large) — the role SentenceTransformer.encode's batch_size plays as a memory knob
+        self.max_forward_tokens = 1 << 18
 
     def get_sentence_embedding_dimension(self) -> int:
         return self._enc.hidden
@@ -291,8 +294,8 @@ class SentenceEncoder:
     def _batches(self, sentences, batch_size):
         """length-sorted batches (longest first, as SentenceTransformer.encode), tokenised one batch AHEAD on a worker
         thread: the tokenizer (Rust, releases the GIL) prepares batch i + 1 while the device runs the forward of
-        batch i (the ctypes call releases the GIL as well).  The forward size is the device's business, not the
-        caller's memory knob (``batch_size`` is accepted and ignored): fewer than 256 sentences go in ONE forward (100
+        batch i (the ctypes call releases the GIL as well).  The forward size is the device's business
+        (``batch_size`` is accepted and ignored; memory is bounded by ``max_forward_tokens``, see ``_token_slices``): fewer than 256 sentences go in ONE forward (100
         sentences as four forwards of 32 took 5 ms, as one 2.5 ms — small forwards leave most CUs idle), 256 and more
         in forwards of 128 (the next is tokenised while one runs: at 256 queries the tokenizer is a third of the time),
         2048 and more in forwards of 256; a forward also ends where the sorted texts get shorter than 60 % of its
@@ -327,6 +330,23 @@ class SentenceEncoder:
                 nxt = self._pool.submit(self.tokenize, [sentences[i] for i in sels[bi + 1]])
             yield sel, cur
 
+    def _token_slices(self, lens):
+        """row ranges [a, b) of one tokenised batch (longest first) and the padded width each needs, so that no forward
+        holds more than ``max_forward_tokens`` padded tokens: 255 long notes under a long-context model (bge-m3:
+        max_seq_length 8192) are 2 M tokens, tens of GB of workspace as ONE forward"""
+        n, a = len(lens), 0
+        budget = max(int(self.max_forward_tokens), 32)
+        while a < n:
+            b, L = a, 0
+            while b < n:
+                L2 = max(L, int(lens[b]))
+                if b > a and (b + 1 - a) * ((L2 + 31) // 32 * 32) > budget:
+                    break
+                L = L2
+                b += 1
+            yield a, b, L
+            a = b
+
     def encode(self, sentences, batch_size: int = 32, show_progress_bar: bool = False, convert_to_numpy: bool = True,
                normalize_embeddings: bool = False, device=None, **_):
         single = isinstance(sentences, str)
@@ -337,7 +357,9 @@ class SentenceEncoder:
         want_norm = bool(normalize_embeddings) or self._info["normalize_module"]
         use_types = self._info["hf"].get("type_vocab_size", 1) > 1
         for sel, (ids, lens, types) in self._batches(sentences, batch_size):
-            out[sel] = self._enc.forward(ids, lens, types if use_types else None, normalize=want_norm)
+            for a, b, L in self._token_slices(lens):
+                out[sel[a:b]] = self._enc.forward(ids[a:b, :L], lens[a:b], types[a:b, :L] if use_types else None,
+                                                  normalize=want_norm)
         return out[0] if single else out
 
     def encode_device(self, sentences, batch_size: int = 32, normalize_embeddings: bool = False):
@@ -349,7 +371,9 @@ class SentenceEncoder:
         want_norm = bool(normalize_embeddings) or self._info["normalize_module"]
         use_types = self._info["hf"].get("type_vocab_size", 1) > 1
         for sel, (ids, lens, types) in self._batches(sentences, batch_size):
-            self._enc.forward_device(ids, lens, types if use_types else None, want_norm, out.ptr, out_rows=sel)
+            for a, b, L in self._token_slices(lens):
+                self._enc.forward_device(ids[a:b, :L], lens[a:b], types[a:b, :L] if use_types else None, want_norm,
+                                         out.ptr, out_rows=sel[a:b])
         return out
 
     def close(self):

@@ -35,6 +35,20 @@ class DeviceArray:
         self.ptr = p.value
 
     @classmethod
+    def wrap(cls, ptr: int, nq: int, n: int, dtype=np.float64, device: int = 0, row_max: "DeviceArray" = None) -> "DeviceArray":
+        """a view of device memory owned by someone else (a torch tensor, another library's buffer): never freed here"""
+        self = object.__new__(cls)
+        self.row_max = row_max
+        self.nq, self.n, self.device = int(nq), int(n), int(device)
+        self.dtype = np.dtype(dtype)
+        if self.dtype not in (np.dtype(np.float64), np.dtype(np.float32)):
+            raise ValueError("DeviceArray holds float64 or float32")
+        self.nbytes = self.nq * self.n * self.dtype.itemsize
+        self.ptr = int(ptr)
+        self._borrowed = True
+        return self
+
+    @classmethod
     def from_numpy(cls, a: np.ndarray, device: int = 0, with_max: bool = False) -> "DeviceArray":
         """with_max: also upload each row's maximum over its non-NaN entries (``row_max``) — the host has the rows in
         hand anyway, and the linear fusion then skips its max pass"""
@@ -62,7 +76,8 @@ class DeviceArray:
             self.row_max.free()
             self.row_max = None
         if getattr(self, "ptr", None):
-            _lib.load().anr_device_free(self.device, C.c_void_p(self.ptr))
+            if not getattr(self, "_borrowed", False):
+                _lib.load().anr_device_free(self.device, C.c_void_p(self.ptr))
             self.ptr = None
 
     def __del__(self):  # pragma: no cover - best effort

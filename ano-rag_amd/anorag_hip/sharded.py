@@ -36,6 +36,14 @@ def shard_bounds(n_total: int, world: int, rank: int) -> Tuple[int, int]:
     return lo, min(lo + per, n_total)
 
 
+def packed_layout(nres: int) -> Tuple[int, int]:
+    """(id_offset, part_bytes) of one rank's packed exchange buffer ``[nres f32 | pad | nres i64]``: the id block
+    starts on an 8-byte boundary (nres may be odd: one query with k = 5) and a part is a multiple of 8 bytes, so the
+    parts of an all-gather are part_bytes / 4 floats and part_bytes / 8 int64 apart — both exact."""
+    id_off = (int(nres) * 4 + 7) // 8 * 8
+    return id_off, id_off + int(nres) * 8
+
+
 def merge_topk_host(Dp: np.ndarray, Ip: np.ndarray, k: int, larger_is_better: bool = True):
     """numpy statement of the merge.  Dp/Ip: [P, B, k'] partial lists (global ids, -1 padded) -> (D [B,k], I [B,k])."""
     P, B, kk = Dp.shape
@@ -259,22 +267,23 @@ class ShardedSearcher:
         dev = torch.device("cuda", idx.device)
         B = q.shape[0]
         nres = B * k
+        id_off, part = packed_layout(nres)
         key = (B, k)
         if key not in self._bufs:
-            self._bufs[key] = (torch.empty(nres * 12, device=dev, dtype=torch.uint8),
-                               torch.empty(self.world * nres * 12, device=dev, dtype=torch.uint8),
+            self._bufs[key] = (torch.empty(part, device=dev, dtype=torch.uint8),
+                               torch.empty(self.world * part, device=dev, dtype=torch.uint8),
                                torch.empty((B, k), device=dev, dtype=torch.float32),
                                torch.empty((B, k), device=dev, dtype=torch.int64))
         mine, allp, Dm, Im = self._bufs[key]
         with torch.cuda.device(dev):
             st = torch.cuda.current_stream(dev)
             qd = torch.from_numpy(np.ascontiguousarray(q, dtype=np.float32)).to(dev, non_blocking=False)
-            idx.search_device_async(qd.data_ptr(), B, k, mine.data_ptr(), mine.data_ptr() + nres * 4, st.cuda_stream)
+            idx.search_device_async(qd.data_ptr(), B, k, mine.data_ptr(), mine.data_ptr() + id_off, st.cuda_stream)
             idx.wait(0)  # final on this shard (certificate recovery done) BEFORE anything leaves it
             self.dist.all_gather_into_tensor(allp, mine, group=self.group)
             _lib.check(_lib.load().anr_merge_topk_strided_dev(
-                idx.device, C.c_void_p(allp.data_ptr()), C.c_void_p(allp.data_ptr() + nres * 4), nres * 3,
-                (nres * 3) // 2, self.world, B, k, int(self.larger), C.c_void_p(Dm.data_ptr()),
+                idx.device, C.c_void_p(allp.data_ptr()), C.c_void_p(allp.data_ptr() + id_off), part // 4,
+                part // 8, self.world, B, k, int(self.larger), C.c_void_p(Dm.data_ptr()),
                 C.c_void_p(Im.data_ptr()), C.c_void_p(st.cuda_stream)), "anr_merge_topk_strided_dev")
             return Dm.cpu().numpy(), Im.cpu().numpy()
 
@@ -292,13 +301,14 @@ class ShardedSearcher:
             return D, I
         B = q.shape[0]
         nres = B * k
-        packed = torch.empty(nres * 12, dtype=torch.uint8)  # one exchange: [B*k f32 | B*k i64]
+        id_off, part = packed_layout(nres)
+        packed = torch.zeros(part, dtype=torch.uint8)  # one exchange: [B*k f32 | pad to 8 | B*k i64]
         packed[: nres * 4] = torch.from_numpy(D.reshape(-1).view(np.uint8))
-        packed[nres * 4:] = torch.from_numpy(I.reshape(-1).view(np.uint8))
+        packed[id_off:] = torch.from_numpy(I.reshape(-1).view(np.uint8))
         parts = [torch.empty_like(packed) for _ in range(self.world)]
         self.dist.all_gather(parts, packed, group=self.group)
         Dp = np.stack([p[: nres * 4].numpy().view(np.float32).reshape(B, k) for p in parts])
-        Ip = np.stack([p[nres * 4:].numpy().view(np.int64).reshape(B, k) for p in parts])
+        Ip = np.stack([p[id_off:].numpy().view(np.int64).reshape(B, k) for p in parts])
         return merge_topk_host_c(Dp, Ip, self.larger)
 
     def search(self, q: np.ndarray, k: int):

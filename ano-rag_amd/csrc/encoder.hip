@@ -690,105 +690,19 @@ __global__ __launch_bounds__(256) void k_gemm_lds(GemmParams p) {
     }
 }
 
-// 8-wave form of the same kernel: a workgroup (4 x 2 waves) owns 256 tokens x (32 TN) features, TN = 8 or 6, so
-// each byte that leaves L2 feeds twice the MFMAs of the 4-wave tile (the 128 x 256 tile needs ~29 TB/s from L2
-// at the MFMA peak, more than the L2 delivers), and two waves share each SIMD so one wave's LDS reads hide
-// behind the other's MFMAs.  Ring of three slots x 3 k-steps x (8 + TN) fragments (<= 144 KiB).  TN = 6 exists
-// for the grid shape: at 16 K tokens a 768-wide output is 192 workgroups of 256 x 256 (a 256-CU chip 3/4 busy)
-// but exactly 256 of 256 x 192; the launcher picks the tile with the fewest workgroup rounds x tile width.
-// When 3 x (8 + TN) fragments do not divide over the 8 waves, the surplus copies repeat the first fragments
-// (same bytes to the same LDS address).
 __device__ __forceinline__ void gemm_glds16(const uint4 *g, uint4 *l) { __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0); }
 // keep a value alive in an ablated build (plain __device__ functions: an asm with a "v" constraint written directly in
 // a __global__ template breaks the host-side instantiation, like the builtin above)
 __device__ __forceinline__ void gemm_keep(const half8 &x) { asm volatile("" ::"v"(x)); }
 __device__ __forceinline__ void gemm_keep(const floatx16 &x) { asm volatile("" ::"v"(x)); }
 
-template <int EPI, int TN, int S>
-__global__ __launch_bounds__(512) void k_gemm_lds8(GemmParams p) {
-  constexpr int TM = 8, F = TM + TN, NW = TN / 2;  // NW: feature tiles per wave; S k-steps per ring slot (3, or 2 when KB % 3 != 0)
-  constexpr int LPW = (S * F + 7) / 8;               // fragment copies per wave per stage
-  static_assert(LPW == 6 || LPW == 4, "the counted vmcnt below knows six or four copies per wave per stage");
-  extern __shared__ uint4 g_lds[];  // ring [3][S][F][64]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int NG = (p.NB + TN - 1) / TN;
-  const int64_t tb0 = (int64_t)(blockIdx.x / NG) * TM;
-  const int nb0 = (int)(blockIdx.x % NG) * TN;
-  const int wm = wave >> 1, wn = wave & 1;
-  const uint4 *src[LPW];
-  int dst[LPW];
-#pragma unroll
-  for (int i = 0; i < LPW; ++i) {
-    const int f = (wave * LPW + i) % (S * F), ks = f / F, idx = f % F;
-    if (idx < TM) {
-      const int64_t tb = tb0 + idx < p.TB ? tb0 + idx : p.TB - 1;
-      src[i] = p.act + (tb * p.KB + ks) * 64 + lane;
-    } else {
-      const int nb = nb0 + idx - TM < p.NB ? nb0 + idx - TM : p.NB - 1;
-      src[i] = p.w + ((int64_t)nb * p.KB + ks) * 64 + lane;
-    }
-    dst[i] = (ks * F + idx) * 64;
-  }
-  floatx16 acc[2][NW];
-#pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int n = 0; n < NW; ++n)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-  const int nstages = p.KB / S;
-  constexpr int BUF = S * F * 64;  // uint4 per ring slot
-#pragma unroll
-  for (int i = 0; i < LPW; ++i) gemm_glds16(src[i], g_lds + dst[i]);
-  if (nstages > 1) {
-#pragma unroll
-    for (int i = 0; i < LPW; ++i) gemm_glds16(src[i] + (int64_t)S * 64, g_lds + BUF + dst[i]);
-  }
-  for (int s = 0; s < nstages; ++s) {
-    if (s + 1 < nstages) {  // LPW copies of stage s+1 stay in flight
-      if (LPW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    if (s + 2 < nstages) {
-      uint4 *slot = g_lds + ((s + 2) % 3) * BUF;
-#pragma unroll
-      for (int i = 0; i < LPW; ++i) gemm_glds16(src[i] + (int64_t)(s + 2) * S * 64, slot + dst[i]);
-    }
-    const uint4 *L = g_lds + (s % 3) * BUF + lane;
-#pragma unroll
-    for (int ks = 0; ks < S; ++ks) {
-      half8 a[2], b[NW];
-#pragma unroll
-      for (int m = 0; m < 2; ++m) a[m] = __builtin_bit_cast(half8, L[(ks * F + 2 * wm + m) * 64]);
-#pragma unroll
-      for (int n = 0; n < NW; ++n) b[n] = __builtin_bit_cast(half8, L[(ks * F + TM + NW * wn + n) * 64]);
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < NW; ++n) {
-          if (EPI == EPI_VT) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m], b[n], acc[m][n], 0, 0, 0);
-          else acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[n], a[m], acc[m][n], 0, 0, 0);
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-#pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int n = 0; n < NW; ++n) {
-      const int64_t tb = tb0 + 2 * wm + m;
-      const int nb = nb0 + NW * wn + n;
-      if (tb < p.TB && nb < p.NB) gemm_store_tile<EPI>(p, acc[m][n], tb, nb, lane);
-    }
-}
-
-// ---- ping-pong form of the 8-wave GEMM --------------------------------------------------------------------
-// Same tile (256 tokens x 32 TN features, 4 x 2 waves, 64 x (16 TN) per wave), same operand layouts; what changes
-// is the schedule.  A k-step (K = 16) is one PHASE per wave:
+// ---- 8-wave ping-pong GEMM ---------------------------------------------------------------------------------
+// A workgroup (4 x 2 waves) owns 256 tokens x (32 TN) features, TN = 8, 6 or 4 (64 x (16 TN) per wave): each byte that
+// leaves L2 feeds twice the MFMAs of the 4-wave 128 x 256 tile above, and two waves share each SIMD.  TN = 6 / 4 exist for
+// the grid shape: at 16 K tokens a 768-wide output is 192 workgroups of 256 x 256 (a 256-CU chip 3/4 busy) but exactly
+// 256 of 256 x 192; the launcher picks the tile with the fewest workgroup rounds x tile width.  When the 8 + TN
+// fragments of a k-step do not divide over the 8 waves, the surplus copies repeat the first fragments (same bytes to the
+// same LDS address).  A k-step (K = 16) is one PHASE per wave:
 //     load segment : 6 ds_read_b128 (its 2 + TN/2 operand fragments of this k-step), 2 global_load_lds (its share
 //                    of the k-step PF ahead), counted s_waitcnt vmcnt   -> s_barrier
 //     MFMA segment : s_waitcnt lgkmcnt(0), s_setprio 1, 2 x TN/2 MFMAs (256 cycles at TN = 8), s_setprio 0 -> s_barrier
@@ -1162,42 +1076,27 @@ int plain_copy(const float *host, int64_t n, float **dst) {
 
 template <int EPI, int TN>
 void launch_gemm8(anr_encoder *e, GemmParams &g, int64_t blocks) {
-  static const bool pp = getenv("ANORAG_GEMM_LDS8") == nullptr;  // developer switch: set to run the older k_gemm_lds8 instead
-  if (pp || TN < 6) {  // (the older kernel has no 128-wide form)
-    constexpr int lds_pp = 8 * (8 + TN) * 1024;
+  constexpr int lds_pp = 8 * (8 + TN) * 1024;
 #ifdef ANR_GEMM_ABLATIONS
-    static const int abl = getenv("ANORAG_GEMM_ABL") ? atoi(getenv("ANORAG_GEMM_ABL")) : 0;  // developer ablations (wrong results)
+  static const int abl = getenv("ANORAG_GEMM_ABL") ? atoi(getenv("ANORAG_GEMM_ABL")) : 0;  // developer ablations (wrong results)
 #else
-    constexpr int abl = 0;
+  constexpr int abl = 0;
 #endif
-    PatchGrid pg = make_patch_grid(ceil_div(g.TB, 8), ceil_div(g.NB, TN));
-    pg.contig = getenv("ANORAG_GEMM_CONTIG") ? 1 : 0;  // developer switch: XCD-contiguous patch assignment
-    const int64_t n_slots = pg.grid();
-    const int64_t grid = std::min<int64_t>(n_slots, std::max(8, e->n_cu / 8 * 8));  // a multiple of 8: slot % 8 = XCD
+  PatchGrid pg = make_patch_grid(ceil_div(g.TB, 8), ceil_div(g.NB, TN));
+  const int64_t n_slots = pg.grid();
+  const int64_t grid = std::min<int64_t>(n_slots, std::max(8, e->n_cu / 8 * 8));  // a multiple of 8: slot % 8 = XCD
 #define ANR_PP(A)                                                                                          \
   {                                                                                                        \
     (void)ensure_dynamic_lds(reinterpret_cast<const void *>(&k_gemm_pp<EPI, TN, A>), lds_pp);              \
     hipLaunchKernelGGL((k_gemm_pp<EPI, TN, A>), dim3((unsigned)grid), dim3(512), lds_pp, e->stream, g, pg, n_slots); \
   }
 #ifdef ANR_GEMM_ABLATIONS
-    if (abl == 1) ANR_PP(1) else if (abl == 2) ANR_PP(2) else if (abl == 3) ANR_PP(3) else if (abl == 4) ANR_PP(4) else
+  if (abl == 1) ANR_PP(1) else if (abl == 2) ANR_PP(2) else if (abl == 3) ANR_PP(3) else if (abl == 4) ANR_PP(4) else
 #endif
-    ANR_PP(0)
-    (void)abl;
+  ANR_PP(0)
+  (void)abl;
+  (void)blocks;
 #undef ANR_PP
-    return;
-  }
-  if constexpr (TN >= 6) {
-    if (g.KB % 3 == 0) {
-      constexpr int lds8 = 3 * 3 * (8 + TN) * 1024;
-      (void)ensure_dynamic_lds(reinterpret_cast<const void *>(&k_gemm_lds8<EPI, TN, 3>), lds8);
-      hipLaunchKernelGGL((k_gemm_lds8<EPI, TN, 3>), dim3((unsigned)blocks), dim3(512), lds8, e->stream, g);
-    } else {  // KB is even (hidden sizes are multiples of 32): two k-steps per slot, e.g. H = 1024 (bge-m3, XLM-R large)
-      constexpr int lds8 = 3 * 2 * (8 + TN) * 1024;
-      (void)ensure_dynamic_lds(reinterpret_cast<const void *>(&k_gemm_lds8<EPI, TN, 2>), lds8);
-      hipLaunchKernelGGL((k_gemm_lds8<EPI, TN, 2>), dim3((unsigned)blocks), dim3(512), lds8, e->stream, g);
-    }
-  }
 }
 
 // small inputs: one workgroup per (feature block, two token blocks), K split over its four waves

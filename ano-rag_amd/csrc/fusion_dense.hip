@@ -1162,6 +1162,16 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
   if (n_arr == 0) return fail(ANR_EINVAL, "no array source: use anr_fuse_lists");
   if (method == 1 && n_arr != 1)
     return fail(ANR_EINVAL, "rrf handles ONE array source (its ranks are counted in the stream); %d given", n_arr);
+  if (method == 1) {
+    // the streaming pass keeps the K' LARGEST raw values of the array source: the best finals only while its weight
+    // is not negative (w / (rrf_k + rank) then grows with the rank, and the lowest-valued ids would win); and its tie
+    // key packs the rank into 28 bits
+    if (!(weights[r1] >= 0.0))
+      return fail(ANR_EINVAL, "rrf: the array source's weight must be >= 0 (%g given): use anr_fuse_rrf_long", weights[r1]);
+    if (src[r1].array_len >= (1ll << 28))
+      return fail(ANR_EINVAL, "rrf: the array source holds %lld entries (at most 2^28 - 1): use anr_fuse_rrf_long",
+                  (long long)src[r1].array_len);
+  }
   // flatten the short lists of all queries into the anr_fuse_lists layout
   std::vector<int64_t> offs((size_t)nq * 5), lids;
   std::vector<double> lsc;

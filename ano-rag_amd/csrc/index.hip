@@ -892,12 +892,29 @@ int search_tiny(anr_index *h, const float *q, int64_t nq, int32_t k, float *D, i
   const size_t q_bytes = (size_t)kTinyMaxQ * h->dim * sizeof(float);
   const size_t d_off = round_up((int64_t)q_bytes, 16), i_off = d_off + (size_t)kTinyMaxQ * kTinyMaxK * 4;
   const size_t f_off = i_off + (size_t)kTinyMaxQ * kTinyMaxK * 8;
-  if (!h->tiny_pin) {
-    ANR_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->tiny_pin), f_off + 64, hipHostMallocDefault));
-    ANR_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&h->tiny_pin_dev), h->tiny_pin, 0));
-    memset(h->tiny_pin + f_off, 0, 64);
-    ANR_TRY(dev_alloc(&h->tiny_cand, (int64_t)kTinyMaxQ * kTinyMaxMerge, true));
-    ANR_TRY(dev_alloc(&h->tiny_ticket, kTinyMaxQ, true));
+  if (!h->tiny_pin || !h->tiny_cand || !h->tiny_ticket) {
+    // first use: the buffers are committed to the handle only as a complete set — a failed allocation leaves nothing
+    // behind that a later call could mistake for an initialised path (it would launch with null list pointers)
+    unsigned char *pin = nullptr, *pin_dev = nullptr;
+    decltype(h->tiny_cand) cand = nullptr;
+    decltype(h->tiny_ticket) ticket = nullptr;
+    int rc = ANR_OK;
+    if (hipHostMalloc(reinterpret_cast<void **>(&pin), f_off + 64, hipHostMallocDefault) != hipSuccess ||
+        hipHostGetDevicePointer(reinterpret_cast<void **>(&pin_dev), pin, 0) != hipSuccess)
+      rc = fail(ANR_EHIP, "tiny search: pinned buffer allocation failed");
+    if (rc == ANR_OK) rc = dev_alloc(&cand, (int64_t)kTinyMaxQ * kTinyMaxMerge, true);
+    if (rc == ANR_OK) rc = dev_alloc(&ticket, kTinyMaxQ, true);
+    if (rc != ANR_OK) {
+      if (pin) (void)hipHostFree(pin);
+      if (cand) (void)hipFree(cand);
+      if (ticket) (void)hipFree(ticket);
+      return rc;
+    }
+    memset(pin + f_off, 0, 64);
+    h->tiny_pin = pin;
+    h->tiny_pin_dev = pin_dev;
+    h->tiny_cand = cand;
+    h->tiny_ticket = ticket;
     if (getenv("ANORAG_TINY_STAMPS")) ANR_TRY(dev_alloc(&h->tiny_stamps, 16, true));
   }
   memcpy(h->tiny_pin, q, (size_t)nq * h->dim * sizeof(float));

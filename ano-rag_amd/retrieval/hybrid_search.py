@@ -150,14 +150,22 @@ class HybridSearcher:
         dicts = [{nid: s for nid, s in (lst or [])} for lst in lists]
         lens = [len(d) for d in dicts]
         rrf = self.fusion_method == "rrf"
+        if pool > _SHORT_MAX:  # beyond the streaming kernel's result capacity (anr_fuse_dense: pool <= 1024)
+            return self._fuse_rrf_long(dicts, pool) if rrf else self._fuse_linear_rounds(dicts, pool)
         order = sorted(range(3 if rrf else 4), key=lambda s: -lens[s])
         arrays = [order[0]]
+
+        def fits(arr):  # the limits anr_fuse_dense checks (csrc/fusion_dense.hip): short-list entries beside the arrays,
+            m = sum(lens[t] for t in range(4) if t not in arr)  # and the entries of the composed lists of its last kernel
+            return m <= _SHORT_MAX and len(arr) * (pool + 2 * m) + m <= _LIST_MAX
+
         if rrf:
-            if sum(lens) - lens[arrays[0]] > _SHORT_MAX:
+            # (a negative weight on the streamed source turns its ranking round: the general path ranks by sorting)
+            if not fits(arrays) or not float(self.weights.get(_SOURCES[arrays[0]], 0.0)) >= 0.0:
                 return self._fuse_rrf_long(dicts, pool)  # two or three long lists: every one ranked by a device sort
         else:
-            for s in order[1:]:
-                if sum(lens[t] for t in range(4) if t not in arrays) <= _SHORT_MAX:
+            for s in order[1:]:  # linear takes any source as an array: promote the next longest until the rest fits
+                if fits(arrays) or not lens[s]:
                     break
                 arrays.append(s)
         # id universe: the first array's ids in ITS list order (rrf ranks ties in list order: array order == list order)
@@ -199,6 +207,65 @@ class HybridSearcher:
                 "final_similarity": float(o_fin[0, j]),
                 "tags": {"source": "graph" if nid in dicts[2] else "semantic", "is_bridge": nid in dicts[3]},
             })
+        return res
+
+    def _fuse_linear_rounds(self, dicts, pool: int) -> List[Dict[str, Any]]:
+        """linear fusion of long lists with ``candidate_pool`` beyond the streaming kernel's 1024 results: every source
+        becomes an array over the query's id universe and the kernel runs in rounds of 1024 — the ids a round returned
+        are marked absent (NaN) for the next one, while each source keeps its ORIGINAL maximum as the normaliser
+        (``row_max``), so every final is the one a single call would give; the order (final, then lower id) is total,
+        so the rounds concatenate to the reference's list.  A rare configuration: one upload per round."""
+        to_int: Dict[Any, int] = {}
+        names: List[Any] = []
+        for d in dicts:
+            for nid in d:
+                if nid not in to_int:
+                    to_int[nid] = len(names)
+                    names.append(nid)
+        if not names:
+            return []
+        host, maxes = {}, {}
+        for s in range(4):
+            if dicts[s]:
+                a = np.full((1, len(names)), np.nan, dtype=np.float64)
+                a[0, [to_int[nid] for nid in dicts[s]]] = [float(v) for v in dicts[s].values()]
+                host[s] = a
+                maxes[s] = DeviceArray.from_numpy(np.fmax.reduce(a, axis=1).reshape(1, 1), self.device)
+        res: List[Dict[str, Any]] = []
+        try:
+            while len(res) < pool:
+                held = []
+                try:
+                    sources = {}
+                    for s, a in host.items():
+                        arr = DeviceArray.from_numpy(a, self.device)
+                        held.append(arr)
+                        arr.row_max = maxes[s]
+                        sources[_SOURCES[s]] = arr
+                    want = min(_SHORT_MAX, pool - len(res))
+                    o_ids, o_fin, _, o_cnt = fuse_dense("linear", self.weights, float(self.rrf_k), want, 1, sources,
+                                                        device=self.device)
+                finally:
+                    for arr in held:
+                        arr.row_max = None  # shared: freed once, below
+                        arr.free()
+                n = int(o_cnt[0])
+                for j in range(n):
+                    i = int(o_ids[0, j])
+                    nid = names[i]
+                    res.append({
+                        "note_id": nid,
+                        "scores": {k: dicts[si].get(nid) for si, k in enumerate(_SOURCES)},
+                        "final_similarity": float(o_fin[0, j]),
+                        "tags": {"source": "graph" if nid in dicts[2] else "semantic", "is_bridge": nid in dicts[3]},
+                    })
+                    for a in host.values():
+                        a[0, i] = np.nan
+                if n < want:
+                    break
+        finally:
+            for m in maxes.values():
+                m.free()
         return res
 
     def _fuse_rrf_long(self, dicts, pool: int) -> List[Dict[str, Any]]:

@@ -15,9 +15,16 @@ all-gathered over RCCL and merged — each batch only after anr_index_wait() has
 
 Rank 0 prints ONE JSON line.  `value` = queries/s of the whole job with the corpus resident in HBM.
 `roofline` is for the dominant kernel (k_scan): algorithmic bytes = rows x 768 x 2 B (the f16 image
-actually streamed) per launch / HIP-event time of that launch.  `cpu_baseline` is the oracle (numpy
-sgemm + argpartition restatement of the reference's faiss-flat path) timed on this box's host cores on
-a bounded row sample and scaled linearly to the full corpus.
+actually streamed) per launch / that kernel's duration.  The duration is taken with HIP events around the
+launch on its own stream in a leg of SERIALISED batches right after the timed region (one batch in flight,
+so the events bracket the kernel and nothing else): inside the timed region three batches are in flight on
+three streams and the same events also span the wait for the previous batch's scan to leave the CUs (that
+figure is kept as `ms_per_launch_overlapped`; in round 2 it was reported as the kernel time and exceeded
+ms_per_step).  `cpu_baseline` is the oracle (numpy sgemm + argpartition restatement of the reference's
+faiss-flat path) timed on this box's host cores on a bounded row sample and scaled linearly to the full corpus.
+`legs` (N = 1 only, untimed extras, never `value`): the other BASELINE.json configurations measured in the same
+driver-run process — the 1.25 M-row shard and the 1 M-row C2 pipeline, the C4 encoder forward (MFMA roofline),
+the C5 N-array fusion (HBM roofline).
 """
 from __future__ import annotations
 
@@ -51,6 +58,9 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--recall-queries", type=int, default=-1,
                     help="queries of the last batch checked against the oracle (-1 = the whole batch, 0 = skip)")
+    ap.add_argument("--no-legs", action="store_true", help="skip the C2 / shard-size / C4 / C5 legs (N = 1 only)")
+    ap.add_argument("--serial-launches", type=int, default=20,
+                    help="serialised batches after the timed region from which the kernel-only scan time is taken")
     ap.add_argument("--no-facade", action="store_true", help="skip the VectorIndex.search (host in, dicts out) leg")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsal)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -162,6 +172,195 @@ def pmc_traffic(rows_per_gpu, dim, notes):
     return p["traffic_bytes_per_launch"] * rows_per_gpu / p["rows"]
 
 
+MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16 / bf16 MFMA peak
+
+
+def serial_kernel_time(idx, Q, first, count, batch, k, d_ptr, i_ptr, stream):
+    """k_scan's own duration: `count` batches issued ONE AT A TIME (sync after each), so the HIP events the library
+    records around the launch (OPT_TIMING) bracket the kernel alone — with several batches in flight they also span
+    the wait for the previous batch's scan to free the CUs.  Returns (ms per launch, bytes per launch)."""
+    idx.sync()
+    idx.reset_stats()
+    for j in range(count):
+        idx.search_device_async(Q[first + j].data_ptr(), batch, k, d_ptr, i_ptr, stream)
+        idx.sync()
+    st = idx.last_stats()
+    idx.reset_stats()
+    return st["scan_ms"] / max(1, count), st["scan_bytes"] / max(1, count)
+
+
+def pipeline_leg(rows, dim, batch, k, dev, seed, steps=60, warmup=10, serial=20):
+    """the search pipeline at another corpus size (the 8-GPU shard, C2): 3-deep asynchronous batches for the per-batch
+    time, then serialised batches for the scan kernel's own time"""
+    from anorag_hip import FlatIndex, METRIC_IP
+    from anorag_hip._lib import OPT_TIMING
+    idx = FlatIndex(dim, METRIC_IP, normalize=True, device=dev.index)
+    idx.reserve(rows)
+    for xb in gen_shard(rows, dim, seed, dev):
+        torch.cuda.synchronize()
+        idx.add_device(xb.data_ptr(), xb.shape[0])
+    del xb
+    idx.set_option(OPT_TIMING, 1)
+    g = torch.Generator(device=dev)
+    g.manual_seed(4321 + seed)
+    nb = warmup + steps
+    Q = torch.randn((nb + serial, batch, dim), generator=g, device=dev, dtype=torch.float32)
+    NS = 3
+    S = [torch.cuda.Stream(device=dev) for _ in range(NS)]
+    D = [torch.empty((batch, k), device=dev, dtype=torch.float32) for _ in range(NS)]
+    I = [torch.empty((batch, k), device=dev, dtype=torch.int64) for _ in range(NS)]
+
+    def run(a, b):
+        for i in range(a, b):
+            idx.search_device_async(Q[i].data_ptr(), batch, k, D[i % NS].data_ptr(), I[i % NS].data_ptr(), S[i % NS].cuda_stream)
+        idx.sync()
+        torch.cuda.synchronize()
+
+    run(0, warmup)
+    idx.reset_stats()
+    t0 = time.perf_counter()
+    run(warmup, nb)
+    dt = (time.perf_counter() - t0) / steps
+    st = idx.last_stats()
+    ms_k, bytes_k = serial_kernel_time(idx, Q, nb, serial, batch, k, D[0].data_ptr(), I[0].data_ptr(), S[0].cuda_stream)
+    idx.close()
+    gbps = bytes_k / 1e9 / (ms_k / 1e3) if ms_k > 0 else None
+    return {"rows": rows, "dim": dim, "batch": batch, "k": k, "ms_per_batch": dt * 1e3, "value": batch / dt,
+            "unit": "queries/s", "batches": steps, "exact_fallback_queries": st["n_fallback"],
+            "scan_ms_per_launch": ms_k, "scan_bytes_per_launch": bytes_k, "scan_GBps": gbps,
+            "scan_frac_hbm": gbps / HBM_PEAK_GBPS if gbps else None,
+            "batch_GBps": bytes_k / 1e9 / dt, "batch_frac_hbm": bytes_k / 1e9 / dt / HBM_PEAK_GBPS}
+
+
+def encoder_leg(dev):
+    """C4's encoder half: bge-base-en SHAPE (12 layers, H 768, 12 heads, I 3072, vocab 30522, CLS pooling + L2
+    normalisation) with seeded random weights — no checkpoint exists offline — token ids in, embeddings left on the
+    device.  flops per SURVEY.md 8d: sum over layers of 2 T (4 H^2 + 2 H I) + 4 B L^2 H with T = B x padded L."""
+    from anorag_hip.encoder import DeviceEncoder
+    LAYERS, H, HEADS, I, V, P = 12, 768, 12, 3072, 30522, 512
+    rng = np.random.default_rng(7)
+
+    def w(*shape, std=0.03):
+        return (rng.standard_normal(shape, dtype=np.float32) * np.float32(std))
+
+    t = {"emb.word": w(V, H), "emb.pos": w(P, H), "emb.type": w(2, H), "emb.ln.g": np.ones(H, np.float32),
+         "emb.ln.b": np.zeros(H, np.float32)}
+    for li in range(LAYERS):
+        for nm, shp in (("q", (H, H)), ("k", (H, H)), ("v", (H, H)), ("o", (H, H)), ("ffn1", (I, H)), ("ffn2", (H, I))):
+            t[f"L{li}.{nm}.w"] = w(*shp)
+            t[f"L{li}.{nm}.b"] = w(shp[0], std=0.01)
+        for ln in ("ln1", "ln2"):
+            t[f"L{li}.{ln}.g"] = np.ones(H, np.float32)
+            t[f"L{li}.{ln}.b"] = np.zeros(H, np.float32)
+    hf = {"num_hidden_layers": LAYERS, "hidden_size": H, "num_attention_heads": HEADS, "intermediate_size": I,
+          "vocab_size": V, "max_position_embeddings": P, "type_vocab_size": 2, "layer_norm_eps": 1e-12}
+    enc = DeviceEncoder(hf, t, pooling="cls", pos_offset=0, device=dev.index)
+    del t
+    out = {"model_shape": "bge-base-en: 12 layers, H 768, 12 heads, I 3072, vocab 30522, CLS + L2 normalise; seeded random weights",
+           "dtype": "f16 MFMA operands and activations, f32 accumulate / LayerNorm", "peak_TFLOPs": MFMA_PEAK_TFLOPS}
+    E = torch.empty((256, H), device=dev, dtype=torch.float32)
+    for name, B, L, ragged in (("b256_l64", 256, 64, False), ("c4_b256_l51_ragged", 256, 51, True)):
+        ids = rng.integers(5, 30000, size=(B, L)).astype(np.int32)
+        lens = (rng.integers(27, L + 1, size=B) if ragged else np.full(B, L)).astype(np.int32)
+        if ragged:
+            lens[0] = L
+        types = np.zeros_like(ids)
+        for _ in range(3):
+            enc.forward_device(ids, lens, types, True, E.data_ptr())
+        n = 10
+        t0 = time.perf_counter()
+        for _ in range(n):
+            enc.forward_device(ids, lens, types, True, E.data_ptr())
+        dt = (time.perf_counter() - t0) / n
+        Lp = (L + 31) // 32 * 32
+        T = B * Lp
+        flops = LAYERS * (2 * T * (4 * H * H + 2 * H * I) + 4 * B * Lp * Lp * H)
+        out[name] = {"sequences": B, "max_len": L, "padded_tokens": T, "ms_per_forward": dt * 1e3,
+                     "TFLOPs": flops / dt / 1e12, "frac_mfma_peak": flops / dt / 1e12 / MFMA_PEAK_TFLOPS,
+                     "sequences_per_s": B / dt,
+                     "note": "host ids in (H2D of ids included), embeddings left on the device, synchronous"}
+    return out, enc, E
+
+
+def c4_leg(dev, rows=1_000_000, dim=768, k=100):
+    """C4: encode 256 queries (bge-base-en shape) and search them over 1 M x 768 notes — token ids in, ids/scores out"""
+    from anorag_hip import FlatIndex, METRIC_IP
+    out, enc, E = encoder_leg(dev)
+    idx = FlatIndex(dim, METRIC_IP, normalize=True, device=dev.index)
+    idx.reserve(rows)
+    for xb in gen_shard(rows, dim, 77, dev):
+        torch.cuda.synchronize()
+        idx.add_device(xb.data_ptr(), xb.shape[0])
+    del xb
+    rng = np.random.default_rng(8)
+    B, L = 256, 51
+    ids = rng.integers(5, 30000, size=(B, L)).astype(np.int32)
+    lens = rng.integers(27, L + 1, size=B).astype(np.int32)
+    types = np.zeros_like(ids)
+
+    def once():
+        enc.forward_device(ids, lens, types, True, E.data_ptr())
+        return idx.search_device_queries(E.data_ptr(), B, k)
+
+    for _ in range(2):
+        once()
+    n = 5
+    t0 = time.perf_counter()
+    for _ in range(n):
+        D, I = once()
+    dt = (time.perf_counter() - t0) / n
+    out["encode_plus_search_1m"] = {"queries": B, "rows": rows, "k": k, "ms_per_256_queries": dt * 1e3, "value": B / dt,
+                                    "unit": "queries/s", "note": "token ids in (tokeniser not included), top-k ids and scores "
+                                    "out in host memory; the encoder's output never leaves the device"}
+    idx.close()
+    enc.close()
+    return out
+
+
+def c5_leg(dev, nq=200, nn=1_000_000, pool=80):
+    """C5's fusion half: HybridSearcher.fuse's arithmetic with bm25 = the FULL N-note score vector per query (what
+    bm25_scores() returns: one float64 per note, ~0.1 % non-zero, divided by its maximum) resident on the device and
+    dense = a top-100 list per query; algorithmic bytes = N x 8 (float64) or N x 4 (float32 arrays) per query."""
+    from anorag_hip.fusion import DeviceArray, fuse_dense
+    g = torch.Generator(device=dev)
+    g.manual_seed(99)
+    bm = torch.zeros((nq, nn), device=dev, dtype=torch.float64)
+    pos = torch.randint(0, nn, (nq, nn // 1000), generator=g, device=dev)
+    val = torch.randn((nq, nn // 1000), generator=g, device=dev, dtype=torch.float64).abs()
+    bm.scatter_(1, pos, val)
+    mx = bm.max(dim=1, keepdim=True).values.contiguous()
+    bm /= mx
+    one = torch.ones_like(mx)
+    bm32 = bm.to(torch.float32)
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(99)
+    dense = [(rng.choice(nn, 100, replace=False).astype(np.int64), np.sort(rng.random(100))[::-1].copy()) for _ in range(nq)]
+    w = {"dense": 1.0, "bm25": 0.5, "graph": 0.5, "path": 0.1}
+    res = {"queries": nq, "notes": nn, "pool": pool, "nonzero_per_query": nn // 1000}
+    for label, method, arr_t, with_max in (("linear_f64_max_known", "linear", bm, True), ("linear_f64", "linear", bm, False),
+                                           ("rrf_f64", "rrf", bm, False), ("linear_f32_max_known", "linear", bm32, True),
+                                           ("rrf_f32", "rrf", bm32, False)):
+        dt_np = np.float64 if arr_t.dtype == torch.float64 else np.float32
+        rm = DeviceArray.wrap(one.data_ptr(), nq, 1, np.float64, dev.index) if with_max else None
+        arr = DeviceArray.wrap(arr_t.data_ptr(), nq, nn, dt_np, dev.index, row_max=rm)
+        fuse_dense(method, w, 60.0, pool, nq, {"dense": dense, "bm25": arr}, device=dev.index)
+        best = None
+        for _ in range(4):
+            t0 = time.perf_counter()
+            o = fuse_dense(method, w, 60.0, pool, nq, {"dense": dense, "bm25": arr}, device=dev.index, want_stats=True)
+            dt = time.perf_counter() - t0
+            if best is None or o[4]["scan_ms"] < best[0]["scan_ms"]:
+                best = (o[4], dt)
+        st, dt = best
+        gbps = st["scan_bytes"] / 1e9 / (st["scan_ms"] / 1e3)
+        res[label] = {"streaming_kernels_ms": st["scan_ms"], "algorithmic_GB": st["scan_bytes"] / 1e9, "GBps": gbps,
+                      "frac_hbm": gbps / HBM_PEAK_GBPS, "call_ms": dt * 1e3, "candidates_per_query": st["n_candidates"] / nq}
+    del bm, bm32
+    torch.cuda.empty_cache()
+    return res
+
+
+
 def facade_leg(idx, args, q_host):
     """The reference-facing call: VectorIndex.search(np.ndarray[B, D], top_k) -> list of per-query lists of dicts
     (reference vector_store/vector_index.py:206-263), timed end to end on the same resident corpus."""
@@ -227,23 +426,26 @@ def main():
     idx.set_option(OPT_TIMING, 1)
 
     nb = args.steps + args.warmup
+    n_serial = max(0, args.serial_launches)
     gq = torch.Generator(device=dev)
     gq.manual_seed(4321)
-    Q = torch.randn((nb, args.batch, args.dim), generator=gq, device=dev, dtype=torch.float32)
+    Q = torch.randn((nb + n_serial, args.batch, args.dim), generator=gq, device=dev, dtype=torch.float32)
     # steps are issued asynchronously and overlap (the small kernels of neighbouring batches run beside the scan):
     # NSLOT rotating sets of output buffers and streams
     NSLOT = 3
     streams = [torch.cuda.Stream(device=dev) for _ in range(NSLOT)]
     # per slot one packed result buffer [B*k f32 | B*k i64]: the index writes both halves, and for N > 1 the
     # partial top-k lists of all ranks travel in ONE all-gather
+    from anorag_hip.sharded import packed_layout
     nres = args.batch * args.k
-    Pl = [torch.empty(nres * 12, device=dev, dtype=torch.uint8) for _ in range(NSLOT)]
+    id_off, part = packed_layout(nres)  # [nres f32 | pad to 8 B | nres i64]
+    Pl = [torch.empty(part, device=dev, dtype=torch.uint8) for _ in range(NSLOT)]
     Dl = [p[: nres * 4].view(torch.float32).view(args.batch, args.k) for p in Pl]
-    Il = [p[nres * 4:].view(torch.int64).view(args.batch, args.k) for p in Pl]
+    Il = [p[id_off:].view(torch.int64).view(args.batch, args.k) for p in Pl]
     if dist_on:
         from anorag_hip._lib import OPT_ID_OFFSET
         idx.set_option(OPT_ID_OFFSET, row0)  # the shard returns global ids (no -1 padding: every shard holds >= k rows)
-        Pg = [torch.empty(world * nres * 12, device=dev, dtype=torch.uint8) for _ in range(NSLOT)]
+        Pg = [torch.empty(world * part, device=dev, dtype=torch.uint8) for _ in range(NSLOT)]
         Dm = [torch.empty_like(Dl[0]) for _ in range(NSLOT)]
         Im = [torch.empty_like(Il[0]) for _ in range(NSLOT)]
     lib = _lib.load()
@@ -264,12 +466,12 @@ def main():
                 dist.all_gather_into_tensor(Pg[s], Pl[s])
             else:  # rehearsal path (gloo has no all_gather_into_tensor for device tensors)
                 st.synchronize()
-                ph = [torch.empty(nres * 12, dtype=torch.uint8) for _ in range(world)]
+                ph = [torch.empty(part, dtype=torch.uint8) for _ in range(world)]
                 dist.all_gather(ph, Pl[s].cpu())
                 Pg[s].copy_(torch.cat(ph))
             _lib.check(lib.anr_merge_topk_strided_dev(
-                local_rank, C.c_void_p(Pg[s].data_ptr()), C.c_void_p(Pg[s].data_ptr() + nres * 4),
-                nres * 3, (nres * 3) // 2, world, args.batch, args.k, 1,
+                local_rank, C.c_void_p(Pg[s].data_ptr()), C.c_void_p(Pg[s].data_ptr() + id_off),
+                part // 4, part // 8, world, args.batch, args.k, 1,
                 C.c_void_p(Dm[s].data_ptr()), C.c_void_p(Im[s].data_ptr()),
                 C.c_void_p(st.cuda_stream)), "anr_merge_topk_strided_dev")
         merged["last"] = (Dm[s], Im[s])
@@ -314,6 +516,10 @@ def main():
         t = torch.tensor([dt], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # the scan kernel's own duration (rank 0's shard): serialised batches, outside the timed region
+    Dk, Ik = Dl[0].clone(), Il[0].clone()  # scratch outputs: the last timed batch's results stay untouched
+    ker_ms, ker_bytes = (serial_kernel_time(idx, Q, nb, n_serial, args.batch, args.k, Dk.data_ptr(), Ik.data_ptr(),
+                                            streams[0].cuda_stream) if n_serial else (None, None))
 
     # the reference-facing call is timed BEFORE the CPU legs: after the oracle's 10 M-row BLAS passes (recall) the same
     # loop ran 2.3x slower on two boxes (6.4 vs 2.8 ms per call) — host threads left spinning, nothing on the device
@@ -342,11 +548,34 @@ def main():
         if rank == 0:
             recall = recall_from_partials(parts, I_gpu, args.k)
 
+    legs = None
+    if rank == 0 and world == 1 and not args.no_legs:
+        # the other BASELINE.json configurations, in the same driver-run process (before the CPU legs: host threads left
+        # spinning by BLAS stretch launch loops several-fold)
+        legs = {}
+        for name, fn in (("shard_1250k", lambda: pipeline_leg(1_250_000, args.dim, args.batch, args.k, dev, 11)),
+                         ("c2_1m", lambda: pipeline_leg(1_000_000, args.dim, args.batch, args.k, dev, 12)),
+                         ("c4", lambda: c4_leg(dev)), ("c5", lambda: c5_leg(dev))):
+            try:
+                legs[name] = fn()
+            except Exception as e:  # a failing extra leg must not cost the headline line
+                legs[name] = {"error": f"{type(e).__name__}: {e}"}
+                print(f"bench.py: leg {name} failed: {e}", file=sys.stderr)
+            torch.cuda.empty_cache()
+
     if rank == 0:
         tnotes = []
         traffic = pmc_traffic(per, args.dim, tnotes)
         qps = args.batch * args.steps / dt
-        achieved = (scan_bytes / 1e9) / (scan_ms / 1e3) if scan_ms > 0 else None
+        ms_step = dt / args.steps * 1e3
+        if ker_ms:
+            achieved = (ker_bytes / 1e9) / (ker_ms / 1e3)
+        else:
+            achieved = (scan_bytes / 1e9) / (scan_ms / 1e3) if scan_ms > 0 else None
+        ms_launch = ker_ms if ker_ms else scan_ms / max(1, args.steps)
+        consistent = bool(ms_launch <= ms_step * 1.005)
+        if not consistent:
+            print(f"bench.py: kernel time per launch {ms_launch:.4f} ms exceeds the step time {ms_step:.4f} ms", file=sys.stderr)
         out = {
             "metric": "queries/sec + recall@k vs CPU ref, 10M×768 corpus, batch-64 top-100",
             "value": qps,
@@ -383,10 +612,18 @@ def main():
                 "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
                 "traffic": traffic,
                 "traffic_note": "; ".join(tnotes),
-                "bytes_per_launch": scan_bytes / max(1, args.steps),
-                "ms_per_launch": scan_ms / max(1, args.steps),
+                "bytes_per_launch": ker_bytes if ker_ms else scan_bytes / max(1, args.steps),
+                "ms_per_launch": ms_launch,
+                "launches_timed": n_serial if ker_ms else args.steps,
+                "timing": ("HIP events around the launch on its stream, serialised batches after the timed region"
+                           if ker_ms else "HIP events around the launch, batches overlapping (includes waits for CUs)"),
+                "ms_per_launch_overlapped": scan_ms / max(1, args.steps),
+                "launch_le_step": consistent,
+                "frac_end_to_end": (scan_bytes / max(1, args.steps) / 1e9) / (ms_step / 1e3) / HBM_PEAK_GBPS,
             },
         }
+        if legs is not None:
+            out["legs"] = legs
         if facade is not None:
             out["facade"] = facade
         if not args.no_cpu and world == 1:
