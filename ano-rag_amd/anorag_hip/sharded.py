@@ -240,11 +240,14 @@ class ShardedSearcher:
     callable (numpy in / numpy out) for shard searches that do not come from the library (the CPU test uses the
     oracle).  ``search`` returns the merged global top-k on every rank."""
 
-    def __init__(self, index_or_search, row_offset: int, larger_is_better: Optional[bool] = None, group=None):
+    def __init__(self, index_or_search, row_offset: int, larger_is_better: Optional[bool] = None, group=None,
+                 force_device: bool = False):
+        """force_device: take the RCCL device path even with a single rank (a world-size-1 rehearsal of the exchange)"""
         import torch.distributed as dist
         self.dist = dist
         self.row_offset = int(row_offset)
         self.group = group
+        self.force_device = bool(force_device)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.backend = dist.get_backend(group) if dist.is_initialized() else None
         self.index = None
@@ -313,7 +316,7 @@ class ShardedSearcher:
 
     def search(self, q: np.ndarray, k: int):
         q = np.asarray(q)
-        if self.index is not None and self.backend == "nccl" and self.world > 1:
+        if self.index is not None and self.backend == "nccl" and (self.world > 1 or self.force_device):
             return self._search_device(q, int(k))
         return self._search_host(q, int(k))
 

@@ -22,8 +22,12 @@ import numpy as np
 
 
 def make_synthetic_model(path: str, *, layers=6, hidden=384, heads=12, intermediate=1536, vocab=2048, max_pos=512,
-                         pooling="mean", seed=0, weight_std=0.05, model_type="bert") -> str:
-    """Write an HF/sentence-transformers style model directory with seeded random weights."""
+                         pooling="mean", seed=0, weight_std=0.05, model_type="bert", outlier_dims=0,
+                         outlier_gain=30.0) -> str:
+    """Write an HF/sentence-transformers style model directory with seeded random weights.
+    outlier_dims > 0: that many hidden dimensions carry OUTLIER FEATURES, as trained BERT-family checkpoints do — every
+    LayerNorm's gain on them is multiplied by outlier_gain (x 20-40) and the word-embedding columns likewise, so their
+    activations reach the tens to hundreds while the rest stay O(1) (the stress case for an f16 residual stream)."""
     import torch
     from transformers import BertConfig, BertModel, MPNetConfig, MPNetModel, XLMRobertaConfig, XLMRobertaModel
 
@@ -66,6 +70,15 @@ def make_synthetic_model(path: str, *, layers=6, hidden=384, heads=12, intermedi
                 p.copy_(1.0 + 0.1 * torch.randn_like(p))
             elif n.endswith("bias"):
                 p.copy_(0.05 * torch.randn_like(p))
+        if outlier_dims:
+            dims = torch.tensor(np.random.default_rng(seed + 1).choice(hidden, size=int(outlier_dims), replace=False))
+            gains = torch.tensor(np.random.default_rng(seed + 2).uniform(0.7, 1.3, int(outlier_dims)) * outlier_gain,
+                                 dtype=torch.float32)
+            for n, p in model.named_parameters():
+                if "LayerNorm.weight" in n:
+                    p[dims] *= gains
+                elif n.endswith("word_embeddings.weight"):
+                    p[:, dims] *= gains
     model.eval()
     model.save_pretrained(path, safe_serialization=True)
     with open(os.path.join(path, "tokenizer_config.json"), "w") as f:

@@ -148,8 +148,40 @@ def test_c4_full_shape_bge_base_12_layers_batch256_encode_then_search_1m(tmp_pat
     assert np.max(np.abs(D - S[:, :k].astype(np.float32))) <= 1e-4
     _, I_ref_emb = top_ref.result()
     recall = np.mean([len(set(I[r]) & set(I_ref_emb[r])) / k for r in range(256)])
+    print(f"C4 end to end: recall@100 of the device-embedding search vs the oracle-embedding search = {recall:.4f}, "
+          f"min cosine {cos.min():.7f}")
     assert recall >= 0.85, recall
     idx.close()
+
+
+def test_outlier_features_bge_base_12_layers(tmp_path):
+    """The f16 activation / residual stream under OUTLIER FEATURES (trained BERT-family checkpoints carry a few hidden
+    dimensions whose LayerNorm gains are tens of times the rest: activations in the tens to hundreds, where f16 resolves
+    0.03-0.06): 6 dimensions with gain x 21-39 in every LayerNorm and in the word embeddings, full 12-layer bge-base
+    shape.  Same bar as the benign-weight tests."""
+    from anorag_hip.encoder import SentenceEncoder
+    d = oenc.make_synthetic_model(str(tmp_path / "model"), layers=12, hidden=768, heads=12, intermediate=3072, pooling="cls",
+                                  weight_std=0.02, outlier_dims=6, outlier_gain=30.0)
+    sents = oenc.synthetic_sentences(d, 40)
+    ref = oenc.encode(d, sents, batch_size=16, normalize=True)
+    enc = SentenceEncoder(d)
+    got = enc.encode(sents, batch_size=16, normalize_embeddings=True)
+    cos = np.sum(got * ref, axis=1)
+    print(f"outlier features, bge-base 12 layers: min cosine {cos.min():.7f}, max |diff| {np.max(np.abs(got - ref)):.2e}")
+    assert cos.min() >= 0.9995, cos.min()
+    assert np.max(np.abs(got - ref)) <= 5e-3
+    # the outlier dimensions really carry large activations: the un-normalised CLS output on them is >> the rest
+    enc._info["normalize_module"] = False
+    raw = enc.encode(sents, batch_size=16, normalize_embeddings=False)
+    mag = np.sort(np.abs(raw).max(axis=0))
+    assert mag[-6] >= 20 * np.median(mag), (mag[-6], np.median(mag))
+    enc.close()
+
+
+def test_outlier_features_xlm_roberta_large_24_layers(tmp_path):
+    """the same stress at the bge-m3 shape (XLM-R large: 24 layers, H 1024, 16 heads, I 4096)"""
+    _check(tmp_path, n=32, layers=24, hidden=1024, heads=16, intermediate=4096, pooling="cls", model_type="xlm-roberta",
+           max_pos=512, weight_std=0.02, outlier_dims=5, outlier_gain=30.0)
 
 
 def test_xlm_roberta_large_shape_24_layers(tmp_path):

@@ -1,0 +1,303 @@
+"""The Python-level logic of the three drop-in classes against fixtures produced by RUNNING the reference's own files
+(tests/golden/make_facade_golden.py; faiss / sentence-transformers replaced there by labelled stand-ins, so these
+fixtures pin the reference's Python around those libraries — result shaping, preprocessing, thresholds, multipliers,
+text assembly — not the libraries themselves):
+
+  rows a3 / a4 / a6 / a7  vector_store/embedding_manager.py:374-407, :409-549, :551-584
+  rows b5 / b6            vector_store/vector_index.py:226-259, :265-282
+  rows c1 / c3 / c5       vector_store/retriever.py:32-116 (defaults), :186-272, :339-512
+
+CPU tests drive the classes with a numpy index in the place of the device index (host logic only, no compute through
+the C ABI); the `gpu` tests run the same cases through the real FlatIndex."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _load(name):
+    with open(os.path.join(HERE, "golden", name)) as f:
+        return json.load(f)
+
+
+def _same(a, b, tol, path="$"):
+    """structural equality: same types / keys (in order) / lengths; floats within tol"""
+    if isinstance(b, float) or isinstance(a, float):
+        assert isinstance(a, (int, float)) and isinstance(b, (int, float)), f"{path}: {a!r} vs {b!r}"
+        assert (math.isnan(a) and math.isnan(b)) or abs(a - b) <= tol, f"{path}: {a!r} vs {b!r}"
+    elif isinstance(b, dict):
+        assert isinstance(a, dict) and list(a) == list(b), f"{path}: keys {list(a) if isinstance(a, dict) else a!r} vs {list(b)}"
+        for k in b:
+            _same(a[k], b[k], tol, f"{path}.{k}")
+    elif isinstance(b, list):
+        assert isinstance(a, list) and len(a) == len(b), f"{path}: length {len(a) if isinstance(a, list) else a!r} vs {len(b)}"
+        for i, (x, y) in enumerate(zip(a, b)):
+            _same(x, y, tol, f"{path}[{i}]")
+    else:
+        assert a == b and type(a) is type(b), f"{path}: {a!r} vs {b!r}"
+
+
+class _NumpyFlat:
+    """host stand-in for anorag_hip.FlatIndex in the CPU tests: exact search in numpy (rows normalised at add, queries
+    at search, like the device index created with normalize=True)"""
+
+    def __init__(self, d, ip, normalize):
+        self.d, self.ip, self.normalize, self.metric = d, ip, normalize, 0 if ip else 1
+        self.x = np.zeros((0, d), np.float32)
+
+    @property
+    def ntotal(self):
+        return self.x.shape[0]
+
+    @staticmethod
+    def _prep(v, normalize):
+        v = np.ascontiguousarray(v, dtype=np.float32)
+        if normalize:
+            n = np.linalg.norm(v, axis=1, keepdims=True)
+            v = v / np.where(n == 0, 1, n)
+        return v
+
+    def add(self, v):
+        self.x = np.vstack([self.x, self._prep(v, self.normalize)])
+
+    def search(self, q, k):
+        q = self._prep(q, self.normalize)
+        if self.ip:
+            s = q @ self.x.T
+            order = np.argsort(-s, axis=1, kind="stable")
+        else:
+            s = ((q[:, None, :] - self.x[None, :, :]) ** 2).sum(-1).astype(np.float32)
+            order = np.argsort(s, axis=1, kind="stable")
+        kk = min(k, self.ntotal)
+        I = np.full((q.shape[0], k), -1, np.int64)
+        D = np.full((q.shape[0], k), -3.4028235e38 if self.ip else 3.4028235e38, np.float32)
+        I[:, :kk] = order[:, :kk]
+        D[:, :kk] = np.take_along_axis(s, order[:, :kk], axis=1)
+        return D, I
+
+    def close(self):
+        pass
+
+
+class _ReplayIndex:
+    """returns the (scores, indices) a fixture recorded"""
+
+    def __init__(self, D, I):
+        self.D, self.I, self.ntotal = np.asarray(D, np.float32), np.asarray(I, np.int64), 1
+
+    def search(self, q, k):
+        return self.D, self.I
+
+
+# ---- embedding_manager.py -----------------------------------------------------------------------------------------
+class _RecordingModel:
+    def __init__(self, dim, table=None):
+        self.calls, self.dim, self.table, self.fail = [], dim, table or {}, False
+
+    def encode(self, texts, **kw):
+        self.calls.append({"texts": list(texts), "kwargs": dict(kw)})
+        if self.fail:
+            raise RuntimeError("asked to fail")
+        out = np.zeros((len(texts), self.dim), np.float32)
+        for i, t in enumerate(texts):
+            out[i] = self.table.get(t, 0.0)
+        return out
+
+    def get_sentence_embedding_dimension(self):
+        return self.dim
+
+
+def _manager(dim, model_name="BAAI/bge-m3", table=None):
+    from vector_store.embedding_manager import EmbeddingManager
+    em = object.__new__(EmbeddingManager)   # the constructor needs a model directory and a device; the methods do not
+    em.model = _RecordingModel(dim, table)
+    em.model_name, em.batch_size, em.device, em.max_length = model_name, 32, "cpu", 512
+    em.normalize_embeddings, em.embedding_dim, em.hip_device = True, dim, 0
+    return em
+
+
+def test_note_text_assembly_matches_the_reference():
+    g = _load("embedding_manager_facade_cases.json")
+    em = _manager(4)
+    c = g["encode_atomic_notes"]
+    em.encode_atomic_notes(c["notes"])
+    assert em.model.calls[-1]["texts"] == c["texts_given_to_encoder"]
+    kw = {k: (v if isinstance(v, (int, float, bool, str, type(None))) else str(v)) for k, v in em.model.calls[-1]["kwargs"].items()}
+    assert kw == c["encode_kwargs"]
+    r = em.encode_atomic_notes([])
+    assert list(r.shape) == g["encode_atomic_notes_empty"]["shape"] and str(r.dtype) == g["encode_atomic_notes_empty"]["dtype"]
+
+
+def test_preprocess_texts_matches_the_reference():
+    g = _load("embedding_manager_facade_cases.json")
+    em = _manager(4)
+    for key in ("preprocess_texts", "preprocess_texts_short_limit"):
+        em.max_length = g[key]["max_length"]
+        assert em._preprocess_texts(g[key]["input"]) == g[key]["expected"]
+
+
+def test_query_prefix_rule_and_sentinels_match_the_reference():
+    g = _load("embedding_manager_facade_cases.json")
+    c = g["encode_queries"]
+    for key, texts in c["texts_given_to_encoder"].items():
+        name, _, flag = key.partition("|")
+        em = _manager(4, model_name=name)
+        if flag:
+            em.encode_queries(c["queries"], query_prefix="")
+        else:
+            em.encode_queries(c["queries"])
+        assert em.model.calls[-1]["texts"] == texts, key
+    em = _manager(4)
+    r = em.encode_texts([])
+    assert list(r.shape) == g["encode_texts_empty"]["shape"] and str(r.dtype) == g["encode_texts_empty"]["dtype"]
+    em.model.fail = True
+    r = em.encode_texts(["a", "b", "c"])
+    f = g["encode_texts_failure"]
+    assert list(r.shape) == f["shape"] and str(r.dtype) == f["dtype"] and bool((r == 0).all()) == f["all_zero"]
+    em.model.fail = False
+    em.encode_texts(["t"], batch_size=7, show_progress=False, normalize=False)
+    assert em.model.calls[-1]["kwargs"] == g["encode_texts_kwargs"]
+
+
+# ---- vector_index.py ------------------------------------------------------------------------------------------------
+def _index_for(case, backend):
+    from vector_store.vector_index import VectorIndex
+    d = len(case["vectors"][0]) if case["vectors"] else (len(case["queries"][0]) if case["queries_ndim"] == 2 else len(case["queries"]))
+    vi = VectorIndex(d)
+    vi.index_type, vi.similarity_metric = case["index_type"], case["metric"]
+    return vi, d
+
+
+def test_preprocess_vectors_matches_the_reference():
+    from oracle import flat_index as orc
+    from vector_store.vector_index import VectorIndex
+    g = _load("vector_index_facade_cases.json")
+    for c in g["preprocess"]:
+        x = np.array(c["input"], dtype=np.dtype(c["input_dtype"]))
+        if not c["input_c_contiguous"]:
+            x = np.asfortranarray(x)
+        vi = VectorIndex(x.shape[1])
+        vi.similarity_metric = c["metric"]
+        out = vi._preprocess_vectors(x)
+        exp = np.array(c["expected"], dtype=np.dtype(c["expected_dtype"]))
+        assert str(out.dtype) == c["expected_dtype"] and bool(out.flags["C_CONTIGUOUS"]) == c["expected_c_contiguous"], c["name"]
+        assert np.array_equal(out, exp), c["name"]
+        if c["metric"] == "cosine":  # the oracle's restatement of the same lines is pinned by the same fixture
+            assert np.array_equal(orc.preprocess_vectors(x), exp), c["name"]
+
+
+def test_search_shaping_matches_the_reference():
+    """the reference's result loop on the (scores, indices) its index returned == this build's shaping of the same arrays
+    (C extension and Python loop), through VectorIndex.search's own guards (empty index, 1-D input, flat vs nested)"""
+    from vector_store import vector_index as vim
+    g = _load("vector_index_facade_cases.json")
+    for c in g["search"]:
+        vi, d = _index_for(c, None)
+        q = np.array(c["queries"], dtype=np.float32)
+        if c["raw_scores"] is None:
+            vi.index, vi.total_vectors = _ReplayIndex(np.zeros((1, 1)), np.zeros((1, 1))), c["total_vectors"]
+            assert vi.search(q, top_k=c["top_k"]) == c["expected"] == [], c["name"]
+            continue
+        vi.index, vi.total_vectors = _ReplayIndex(c["raw_scores"], c["raw_indices"]), c["total_vectors"]
+        got = vi.search(q, top_k=c["top_k"])
+        _same(got, c["expected"], 0.0, c["name"])
+        saved, vim._pyshape = vim._pyshape, None   # the Python loop builds the same objects
+        try:
+            _same(vi.search(q, top_k=c["top_k"]), c["expected"], 0.0, c["name"] + "/py")
+        finally:
+            vim._pyshape = saved
+    assert vim.VectorIndex(8).search(np.zeros((1, 8), np.float32)) == []   # no index created yet
+
+
+# ---- retriever.py ---------------------------------------------------------------------------------------------------
+def _retriever(case, make_index):
+    from vector_store import embedding_manager as emm
+    from vector_store.retriever import VectorRetriever
+    emb = np.array(case["note_embeddings"], dtype=np.float32) if case["note_embeddings"] else np.zeros((0, 8), np.float32)
+    d = emb.shape[1]
+    table = {k: np.array(v, dtype=np.float32) for k, v in case["query_vectors"].items()}
+    em = _manager(d, table=table)
+    old = (emm.EmbeddingManager._instance, emm.EmbeddingManager._model_loaded)
+    emm.EmbeddingManager._instance, emm.EmbeddingManager._model_loaded = em, True
+    try:
+        r = VectorRetriever()
+    finally:
+        emm.EmbeddingManager._instance, emm.EmbeddingManager._model_loaded = old
+    r.atomic_notes = case["notes"]
+    r.note_embeddings = emb
+    r._build_id_mappings()
+    vi = r.vector_index
+    vi.index_type, vi.similarity_metric = "Flat", "cosine"
+    make_index(vi, emb)
+    return r, em
+
+
+def _numpy_backend(vi, emb):
+    vi.index = _NumpyFlat(emb.shape[1], True, True)
+    vi.index.add(emb)
+    vi.is_trained, vi.total_vectors = True, emb.shape[0]
+
+
+def _device_backend(vi, emb):
+    assert vi.create_index()
+    assert vi.add_vectors(emb, np.arange(emb.shape[0], dtype=np.int64))
+
+
+def _filter_from(spec):
+    mod = spec["paragraph_mod"]
+    return lambda c: 1 // (c["paragraph_idxs"][0] - mod["raise_on"]) and c["paragraph_idxs"][0] != mod["reject"]
+
+
+def _run_retriever_cases(make_index, tol):
+    g = _load("retriever_facade_cases.json")
+    checked_defaults = False
+    for c in g["cases"]:
+        r, em = _retriever(c, make_index)
+        if not checked_defaults:
+            for k, v in g["defaults"].items():
+                assert getattr(r, k) == v, k
+            checked_defaults = True
+        if c["kind"] == "search":
+            got = r.search(c["queries"], **c["kwargs"])
+            if c["encoder_texts"] is not None:
+                assert em.model.calls[-1]["texts"] == c["encoder_texts"], c["name"]
+        else:
+            kw = dict(c["kwargs"])
+            if c["filter_spec"] is not None:
+                kw["filter_fn"] = _filter_from(c["filter_spec"])
+            got = r.retrieve(c["query"], **kw)
+        _same(got, c["expected"], tol, c["name"])
+        if getattr(r.vector_index.index, "close", None):
+            r.vector_index.index.close()
+
+
+def test_retriever_search_and_retrieve_match_the_reference_host_logic():
+    _run_retriever_cases(_numpy_backend, 1e-6)
+
+
+@pytest.mark.gpu
+def test_retriever_search_and_retrieve_match_the_reference_on_the_device():
+    """the same fixtures through the real device index: ids, order, keys, adjustments identical, scores within 1e-4"""
+    _run_retriever_cases(_device_backend, 1e-4)
+
+
+@pytest.mark.gpu
+def test_vector_index_search_matches_the_reference_on_the_device():
+    from vector_store.vector_index import VectorIndex
+    g = _load("vector_index_facade_cases.json")
+    for c in g["search"]:
+        if not c["vectors"]:
+            continue
+        vi, d = _index_for(c, None)
+        assert vi.create_index()
+        assert vi.add_vectors(np.array(c["vectors"], dtype=np.float32))
+        q = np.array(c["queries"], dtype=np.float32 if c["name"] != "float64_queries" else np.float64)
+        got = vi.search(q, top_k=c["top_k"])
+        if c["name"] == "zero_row_in_corpus":   # the zero row scores exactly 0 for every query: its rank is well defined
+            pass
+        _same(got, c["expected"], 1e-4, c["name"])
+        vi.cleanup()

@@ -119,15 +119,65 @@ def test_fuse_long_lists_with_string_ids_and_an_unsorted_long_list():
         _compare(got, exp, 70, method)
 
 
+def _long_lists(rng, n, sizes):
+    """(dense, bm25, graph, path) lists with the given entry counts over note ids note_00000 .. note_{n-1}"""
+    out = []
+    for m in sizes:
+        pick = rng.choice(n, m, replace=False)
+        out.append([(f"note_{int(i):05d}", float(s)) for i, s in zip(pick, rng.uniform(0.01, 1.0, m))])
+    return out
+
+
+@pytest.mark.parametrize("sizes,pool", [((5000, 5000, 900, 0), 50),      # two long lists + 900 graph hits: linear must
+                                         ((5000, 5000, 900, 300), 50),    # promote the third source too (ADVICE r2)
+                                         ((4100, 700, 600, 500), 80),
+                                         ((6000, 10, 5, 3), 1500),         # candidate_pool beyond the kernel's 1024 results
+                                         ((3000, 2500, 40, 20), 2600)])
+@pytest.mark.parametrize("method", ["linear", "rrf"])
+def test_fuse_accepts_every_combination_of_long_lists(sizes, pool, method):
+    """HybridSearcher.fuse must not refuse an input the reference accepts: several long lists beside many short
+    entries (n_arr * (pool + 2 m) + m <= 4096 inside anr_fuse_dense decides how many sources go as arrays) and
+    candidate_pool > 1024 (linear: rounds of 1024 with the selected ids masked; rrf: the sorting path)"""
+    from retrieval.hybrid_search import HybridSearcher
+    rng = np.random.default_rng(sum(sizes) + pool)
+    dense, bm25, graph, path = _long_lists(rng, 9000, sizes)
+    w = {"dense": 1.0, "bm25": 0.5, "graph": 0.5, "path": 0.1}
+    hs = HybridSearcher({"retrieval": {"candidate_pool": pool, "hybrid": {"enabled": True, "fusion_method": method, "rrf_k": 60,
+                                                                         "weights": w}}})
+    got = hs.fuse(dense, bm25, graph, path)
+    exp = ofu.fuse(dense, bm25, graph, path, candidate_pool=pool, fusion_method=method, weights=w, rrf_k=60)
+    _compare(got, exp, pool, method)
+
+
+def test_rrf_negative_weight_on_the_long_list_takes_the_sorting_path():
+    """a negative weight on the streamed source turns its ranking round (the best finals are the LOWEST-valued ids):
+    anr_fuse_dense rejects it, HybridSearcher.fuse routes the query to anr_fuse_rrf_long — same result as the reference"""
+    from anorag_hip import AnoragError
+    from anorag_hip.fusion import DeviceArray, fuse_dense
+    from retrieval.hybrid_search import HybridSearcher
+    rng = np.random.default_rng(77)
+    dense, bm25, graph, path = _long_lists(rng, 8000, (100, 6000, 20, 5))
+    w = {"dense": 1.0, "bm25": -0.5, "graph": 0.5, "path": 0.1}
+    hs = HybridSearcher({"retrieval": {"candidate_pool": 60, "hybrid": {"enabled": True, "fusion_method": "rrf", "rrf_k": 60,
+                                                                       "weights": w}}})
+    got = hs.fuse(dense, bm25, graph, path)
+    exp = ofu.fuse(dense, bm25, graph, path, candidate_pool=60, fusion_method="rrf", weights=w, rrf_k=60)
+    _compare(got, exp, 60, "rrf")
+    arr = DeviceArray.from_numpy(rng.random((1, 5000)))
+    with pytest.raises(AnoragError):
+        fuse_dense("rrf", w, 60.0, 10, 1, {"bm25": arr})
+    arr.free()
+
+
 @pytest.mark.parametrize("method", ["rrf", "linear"])
 def test_c5_shape_1m_notes_device_bm25_vector(method):
     """C5 shape: N = 1 M notes, dense = a top-100 list per query, bm25 = abs(normal) kept at ~0.1 %
-    of the ids and divided by its maximum, weights {1.0, 0.5, 0.5, 0.1}, rrf_k 60, pool 80; 12 queries in one call,
-    one of them with an all-zero bm25 vector, one whose dense hits are the first ids (they win the zero ties)."""
+    of the ids and divided by its maximum, weights {1.0, 0.5, 0.5, 0.1}, rrf_k 60, pool 80; the stated 200 queries in ONE
+    call (every one checked against the oracle), one of them with an all-zero bm25 vector, one whose dense hits are the first ids (they win the zero ties)."""
     from anorag_hip.fusion import DeviceArray
     from retrieval.hybrid_search import HybridSearcher
     rng = np.random.default_rng(99)
-    n, nq, pool = 1_000_000, 12, 80
+    n, nq, pool = 1_000_000, 200, 80
     w = {"dense": 1.0, "bm25": 0.5, "graph": 0.5, "path": 0.1}
     hs = HybridSearcher({"retrieval": {"candidate_pool": pool, "hybrid": {"enabled": True, "fusion_method": method,
                                                                          "rrf_k": 60, "weights": w}}})

@@ -294,22 +294,24 @@ def test_two_shards_id_offset_packed_exchange_and_strided_merge():
     cut = 50_016
     dev = torch.device("cuda", 0)
     qt = torch.from_numpy(q).to(dev)
+    from anorag_hip.sharded import packed_layout
     nres = B * k
-    packed = torch.zeros(2 * nres * 12, device=dev, dtype=torch.uint8)
+    id_off, part = packed_layout(nres)
+    packed = torch.zeros(2 * part, device=dev, dtype=torch.uint8)
     shards = []
     for r, (lo, hi) in enumerate(((0, cut), (cut, n))):
         idx = FlatIndex(d, METRIC_IP, normalize=True)
         idx.add(x[lo:hi])
         idx.set_option(OPT_ID_OFFSET, lo)
-        base = packed.data_ptr() + r * nres * 12
-        idx.search_device(qt.data_ptr(), B, k, base, base + nres * 4)
+        base = packed.data_ptr() + r * part
+        idx.search_device(qt.data_ptr(), B, k, base, base + id_off)
         shards.append(idx)
     torch.cuda.synchronize()
     Dm = torch.empty((B, k), device=dev)
     Im = torch.empty((B, k), device=dev, dtype=torch.int64)
     lib = _lib.load()
-    _lib.check(lib.anr_merge_topk_strided_dev(0, C.c_void_p(packed.data_ptr()), C.c_void_p(packed.data_ptr() + nres * 4),
-                                              nres * 3, nres * 3 // 2, 2, B, k, 1, C.c_void_p(Dm.data_ptr()),
+    _lib.check(lib.anr_merge_topk_strided_dev(0, C.c_void_p(packed.data_ptr()), C.c_void_p(packed.data_ptr() + id_off),
+                                              part // 4, part // 8, 2, B, k, 1, C.c_void_p(Dm.data_ptr()),
                                               C.c_void_p(Im.data_ptr()), C.c_void_p(0)), "merge")
     torch.cuda.synchronize()
     xm, qm = orc.preprocess_vectors(x), orc.preprocess_vectors(q)

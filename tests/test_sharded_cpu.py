@@ -36,8 +36,9 @@ def _worker(rank, world, port, n, d, nq, k, out_dir):
     dist.destroy_process_group()
 
 
-def test_sharded_search_matches_single_index(tmp_path):
-    n, d, nq, k, world = 5001, 64, 9, 20, 2
+@pytest.mark.parametrize("nq,k", [(9, 20), (1, 5), (3, 7)])   # odd nq * k: the id block of the packed exchange buffer
+def test_sharded_search_matches_single_index(tmp_path, nq, k):  # must stay 8-byte aligned and the part stride exact
+    n, d, world = 5001, 64, 2
     port = _free_port()
     mp.spawn(_worker, args=(world, port, n, d, nq, k, str(tmp_path)), nprocs=world, join=True)
     x = orc.preprocess_vectors(np.random.default_rng(1234).standard_normal((n, d), dtype=np.float32))
@@ -48,6 +49,14 @@ def test_sharded_search_matches_single_index(tmp_path):
         got = np.load(os.path.join(str(tmp_path), f"r{r}.npz"))
         assert np.array_equal(got["I"], Ir)
         assert np.array_equal(got["D"], Dr)
+
+
+def test_packed_layout_alignment():
+    from anorag_hip.sharded import packed_layout
+    for nres in (1, 5, 7, 21, 100, 6400, 6401):
+        id_off, part = packed_layout(nres)
+        assert id_off % 8 == 0 and part % 8 == 0 and id_off >= nres * 4 and part == id_off + nres * 8
+        assert id_off - nres * 4 < 8
 
 
 def test_shard_bounds_and_merge_edges():

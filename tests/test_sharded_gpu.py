@@ -62,8 +62,10 @@ def _pipeline(shards, Q, B, k, dev):
     import torch
     from anorag_hip import _lib
     lib = _lib.load()
+    from anorag_hip.sharded import packed_layout
     P, nres, NSLOT = len(shards), B * k, 3
-    packed = [torch.zeros(P * nres * 12, device=dev, dtype=torch.uint8) for _ in range(NSLOT)]
+    id_off, part = packed_layout(nres)
+    packed = [torch.zeros(P * part, device=dev, dtype=torch.uint8) for _ in range(NSLOT)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(NSLOT)]
     out, pending = {}, []
 
@@ -75,16 +77,16 @@ def _pipeline(shards, Q, B, k, dev):
         Im = torch.empty((B, k), device=dev, dtype=torch.int64)
         with torch.cuda.stream(streams[s]):
             _lib.check(lib.anr_merge_topk_strided_dev(
-                0, C.c_void_p(packed[s].data_ptr()), C.c_void_p(packed[s].data_ptr() + nres * 4), nres * 3,
-                nres * 3 // 2, P, B, k, 1, C.c_void_p(Dm.data_ptr()), C.c_void_p(Im.data_ptr()),
+                0, C.c_void_p(packed[s].data_ptr()), C.c_void_p(packed[s].data_ptr() + id_off), part // 4,
+                part // 8, P, B, k, 1, C.c_void_p(Dm.data_ptr()), C.c_void_p(Im.data_ptr()),
                 C.c_void_p(streams[s].cuda_stream)), "merge")
         out[i] = (Dm, Im)
 
     for i in range(Q.shape[0]):
         s = i % NSLOT
         for r, sh in enumerate(shards):
-            base = packed[s].data_ptr() + r * nres * 12
-            sh.search_device_async(Q[i].data_ptr(), B, k, base, base + nres * 4, streams[s].cuda_stream)
+            base = packed[s].data_ptr() + r * part
+            sh.search_device_async(Q[i].data_ptr(), B, k, base, base + id_off, streams[s].cuda_stream)
         pending.append(i)
         if len(pending) > NSLOT - 1:
             exchange(pending.pop(0))
@@ -215,3 +217,40 @@ def test_sharded_flat_index_single_process_and_vector_index_devices_key(tmp_path
         vj.cleanup()
     finally:
         config.set("anorag_hip.devices", old)
+
+
+def test_sharded_searcher_device_path_under_an_nccl_group_of_one():
+    """ShardedSearcher's RCCL leg (packed [B*k f32 | pad | B*k i64] buffer, anr_index_wait, all_gather_into_tensor,
+    anr_merge_topk_strided_dev out of the receive buffer) executed under an initialised nccl process group of world
+    size 1 — the most one GPU allows; odd B*k included (the id block must stay 8-byte aligned, the part stride exact).
+    Results == the oracle with the shard's id offset applied."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from anorag_hip import FlatIndex, METRIC_IP
+    from anorag_hip.sharded import ShardedSearcher
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        n, d, off = 30_000, 96, 1_000_000
+        x = np.random.default_rng(5).standard_normal((n, d), dtype=np.float32)
+        idx = FlatIndex(d, METRIC_IP, normalize=True)
+        idx.add(x)
+        srch = ShardedSearcher(idx, off, force_device=True)
+        assert srch.backend == "nccl" and srch.world == 1
+        xn = orc.preprocess_vectors(x)
+        for B, k in ((1, 5), (3, 7), (64, 100), (5, 1)):
+            q = np.random.default_rng(100 + B).standard_normal((B, d), dtype=np.float32)
+            D, I = srch.search(q, k)
+            qn = orc.preprocess_vectors(q)
+            Dr, Ir = orc.flat_search(qn, xn, k, "ip")
+            s64 = orc.exact_scores(qn, xn, "ip")
+            assert orc.near_tie_equal(I - off, Ir, s64, k, 1e-6), (B, k)
+            assert np.max(np.abs(D - Dr)) <= SCORE_TOL
+        idx.close()
+    finally:
+        dist.destroy_process_group()
