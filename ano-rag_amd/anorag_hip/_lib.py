@@ -106,6 +106,8 @@ SIGNATURES = {
     "anr_index_wait": (C.c_int, [C.c_void_p, C.c_int32]),
     "anr_index_reset_stats": (C.c_int, [C.c_void_p]),
     "anr_index_score_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]),
+    "anr_similarity_matrix": (C.c_int, [C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                        C.c_void_p]),
     "anr_index_self_join": (
         C.c_int,
         [C.c_void_p, C.c_float, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)],

@@ -267,28 +267,21 @@ class EmbeddingManager:
             b = embeddings2.reshape(1, -1) if embeddings2.ndim == 1 else embeddings2
             if metric not in ("cosine", "dot", "euclidean"):
                 raise ValueError(f"unsupported similarity metric: {metric}")
-            from anorag_hip import METRIC_IP, METRIC_L2, FlatIndex
-            n = b.shape[0]
-            if metric == "cosine":
-                # reference: x / (||x|| + 1e-8) on both sides, then the dot product
-                a = a / (np.linalg.norm(a, axis=1, keepdims=True) + 1e-8)
-                b = b / (np.linalg.norm(b, axis=1, keepdims=True) + 1e-8)
-            idx = FlatIndex(b.shape[1], METRIC_L2 if metric == "euclidean" else METRIC_IP, normalize=False,
-                            device=self.hip_device)
-            try:
-                idx.add(b)
-                # exact value of every (row of a, row of b) pair: the gather-dot kernel over all ids, in column
-                # blocks so that the id matrix stays small
-                sim = np.empty((a.shape[0], n), dtype=np.float64)
-                a32 = np.ascontiguousarray(a, dtype=np.float32)
-                step = 4096
-                for c0 in range(0, n, step):
-                    ids = np.tile(np.arange(c0, min(n, c0 + step), dtype=np.int64), (a32.shape[0], 1))
-                    sim[:, c0:c0 + ids.shape[1]] = idx.score_rows(a32, ids)
-            finally:
-                idx.close()
+            import ctypes as C
+            from anorag_hip import _lib
+            # one tiled kernel (anr_similarity_matrix): the cosine normalisation x / (||x|| + 1e-8), the products
+            # (float64 accumulation) and the euclidean 1 / (1 + distance) all run on the device
+            a32 = np.ascontiguousarray(a, dtype=np.float32)
+            b32 = np.ascontiguousarray(b, dtype=np.float32)
+            if a32.shape[1] != b32.shape[1]:
+                raise ValueError(f"shapes {a.shape} and {b.shape} not aligned")
+            sim = np.empty((a32.shape[0], b32.shape[0]), dtype=np.float64)
+            code = {"cosine": 0, "dot": 1, "euclidean": 2}[metric]
+            _lib.check(_lib.load().anr_similarity_matrix(self.hip_device, a32.ctypes.data_as(C.c_void_p), a32.shape[0],
+                                                         b32.ctypes.data_as(C.c_void_p), b32.shape[0], a32.shape[1], code,
+                                                         sim.ctypes.data_as(C.c_void_p)), "anr_similarity_matrix")
             if metric == "euclidean":
-                sim = 1.0 / (1.0 + np.sqrt(np.maximum(sim, 0.0)))
+                return sim  # scipy's cdist returns float64 whatever the inputs are (:613-616)
             return sim.astype(np.result_type(embeddings1.dtype, embeddings2.dtype), copy=False)
         except Exception as e:
             logger.error(f"Similarity computation failed: {e}")

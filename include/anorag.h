@@ -100,6 +100,14 @@ int anr_index_wait(anr_index *h, int32_t keep);
 int anr_index_score_rows(anr_index *h, const float *q_host, int64_t nq, const int64_t *ids_host,
                          int32_t per_query, float *out_host);
 
+/* All-pairs similarity of two sets of embeddings: EmbeddingManager.compute_similarity,
+ * vector_store/embedding_manager.py:586-629, as one tiled kernel.  a [m][d], b [n][d] float32 host buffers;
+ * metric 0 = cosine (rows / (||row|| + 1e-8) on both sides in float32, then the dot product, :602-609),
+ * 1 = dot (:620), 2 = euclidean as 1 / (1 + ||a - b||) (:613-616).  Products are accumulated in float64;
+ * out [m][n] float64 (the caller casts to the reference's result dtype). */
+int anr_similarity_matrix(int32_t device, const float *a_host, int64_t m, const float *b_host, int64_t n, int32_t d,
+                          int32_t metric, double *out_host);
+
 /* Self join: every pair i < j of stored rows whose inner product reaches `threshold` — for a cosine
  * index (normalize = 1) the thresholded upper triangle of the N x N similarity matrix that
  * graph/relation_extractor.py:769-782 forms in full and :604-608 scans pair by pair, without the matrix.

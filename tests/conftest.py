@@ -19,11 +19,14 @@ def pytest_configure(config):
 
 
 def _has_gpu():
+    """False only when the HIP library LOADS and reports no device (the CPU build container).  A library that fails to
+    load is not "no GPU": the gpu tests then run and fail loudly instead of being skipped in silence."""
     try:
         from anorag_hip import _lib
         return _lib.device_count() > 0
-    except Exception:
-        return False
+    except Exception as e:  # missing / truncated libanorag_hip.so, unresolved symbol, ...
+        print(f"conftest: libanorag_hip.so could not be loaded ({e}); gpu tests will run and fail", file=sys.stderr)
+        return True
 
 
 def pytest_collection_modifyitems(config, items):
