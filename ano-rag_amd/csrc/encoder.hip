@@ -727,8 +727,12 @@ __device__ __forceinline__ void gemm_keep(const floatx16 &x) { asm volatile("" :
 // loop waits for); two workgroups per CU on a 5-slot ring (the epilogue of one beside the k-loop of the other: +5 % on
 // the GEMMs that ran 2 rounds, nothing overall); XCD-contiguous instead of round-robin patch assignment (no change in
 // TCC misses, which are mostly the output stores).  MFMA pipes: 54 % busy at the 1.66 GHz the chip holds under this load.
+#ifndef ANR_GEMM_STAGGER
+#define ANR_GEMM_STAGGER 1
+#endif
 template <int EPI, int TN, int ABL = 0>  // ABL: developer ablations (1 no copies in the loop, 2 no MFMAs, 3 no epilogue, 4 no k-loop barriers)
 __global__ __launch_bounds__(512) void k_gemm_pp(GemmParams p, PatchGrid pg, int64_t n_slots) {
+  constexpr bool STAG = ANR_GEMM_STAGGER != 0;
   constexpr int TM = 8, F = TM + TN, NW = TN / 2;
   constexpr int R = 8, PF = 5;
   static_assert(R >= PF + 2, "ring too small for the prefetch distance");
@@ -812,8 +816,18 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmParams p, PatchGrid pg, int
             gemm_keep(b[n]);
           } else if (EPI == EPI_VT) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m], b[n], acc[m][n], 0, 0, 0);
           else acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[n], a[m], acc[m][n], 0, 0, 0);
-          if (m == 0 && n == 1 && more) gemm_glds16(srcA + (int64_t)(ks + PF) * 64, dst + dstA);
-          if (m == 1 && n == 0 && more) gemm_glds16(srcB + (int64_t)(ks + PF) * 64, dst + dstB);
+          // staggered by wave: the four waves of a group reach the same MFMA at the same time, and their copies,
+          // issued from the same slot, queued at the CU's one address / data path for vector memory (an issue that
+          // waits there blocks the wave's NEXT MFMA: in-order issue) — wave wq now takes slots wq and wq + NW
+          constexpr int NSLOTS = 2 * NW;
+          const int slot_i = m * NW + n;
+          if (STAG) {
+            if (slot_i == wq % NSLOTS && more) gemm_glds16(srcA + (int64_t)(ks + PF) * 64, dst + dstA);
+            if (slot_i == (wq + NSLOTS / 2) % NSLOTS && more) gemm_glds16(srcB + (int64_t)(ks + PF) * 64, dst + dstB);
+          } else {
+            if (m == 0 && n == 1 && more) gemm_glds16(srcA + (int64_t)(ks + PF) * 64, dst + dstA);
+            if (m == 1 && n == 0 && more) gemm_glds16(srcB + (int64_t)(ks + PF) * 64, dst + dstB);
+          }
         }
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);

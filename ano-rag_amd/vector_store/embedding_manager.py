@@ -117,12 +117,51 @@ class EmbeddingManager:
             for path in candidates:
                 if self._try_load_model_from_path(path):
                     return
-            raise FileNotFoundError(f"no local model directory among {candidates}; this build cannot download")
+            if self._try_fallback_model(os.path.join(root, "models/embedding")):
+                return
+            raise FileNotFoundError(f"no local model directory among {candidates} (nor for the fallback models); "
+                                    "this build cannot download")
         except Exception as e:
             logger.error(f"Failed to load the embedding model: {e}")
             raise RuntimeError(f"Unable to load the embedding model: {e}")
 
-    def _try_load_model_from_path(self, model_path: str) -> bool:
+    _FALLBACK_MODELS = ("sentence-transformers/all-MiniLM-L6-v2", "sentence-transformers/all-mpnet-base-v2",
+                        "sentence-transformers/paraphrase-multilingual-MiniLM-L12-v2")
+
+    def _try_fallback_model(self, local_models_dir: str) -> bool:
+        """The reference's three fallback models (embedding_manager.py:215-248), resolved LOCALLY: the same directories
+        as the configured model plus the Hugging Face caches SentenceTransformer(name) would read offline
+        ($SENTENCE_TRANSFORMERS_HOME, $HF_HOME/hub, $TRANSFORMERS_CACHE, ~/.cache/huggingface/hub).  No download.  As in
+        the reference, model_name becomes the fallback's NAME (:238) and max_seq_length is left as the model has it."""
+        configured = self.model_name
+        caches = [os.environ.get("SENTENCE_TRANSFORMERS_HOME"), os.environ.get("TRANSFORMERS_CACHE"),
+                  os.path.join(os.environ["HF_HOME"], "hub") if os.environ.get("HF_HOME") else None,
+                  os.path.join(os.path.expanduser("~"), ".cache", "huggingface", "hub")]
+        try:
+            for name in self._FALLBACK_MODELS:
+                self.model_name = name
+                paths = self._get_local_model_paths(local_models_dir)
+                for cache in caches:
+                    if not cache:
+                        continue
+                    paths.append(os.path.join(cache, name.replace("/", "_")))
+                    snaps = os.path.join(cache, f"models--{name.replace('/', '--')}", "snapshots")
+                    if os.path.isdir(snaps):
+                        paths += [os.path.join(snaps, d) for d in sorted(os.listdir(snaps), reverse=True)]
+                for path in paths:
+                    if path in (config.get("embedding.model_path"), os.environ.get("ANORAG_MODEL_DIR")):
+                        continue  # already tried for the configured model
+                    if self._try_load_model_from_path(path, keep_seq_length=True):
+                        self.model_name = name
+                        self.max_seq_length = getattr(self.model, "max_seq_length", 512)  # (:237)
+                        logger.info(f"Fallback model loaded: {name} from {path}")
+                        return True
+        except Exception as e:
+            logger.warning(f"Fallback model lookup failed: {e}")
+        self.model_name = configured
+        return False
+
+    def _try_load_model_from_path(self, model_path: str, keep_seq_length: bool = False) -> bool:
         if not os.path.isdir(model_path):
             return False
         if not any(os.path.exists(os.path.join(model_path, f))
@@ -132,7 +171,8 @@ class EmbeddingManager:
             from anorag_hip.encoder import SentenceEncoder
             self.model = SentenceEncoder(model_path, device=self.hip_device, trust_remote_code=True)
             self.embedding_dim = self.model.get_sentence_embedding_dimension()
-            self.model.max_seq_length = self.max_length            # embedding_manager.py:361-362
+            if not keep_seq_length:
+                self.model.max_seq_length = self.max_length        # embedding_manager.py:361-362
             self.model_name = model_path                           # :365 — the name becomes the path
             logger.info(f"Model loaded from {model_path}, embedding dim {self.embedding_dim}")
             return True

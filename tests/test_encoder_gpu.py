@@ -150,7 +150,7 @@ def test_c4_full_shape_bge_base_12_layers_batch256_encode_then_search_1m(tmp_pat
     recall = np.mean([len(set(I[r]) & set(I_ref_emb[r])) / k for r in range(256)])
     print(f"C4 end to end: recall@100 of the device-embedding search vs the oracle-embedding search = {recall:.4f}, "
           f"min cosine {cos.min():.7f}")
-    assert recall >= 0.85, recall
+    assert recall >= 0.99, recall   # measured 0.9976 (round 3)
     idx.close()
 
 
@@ -173,8 +173,8 @@ def test_outlier_features_bge_base_12_layers(tmp_path):
     # the outlier dimensions really carry large activations: the un-normalised CLS output on them is >> the rest
     enc._info["normalize_module"] = False
     raw = enc.encode(sents, batch_size=16, normalize_embeddings=False)
-    mag = np.sort(np.abs(raw).max(axis=0))
-    assert mag[-6] >= 20 * np.median(mag), (mag[-6], np.median(mag))
+    mag = np.sort(np.abs(raw).max(axis=0))   # (measured: 722, 625, 294, 20, 15 ... median 0.31)
+    assert mag[-3] >= 100 * np.median(mag) and mag[-1] >= 100.0, (mag[-6:], np.median(mag))
     enc.close()
 
 
