@@ -11,7 +11,8 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libanorag_hip.so"
-LIB_PATH = os.path.join(_HERE, LIB_NAME)
+# ANORAG_LIB: load another build of the same C ABI (a deployment's own path, or a developer's A/B variant)
+LIB_PATH = os.environ.get("ANORAG_LIB") or os.path.join(_HERE, LIB_NAME)
 
 ANR_OK = 0
 METRIC_IP = 0

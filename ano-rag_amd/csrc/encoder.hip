@@ -727,12 +727,8 @@ __device__ __forceinline__ void gemm_keep(const floatx16 &x) { asm volatile("" :
 // loop waits for); two workgroups per CU on a 5-slot ring (the epilogue of one beside the k-loop of the other: +5 % on
 // the GEMMs that ran 2 rounds, nothing overall); XCD-contiguous instead of round-robin patch assignment (no change in
 // TCC misses, which are mostly the output stores).  MFMA pipes: 54 % busy at the 1.66 GHz the chip holds under this load.
-#ifndef ANR_GEMM_STAGGER
-#define ANR_GEMM_STAGGER 1
-#endif
 template <int EPI, int TN, int ABL = 0>  // ABL: developer ablations (1 no copies in the loop, 2 no MFMAs, 3 no epilogue, 4 no k-loop barriers)
 __global__ __launch_bounds__(512) void k_gemm_pp(GemmParams p, PatchGrid pg, int64_t n_slots) {
-  constexpr bool STAG = ANR_GEMM_STAGGER != 0;
   constexpr int TM = 8, F = TM + TN, NW = TN / 2;
   constexpr int R = 8, PF = 5;
   static_assert(R >= PF + 2, "ring too small for the prefetch distance");
@@ -805,6 +801,8 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmParams p, PatchGrid pg, int
       __builtin_amdgcn_s_setprio(1);
       // the two copies of k-step ks + PF are issued BETWEEN the MFMAs: an LDS-DMA piece costs the wave 60-180 cycles of
       // issue, which hides behind the 32 cycles each MFMA keeps the pipe busy instead of lengthening the load segment
+      // (round 3, tried and dropped: each wave of a group issuing from its own pair of MFMA slots so that the four do not
+      // queue at the CU's vector-memory path together — the uniform branches broke the MFMA cadence, FFN-up 98 -> 111 us)
       const bool more = ABL != 1 && ks + PF < KB;
       uint4 *dst = g_lds + wr * SLOT;
 #pragma unroll
@@ -816,18 +814,8 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmParams p, PatchGrid pg, int
             gemm_keep(b[n]);
           } else if (EPI == EPI_VT) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m], b[n], acc[m][n], 0, 0, 0);
           else acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[n], a[m], acc[m][n], 0, 0, 0);
-          // staggered by wave: the four waves of a group reach the same MFMA at the same time, and their copies,
-          // issued from the same slot, queued at the CU's one address / data path for vector memory (an issue that
-          // waits there blocks the wave's NEXT MFMA: in-order issue) — wave wq now takes slots wq and wq + NW
-          constexpr int NSLOTS = 2 * NW;
-          const int slot_i = m * NW + n;
-          if (STAG) {
-            if (slot_i == wq % NSLOTS && more) gemm_glds16(srcA + (int64_t)(ks + PF) * 64, dst + dstA);
-            if (slot_i == (wq + NSLOTS / 2) % NSLOTS && more) gemm_glds16(srcB + (int64_t)(ks + PF) * 64, dst + dstB);
-          } else {
-            if (m == 0 && n == 1 && more) gemm_glds16(srcA + (int64_t)(ks + PF) * 64, dst + dstA);
-            if (m == 1 && n == 0 && more) gemm_glds16(srcB + (int64_t)(ks + PF) * 64, dst + dstB);
-          }
+          if (m == 0 && n == 1 && more) gemm_glds16(srcA + (int64_t)(ks + PF) * 64, dst + dstA);
+          if (m == 1 && n == 0 && more) gemm_glds16(srcB + (int64_t)(ks + PF) * 64, dst + dstB);
         }
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
@@ -1023,6 +1011,7 @@ struct anr_encoder {
   int64_t ws_b = 0, ws_bl = 0;
   float *res = nullptr, *out = nullptr;  // res: the last LayerNorm's output in f32 (pooling input)
   _Float16 *act = nullptr, *delta = nullptr, *qk = nullptr, *vt = nullptr, *ctx = nullptr, *ffn = nullptr;
+  _Float16 *big = nullptr;  // the block qk / vt / ctx / ffn point into
 };
 
 namespace {
@@ -1163,17 +1152,22 @@ int ensure_ws(anr_encoder *e, int B, int L, int Lp) {
     enc_free(e->res);
     enc_free(e->delta);
     enc_free(e->act);
-    enc_free(e->qk);
-    enc_free(e->vt);
-    enc_free(e->ctx);
-    enc_free(e->ffn);
+    enc_free(e->big);
+    e->qk = e->vt = e->ctx = e->ffn = nullptr;
     ANR_TRY(enc_alloc(&e->res, T * c.hidden));
     ANR_TRY(enc_alloc(&e->delta, T * c.hidden));
     ANR_TRY(enc_alloc(&e->act, T * c.hidden));
-    ANR_TRY(enc_alloc(&e->qk, T * c.hidden * 2));
-    ANR_TRY(enc_alloc(&e->vt, T * c.hidden));
-    ANR_TRY(enc_alloc(&e->ctx, T * c.hidden));
-    ANR_TRY(enc_alloc(&e->ffn, T * c.intermediate));
+    // Q/K, V, the attention context and the FFN intermediate share ONE block: the first three are dead once the
+    // output projection has run, and the intermediate (as large as the three together when I = 4 H) is written
+    // after that.  A layer then touches 150 MB at 16 K tokens x 768 instead of 250 MB — inside the 256 MB Infinity
+    // Cache, so the activations one kernel writes are still there when the next reads them, and overwritten lines
+    // never have to reach HBM.
+    const int64_t attn_elems = T * c.hidden * 4, ffn_elems = T * c.intermediate;
+    ANR_TRY(enc_alloc(&e->big, std::max(attn_elems, ffn_elems)));
+    e->qk = e->big;
+    e->vt = e->big + T * c.hidden * 2;
+    e->ctx = e->big + T * c.hidden * 3;
+    e->ffn = e->big;
     e->ws_tokens = T;
   }
   if (B > e->ws_b) {
@@ -1241,7 +1235,7 @@ int anr_encoder_destroy(anr_encoder *e) {
   }
   enc_free(e->d_ids); enc_free(e->d_types); enc_free(e->d_lens); enc_free(e->d_rows);
   enc_free(e->res); enc_free(e->delta); enc_free(e->out);
-  enc_free(e->act); enc_free(e->qk); enc_free(e->vt); enc_free(e->ctx); enc_free(e->ffn);
+  enc_free(e->act); enc_free(e->big);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
   return ANR_OK;

@@ -9,7 +9,7 @@ for abl in ${ABLS:-0 1 2 3}; do
   python3 - $abl <<'PY'
 import csv, glob, os, sys
 abl = sys.argv[1]
-f = glob.glob(os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out/abl%s/*/*kernel_stats.csv" % abl)[0]
+f = max(glob.glob(os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out/abl%s/*/*kernel_stats.csv" % abl), key=os.path.getmtime)
 for r in csv.DictReader(open(f)):
     if "gemm" in r["Name"]:
         print("ABL", abl, r["Name"][:44].ljust(44), "avg %.1f us" % (float(r["AverageNs"]) / 1e3))
