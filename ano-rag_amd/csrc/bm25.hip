@@ -18,7 +18,7 @@ namespace anr {
 
 struct Bm25Params {
   const int64_t *indptr;   // [n_terms + 1]
-  const int32_t *docs;     // [nnz]
+  const int32_t *docs;     // [nnz], ascending inside each term's list (host-checked at anr_bm25_create)
   const double *weights;   // [nnz]
   int64_t n_docs;
   const int64_t *q_indptr; // [nq + 1]
@@ -77,11 +77,41 @@ __global__ __launch_bounds__(1024) void k_bm25(Bm25Params p) {
   const double mx = s_max;
   const bool divide = p.normalize && mx > 0.0;
   if (tid == 0 && p.max_out) p.max_out[q] = divide ? 1.0 : mx;  // (mx / mx == 1.0 exactly; division is monotone)
-  if (divide)
+  if (!divide) return;
+  if (touched >= p.n_docs) {  // a query whose postings cover the corpus: one pass over the row
     for (int64_t d = tid; d < p.n_docs; d += 1024) {
       const double v = __hip_atomic_load(sc + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       sc[d] = v / mx;
     }
+    return;
+  }
+  // Only the touched documents are non-zero (0 / mx = 0): divide THEM, not the whole row — at 1 M notes the row pass
+  // read and wrote 16 MB per query (3.2 GB per 200 queries, most of this kernel's time) for ~10 K touched documents.
+  // A document listed under several of the query's tokens must be divided once: by its FIRST occurrence, i.e. the
+  // posting whose document is in no earlier token's list (each list is sorted by document: bisection).
+  const int64_t t_lo = p.q_indptr[q], t_hi = p.q_indptr[q + 1];
+  for (int64_t t = t_lo; t < t_hi; ++t) {
+    const int term = p.q_terms[t];
+    const int64_t lo = p.indptr[term], hi = p.indptr[term + 1];
+    for (int64_t e = lo + tid; e < hi; e += 1024) {
+      const int32_t doc = p.docs[e];
+      bool first = true;
+      for (int64_t u = t_lo; u < t && first; ++u) {
+        const int tu = p.q_terms[u];
+        int64_t a = p.indptr[tu], b = p.indptr[tu + 1];
+        while (a < b) {
+          const int64_t mid = (a + b) >> 1;
+          if (p.docs[mid] < doc) a = mid + 1;
+          else b = mid;
+        }
+        first = !(a < p.indptr[tu + 1] && p.docs[a] == doc);
+      }
+      if (first) {
+        const double v = __hip_atomic_load(sc + doc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sc[doc] = v / mx;
+      }
+    }
+  }
 }
 
 // compaction of the non-zero scores of each query: (doc, score) pairs, unordered
@@ -256,6 +286,10 @@ int anr_bm25_create(int32_t device, int64_t n_docs, int64_t n_terms, const int64
     if (indptr[t + 1] < indptr[t]) return fail(ANR_EINVAL, "indptr must be non-decreasing");
   for (int64_t e = 0; e < nnz; ++e)
     if (doc_ids[e] < 0 || doc_ids[e] >= n_docs) return fail(ANR_EINVAL, "posting %lld: document id out of range", (long long)e);
+  for (int64_t t = 0; t < n_terms; ++t)  // one posting per (term, document), documents ascending: the scoring kernel
+    for (int64_t e = indptr[t] + 1; e < indptr[t + 1]; ++e)  // adds a term's postings concurrently and bisects the lists
+      if (doc_ids[e] <= doc_ids[e - 1])
+        return fail(ANR_EINVAL, "term %lld: document ids must be strictly ascending inside a posting list", (long long)t);
   int ndev = anr_device_count();
   if (ndev <= 0) return fail(ANR_EHIP, "no HIP device is visible");
   if (device < 0 || device >= ndev) return fail(ANR_EINVAL, "device %d out of range", device);

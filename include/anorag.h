@@ -293,6 +293,7 @@ int anr_encoder_forward_dev(anr_encoder *e, const int32_t *ids, const int32_t *l
  *   w(t,d) = idf_t * (tf*(k1+1) / (tf + k1*(1 - b + b*(dl_d/avgdl))))
  * are host work (anorag_hip/bm25_search.py); the device adds them per query in the reference's order, so the
  * float64 scores are bit-identical.  normalize != 0 divides by the maximum when it is > 0 (:329-333).
+ * A term's posting list holds each document once, document ids strictly ascending (checked at create).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct anr_bm25 anr_bm25;
 int anr_bm25_create(int32_t device, int64_t n_docs, int64_t n_terms, const int64_t *indptr /*[n_terms+1]*/,
