@@ -1215,6 +1215,9 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
   // zeroed per sub-batch with one memset: [H | smax | T | tau0 | c_cnt]
   const size_t z_H = 0, z_smax = z_H + (((size_t)QB * (kFdMaxSparse + 1) * 4 + 7) & ~(size_t)7), z_T = z_smax + (size_t)QB * 32,
                z_tau = z_T + (size_t)QB * 8, z_cnt = z_tau + (size_t)QB * 8, z_bytes = z_cnt + (size_t)QB * n_chunks * 4;
+  // (the 64-bit words behind the odd-sized histogram — 4100 bytes per query — must stay 8-byte aligned: k_fd_max and
+  // the scan apply 64-bit atomics to them, and a 4-byte-aligned one raises a bus error)
+  if ((z_smax | z_T | z_tau) & 7) return fail(ANR_EINTERNAL, "fuse_dense: misaligned 64-bit work area");
   const size_t d_zero = dc.take(z_bytes);
   const size_t d_kp = dc.take((size_t)QB * 4), d_su = dc.take((size_t)QB * kFdMaxSparse * 4), d_sun = dc.take((size_t)QB * 4),
                d_skh = dc.take((size_t)QB * kFdMaxSparse * 8), d_ski = dc.take((size_t)QB * kFdMaxSparse * 4),

@@ -864,12 +864,13 @@ int search_large_k(anr_index *h, const float *q, bool q_on_host, int64_t nq, int
 
 // Tiny corpus, host buffers, a handful of queries: ONE kernel launch, completion by a word in pinned memory
 // (tiny_kernels.hpp).  Exact by construction (f32 rows, f64 accumulation): no certificate, no fallback.
-// workgroups of the single-launch search: few enough that the last one merges <= kTinyMaxMerge entries, enough that
-// every CU's slice is short — 128 up to 64 K rows, 256 beyond (measured, k = 10, bare C ABI: 10 k x 384 33 us with 128
-// vs 37 with 204 workgroups — the merge grows; 100 k x 768 85 vs 101)
+// workgroups of the single-launch search: enough that every CU's slice is short, few enough for the last one's merge
 int64_t tiny_workgroups(const anr_index *h, int32_t k) {
-  const int64_t cap = h->ntotal > 65536 ? kTinyMaxWG : kTinyMaxWG / 2;
-  return std::max<int64_t>(1, std::min<int64_t>(cap, kTinyMaxMerge / k));
+  // k <= kTinySortK: the merge prunes by the k-th largest list head and hardly notices the number of lists, so every CU
+  // gets a (short) slice; beyond, the merge sorts all n_wg * k keys in registers: at most kTinyMaxMerge of them
+  (void)h;
+  const int64_t merge_cap = k <= kTinySortK ? kTinyMaxPrune : kTinyMaxMerge;
+  return std::max<int64_t>(1, std::min<int64_t>(kTinyMaxWG, merge_cap / k));
 }
 
 // Where the single launch beats the five-kernel pipeline for batches of <= 4 queries (tools/tiny_perf.py, k = 10):
@@ -890,8 +891,8 @@ bool tiny_applies(const anr_index *h, int64_t nq, int32_t k) {
 
 int search_tiny(anr_index *h, const float *q, int64_t nq, int32_t k, float *D, int64_t *I) {
   const size_t q_bytes = (size_t)kTinyMaxQ * h->dim * sizeof(float);
-  const size_t d_off = round_up((int64_t)q_bytes, 16), i_off = d_off + (size_t)kTinyMaxQ * kTinyMaxK * 4;
-  const size_t f_off = i_off + (size_t)kTinyMaxQ * kTinyMaxK * 8;
+  // pinned block: raw queries | result words [kTinyMaxQ][kTinyMaxK][2] (8 bytes each, see k_tiny_search)
+  const size_t r_off = round_up((int64_t)q_bytes, 16), f_off = r_off + (size_t)kTinyMaxQ * kTinyMaxK * 16;
   if (!h->tiny_pin || !h->tiny_cand || !h->tiny_ticket) {
     // first use: the buffers are committed to the handle only as a complete set — a failed allocation leaves nothing
     // behind that a later call could mistake for an initialised path (it would launch with null list pointers)
@@ -910,7 +911,7 @@ int search_tiny(anr_index *h, const float *q, int64_t nq, int32_t k, float *D, i
       if (ticket) (void)hipFree(ticket);
       return rc;
     }
-    memset(pin + f_off, 0, 64);
+    memset(pin + r_off, 0, f_off - r_off);  // sequence 0 is never used: no word is valid yet
     h->tiny_pin = pin;
     h->tiny_pin_dev = pin_dev;
     h->tiny_cand = cand;
@@ -934,14 +935,14 @@ int search_tiny(anr_index *h, const float *q, int64_t nq, int32_t k, float *D, i
   tp.n_wg = (int)ceil_div(h->ntotal, tp.rows_per_wg);
   tp.cand = h->tiny_cand;
   tp.ticket = h->tiny_ticket;
-  tp.D = reinterpret_cast<float *>(h->tiny_pin_dev + d_off);
-  tp.I = reinterpret_cast<int64_t *>(h->tiny_pin_dev + i_off);
-  tp.flag = reinterpret_cast<unsigned *>(h->tiny_pin_dev + f_off);
-  if (++h->tiny_seq == 0) h->tiny_seq = 1;
+  tp.R = reinterpret_cast<unsigned long long *>(h->tiny_pin_dev + r_off);
+  if (++h->tiny_seq == 0) {  // wrapped: no stale word may carry a sequence number that comes round again
+    memset(h->tiny_pin + r_off, 0, f_off - r_off);
+    h->tiny_seq = 1;
+  }
   tp.seq = h->tiny_seq;
-  tp.id_offset = h->id_offset;
   tp.stamps = h->tiny_stamps;
-  const size_t lds = (size_t)kTinyMaxMerge * 8 + (size_t)16 * kTinyMaxK * 8 + (size_t)round_up(h->dim, 4) * sizeof(float);
+  const size_t lds = (size_t)kTinyMaxPrune * 8 + (size_t)16 * kTinyMaxK * 8 + (size_t)round_up(h->dim, 4) * sizeof(float);
   const int kc = (h->dim % 4 == 0 && h->dim <= 1024) ? (int)ceil_div(h->dim / 4, 64) : 0;
 #define ANR_TINY_LAUNCH(KC)                                                                                   \
   {                                                                                                           \
@@ -957,18 +958,22 @@ int search_tiny(anr_index *h, const float *q, int64_t nq, int32_t k, float *D, i
   }
 #undef ANR_TINY_LAUNCH
   ANR_HIP(hipGetLastError());
-  // completion: spin on the words the last workgroups write into pinned memory (an event / stream wait costs more
-  // than the whole kernel); after ~2 s fall back to the stream so a device fault surfaces as an error
-  volatile unsigned *flag = reinterpret_cast<volatile unsigned *>(h->tiny_pin + f_off);
-  for (int64_t qi = 0; qi < nq; ++qi) {
+  // completion: spin on the result words themselves — each carries this call's sequence number in its upper half (an
+  // event / stream wait costs more than the whole kernel; a separate flag needed a system-scope fence on the device);
+  // after ~2 s fall back to the stream so a device fault surfaces as an error
+  volatile unsigned long long *R = reinterpret_cast<volatile unsigned long long *>(h->tiny_pin + r_off);
+  const int64_t n_words = nq * (int64_t)k * 2;
+  {
     uint64_t spins = 0;
-    while (__atomic_load_n(&flag[qi], __ATOMIC_ACQUIRE) != tp.seq) {
-      __builtin_ia32_pause();
-      if (++spins > (1ull << 28)) {
-        ANR_HIP(hipStreamSynchronize(h->stream));
-        if (__atomic_load_n(&flag[qi], __ATOMIC_ACQUIRE) != tp.seq)
-          return fail(ANR_EINTERNAL, "tiny search: the kernel finished without raising its completion word");
-        break;
+    for (int64_t i = n_words - 1; i >= 0; --i) {  // last words first: they are written last
+      while ((unsigned)(__atomic_load_n(&R[i], __ATOMIC_ACQUIRE) >> 32) != tp.seq) {
+        __builtin_ia32_pause();
+        if (++spins > (1ull << 28)) {
+          ANR_HIP(hipStreamSynchronize(h->stream));
+          if ((unsigned)(__atomic_load_n(&R[i], __ATOMIC_ACQUIRE) >> 32) != tp.seq)
+            return fail(ANR_EINTERNAL, "tiny search: the kernel finished without writing its results");
+          spins = 0;
+        }
       }
     }
   }
@@ -978,10 +983,13 @@ int search_tiny(anr_index *h, const float *q, int64_t nq, int32_t k, float *D, i
     ANR_HIP(hipMemcpy(st, h->tiny_stamps, sizeof st, hipMemcpyDeviceToHost));
     auto us = [&](int a, int b) { return (double)((long long)st[b] - (long long)st[a]) / 100.0; };  // 100 MHz clock
     fprintf(stderr, "[tiny] wg0: query %.2f norm %.2f score %.2f rank+publish %.2f ticket %.2f | last: start+%.2f load %.2f "
-                    "merge %.2f fence %.2f us\n", us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5), us(0, 8), us(8, 9), us(9, 10), us(10, 11));
+                    "merge-1 %.2f merge-2 %.2f write %.2f us\n", us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5), us(0, 8), us(8, 9), us(9, 12), us(12, 13), us(13, 10));
   }
-  memcpy(D, h->tiny_pin + d_off, (size_t)nq * k * sizeof(float));
-  memcpy(I, h->tiny_pin + i_off, (size_t)nq * k * sizeof(int64_t));
+  for (int64_t i = 0; i < nq * (int64_t)k; ++i) {
+    const unsigned sbits = (unsigned)R[2 * i], row = (unsigned)R[2 * i + 1];
+    memcpy(D + i, &sbits, 4);
+    I[i] = row == 0xffffffffu ? -1 : (int64_t)row + h->id_offset;
+  }
   h->stats.n_dense_exact += nq;
   return ANR_OK;
 }

@@ -18,7 +18,8 @@ constexpr int kTinyMaxWG = 256;       // (128 up to 64 K rows: see tiny_workgrou
 constexpr int kTinyMaxK = 128;
 constexpr int kTinyMaxQ = 4;
 constexpr int kTinyRowsPerWG = 1024;   // rows a workgroup ranks among themselves
-constexpr int kTinyMaxMerge = 2048;    // partial-list entries the last workgroup merges
+constexpr int kTinyMaxMerge = 2048;    // partial-list entries the last workgroup merges by sorting (k > kTinySortK)
+constexpr int kTinyMaxPrune = 4096;    // ... by pruning (k <= kTinySortK): its cost barely grows with the number of lists
 constexpr int kTinySortRows = 192;     // slices longer than this are ordered by the bitonic network instead of rank counting
 constexpr int kTinySortK = 32;         // merges for k beyond this likewise (the second rank-counting level grows as (16 k)^2)
 
@@ -30,11 +31,8 @@ struct TinyParams {
   int rows_per_wg, n_wg;
   unsigned long long *cand;  // [nq][n_wg][k] keys, 0 = empty
   unsigned *ticket;          // [nq], zero between calls
-  float *D;                  // pinned host [nq][k]
-  int64_t *I;                // pinned host [nq][k]
-  unsigned *flag;            // pinned host [nq]: set to seq when query q is complete
-  unsigned seq;
-  int64_t id_offset;
+  unsigned long long *R;     // pinned host [nq][k][2]: (score bits | seq << 32), (local row or 0xffffffff | seq << 32)
+  unsigned seq;              // this call's sequence number: a result word is valid once its upper half equals it
   unsigned long long *stamps;  // developer aid (ANORAG_TINY_STAMPS): [16] wall-clock stamps of workgroup 0 / the last one
 };
 
@@ -105,8 +103,8 @@ __device__ __forceinline__ void tiny_sort_desc(unsigned long long *buf, int n_po
 template <int KC>
 __global__ __launch_bounds__(kTinyThreads) void k_tiny_search(TinyParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tiny_smem[];
-  unsigned long long *s_keys = reinterpret_cast<unsigned long long *>(tiny_smem);             // [kTinyMaxMerge]
-  float *s_q = reinterpret_cast<float *>(tiny_smem + (size_t)kTinyMaxMerge * 8 + (size_t)16 * kTinyMaxK * 8);  // [dim rounded to 4]
+  unsigned long long *s_keys = reinterpret_cast<unsigned long long *>(tiny_smem);             // [kTinyMaxPrune]
+  float *s_q = reinterpret_cast<float *>(tiny_smem + (size_t)kTinyMaxPrune * 8 + (size_t)16 * kTinyMaxK * 8);  // [dim rounded to 4]
   __shared__ double s_red[4];
   __shared__ float s_scale;
   __shared__ int s_last;
@@ -261,8 +259,6 @@ __global__ __launch_bounds__(kTinyThreads) void k_tiny_search(TinyParams p) {
     s_keys[i] = __hip_atomic_load(all + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   TINY_STAMP(9, q == 0);
-  float *D = p.D + (int64_t)q * p.k;
-  int64_t *I = p.I + (int64_t)q * p.k;
   const int64_t found = p.n_rows < p.k ? p.n_rows : p.k;
   if (p.k > kTinySortK) {
     // the n_wg * k <= 2048 keys of all partial lists, ordered by the register bitonic network (binary searches across the
@@ -278,57 +274,72 @@ __global__ __launch_bounds__(kTinyThreads) void k_tiny_search(TinyParams p) {
       __syncthreads();
     }
   } else {
-    // two-level merge with INDEPENDENT LDS reads (binary searches across the sorted lists were tried: ~1000 dependent LDS
-    // round trips per entry, 100 us): level 1 — each of the 16 waves ranks the entries of its share of the lists among
-    // themselves and keeps the k best; level 2 — the 16 k survivors are ranked among themselves
-    unsigned long long *s_l2 = s_keys + kTinyMaxMerge;  // [16][k]
-    const int G = (p.n_wg + 15) / 16;                    // lists per level-1 group
-    const int GE = G * p.k;                              // entries per group
-    for (int i = tid; i < 16 * p.k; i += kTinyThreads) s_l2[i] = 0ull;
-    __syncthreads();
-    for (int i = tid; i < M; i += kTinyThreads) {
-      const unsigned long long key = s_keys[i];
-      if (key == 0ull) continue;
-      const int g = i / GE;
-      const int e0 = g * GE, e1 = e0 + GE < M ? e0 + GE : M;
-      int rank = 0;
-      for (int j = e0; j < e1; ++j) rank += (s_keys[j] > key) ? 1 : 0;
-      if (rank < p.k) s_l2[g * p.k + rank] = key;
+    // Prune, then rank: every partial list is sorted, so a key below the k-th largest list HEAD has k larger keys
+    // (those heads) and cannot be among the k best.  (1) each list's head counts the heads above it — n_wg independent
+    // LDS reads — and the k-th largest becomes the threshold; (2) the keys at or above it (at most k lists qualify: <= k^2
+    // keys, ~2 k in practice) are compacted; (3) the survivors rank themselves by counting.
+    // (Round 2 ranked all n_wg * k keys by counting in two levels: 11.7 us of the kernel's 22 at k = 10, its largest
+    // phase; a register tournament of wave-wide maxima — 2 k dependent shuffle butterflies — took just as long;
+    // binary searches across the sorted lists: 100 us.)
+    unsigned long long *s_l2 = s_keys + kTinyMaxPrune;  // survivors: <= kTinySortK^2 = 1024 <= 16 * kTinyMaxK entries
+    __shared__ unsigned long long s_thr;
+    __shared__ unsigned s_nsurv;
+    if (tid == 0) {
+      s_thr = 0ull;
+      s_nsurv = 0u;
     }
     __syncthreads();
-    const int M2 = 16 * p.k;
-    for (int i = tid; i < M2; i += kTinyThreads) {
+    if (p.n_wg > p.k && tid < p.n_wg) {
+      const unsigned long long h = s_keys[tid * p.k];
+      int r = 0;
+      for (int j = 0; j < p.n_wg; ++j) r += (s_keys[j * p.k] > h) ? 1 : 0;
+      if (r == p.k - 1 && h != 0ull) s_thr = h;  // (keys are unique: one head has exactly k - 1 heads above it)
+    }
+    __syncthreads();
+    const unsigned long long thr = s_thr;
+    for (int i = tid; i < M; i += kTinyThreads) {
+      const unsigned long long key = s_keys[i];
+      if (key != 0ull && key >= thr) s_l2[atomicAdd(&s_nsurv, 1u)] = key;
+    }
+    __syncthreads();
+    TINY_STAMP(12, q == 0);
+    const int ns = (int)s_nsurv;
+    for (int i = tid; i < ns; i += kTinyThreads) {
       const unsigned long long key = s_l2[i];
-      if (key == 0ull) continue;
       int rank = 0;
-      for (int j = 0; j < M2; ++j) rank += (s_l2[j] > key) ? 1 : 0;
+      for (int j = 0; j < ns; ++j) rank += (s_l2[j] > key) ? 1 : 0;
       if (rank < p.k) s_rank[rank] = key;  // ranks are distinct: one writer per slot
     }
     __syncthreads();
+    TINY_STAMP(13, q == 0);
   }
-  // one wave writes the k results into pinned host memory and fences them ONCE at system scope (a fence per writing
-  // thread, or system-scope atomic stores, cost 5-10 us apiece here)
+  // One wave writes the k results into pinned host memory as SELF-VALIDATING 8-byte words — the call's sequence number
+  // rides in the upper half of each — with plain stores and NO fence and NO completion flag: the host spins until every
+  // word of the query carries the sequence number.  (Round 2 wrote D / I plainly, fenced them once at system scope and
+  // then raised a flag: the fence alone was ~5 of the kernel's 22 us; a fence per writing thread or system-scope atomic
+  // stores cost 5-10 us apiece.)  An aligned 8-byte store reaches host memory as one write, so a word is either the
+  // previous call's or complete; the id offset of a shard is added on the host.
   if (wave == 0) {
+    unsigned long long *R = p.R + (int64_t)q * p.k * 2;
+    const unsigned long long tag = (unsigned long long)p.seq << 32;
     for (int i = lane; i < p.k; i += 64) {
+      unsigned sbits, row;
       if (i < (int)found) {
         const unsigned long long key = s_rank[i];
         const float v = ord2f((unsigned)(key >> 32));
-        D[i] = p.metric == 0 ? v : -v;
-        I[i] = (int64_t)(0xffffffffu - (unsigned)(key & 0xffffffffu)) + p.id_offset;
+        sbits = __float_as_uint(p.metric == 0 ? v : -v);
+        row = 0xffffffffu - (unsigned)(key & 0xffffffffu);
       } else {  // fewer rows than k: faiss padding
-        D[i] = p.metric == 0 ? -3.402823466e+38f : 3.402823466e+38f;
-        I[i] = -1;
+        sbits = __float_as_uint(p.metric == 0 ? -3.402823466e+38f : 3.402823466e+38f);
+        row = 0xffffffffu;
       }
+      reinterpret_cast<volatile unsigned long long *>(R)[2 * i] = tag | sbits;
+      reinterpret_cast<volatile unsigned long long *>(R)[2 * i + 1] = tag | row;
     }
-    __threadfence_system();
   }
   TINY_STAMP(10, q == 0);
-  __syncthreads();
+  if (tid == 0) __hip_atomic_store(p.ticket + q, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next call
   TINY_STAMP(11, q == 0);
-  if (tid == 0) {
-    __hip_atomic_store(p.ticket + q, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next call
-    __hip_atomic_store(p.flag + q, p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
 }
 
 }  // namespace anr

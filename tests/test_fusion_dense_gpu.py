@@ -245,6 +245,26 @@ def test_fuse_dense_argument_errors():
     a.free()
 
 
+@pytest.mark.parametrize("nq", [1, 3, 5])
+def test_linear_max_pass_with_an_odd_number_of_queries(nq):
+    """the device max pass (k_fd_max: a 64-bit atomicMax per source and query) with an ODD number of queries and no
+    maxima supplied: the 64-bit work words sit behind a 4100-byte-per-query histogram and must stay 8-byte aligned —
+    a 4-byte-aligned 64-bit atomic is a bus error (the SIGBUS seen once during round 2's arena rewrite)"""
+    from anorag_hip.fusion import DeviceArray, fuse_dense
+    rng = np.random.default_rng(nq)
+    n, pool = 30_000, 40
+    a = rng.random((nq, n))
+    arr = DeviceArray.from_numpy(a)            # no row maxima: the kernel finds them
+    dense = [(rng.choice(n, 50, replace=False).astype(np.int64), rng.random(50)) for _ in range(nq)]
+    w = {"dense": 1.0, "bm25": 0.5, "graph": 0.5, "path": 0.1}
+    ids, fin, _, cnt = fuse_dense("linear", w, 60.0, pool, nq, {"dense": dense, "bm25": arr})
+    arr.free()
+    full = np.arange(n, dtype=np.int64)
+    for q in range(nq):
+        _, f = ofu.fuse_arrays(n, (dense[q], (full, a[q]), None, None), [1.0, 0.5, 0.5, 0.1], "linear", 60, pool)
+        assert cnt[q] == pool and fin[q].tolist() == f.tolist()
+
+
 def test_host_supplied_row_maxima_match_the_device_max_pass():
     """DeviceArray.from_numpy(with_max=True): rows with NaN (absent ids), an all-NaN row, an all-negative row, an
     all-zero row — the linear fusion with the supplied maxima equals the one that runs k_fd_max"""
