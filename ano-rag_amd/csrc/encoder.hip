@@ -943,6 +943,230 @@ __global__ __launch_bounds__(256) void k_attention(AttnParams p) {
     }
 }
 
+// ---- Q/K/V projection + attention in ONE kernel (round 3) ---------------------------------------------------
+// For sequences of at most 128 padded tokens (queries, short notes) and 64-wide heads.  A workgroup owns 256 tokens — two
+// to eight whole sequences — and ONE head: its tile is 256 tokens x 192 features (that head's 64 Q, 64 K and 64 V rows of
+// the two weight images), computed by the ping-pong k-loop of k_gemm_pp with TN = 6; then the tile is turned into f16
+// operand fragments in LDS (the ring is free by then: 96 KiB), every wave picks up the operands of ONE 32-query block —
+// its Q, and the K and V of its sequence's key blocks — into registers, the next tile's first k-steps are requested, and
+// the wave runs the attention of its query block (online softmax, exactly k_attention's arithmetic) beside that
+// prefetch.  The Q/K/V activations never touch global memory: three launches and ~150 MB of writes + reads per layer
+// at 16 K tokens become one launch whose only output is the 25 MB context.
+// Wave (wm, wn) multiplies token blocks 2 wm, 2 wm + 1 with the feature blocks {wn, wn + 2, wn + 4} of the tile's six
+// (Q0 Q1 K0 K1 V0 V1): every wave has one Q, one K and one V block, so the operand order of each MFMA — V is projected
+// with the operands swapped: feature on lane, keys in k — is a compile-time property of n.
+struct QkvAttnParams {
+  const uint4 *act;        // [TB][KB][64]
+  const uint4 *wqk, *wv;   // [2H/32][KB][64], [H/32][KB][64]
+  const float *bqk_acc;    // [2H/32][2][16]
+  const float *bv;         // [H]
+  int64_t TB;
+  int KB, H, heads, Lp;
+  const int *lens;
+  float scale;
+  const float *relbias;    // optional (MPNet)
+  int rel_span;
+  _Float16 *ctx;           // act layout [TB][H/16][64][8]
+};
+
+template <int NKB>  // key blocks per sequence: Lp = 32 NKB
+__global__ __launch_bounds__(512) void k_qkv_attn(QkvAttnParams p, PatchGrid pg, int64_t n_slots) {
+  constexpr int TM = 8, TN = 6, F = TM + TN, NW = 3;
+  constexpr int R = 8, PF = 5;
+  extern __shared__ uint4 g_lds[];  // ring [R][F][64]; after the k-loop: Q [8][4] | K [8][4] | V [2][16] fragments of 64 uint4
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int grp = wave >> 2, wq = wave & 3;
+  const int wm = wq, wn = grp;
+  const int fb = wave < TN ? wave : wave - TN;
+  const int dstA = wave * 64, dstB = (TM + fb) * 64;
+  constexpr int SLOT = F * 64;
+  const int KB = p.KB, NBH = p.H / 32;  // feature blocks per projection
+  const uint4 *srcA = nullptr, *srcB = nullptr;
+  auto find_tile = [&](int64_t &slot, int &bm, int &bn) -> bool {
+    for (; slot < n_slots; slot += gridDim.x)
+      if (patch_tile(pg, slot, bm, bn)) return true;
+    return false;
+  };
+  auto request = [&](int bm, int hd) {
+    const int64_t tb_c = (int64_t)bm * TM + wave < p.TB ? (int64_t)bm * TM + wave : p.TB - 1;
+    srcA = p.act + (tb_c * KB) * 64 + lane;
+    // feature fragment fb of the head's tile: Q0 Q1 | K0 K1 | V0 V1
+    const uint4 *w = fb < 4 ? p.wqk + ((int64_t)((fb >> 1) * NBH + hd * 2 + (fb & 1)) * KB) * 64
+                            : p.wv + ((int64_t)(hd * 2 + (fb & 1)) * KB) * 64;
+    srcB = w + lane;
+#pragma unroll
+    for (int i = 0; i < PF; ++i)
+      if (i < KB) {
+        gemm_glds16(srcA + (int64_t)i * 64, g_lds + i * SLOT + dstA);
+        gemm_glds16(srcB + (int64_t)i * 64, g_lds + i * SLOT + dstB);
+      }
+  };
+  int64_t slot = blockIdx.x;
+  int bm = 0, hd = 0;
+  bool have = find_tile(slot, bm, hd);
+  if (have) request(bm, hd);
+  while (have) {
+    floatx16 acc[2][NW];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < NW; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    if (KB >= PF) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();  // the stagger (see k_gemm_pp)
+    __builtin_amdgcn_sched_barrier(0);
+    int rd = 0, wr = PF % R;
+    for (int ks = 0; ks < KB; ++ks) {
+      const uint4 *L = g_lds + rd * SLOT + lane;
+      half8 a[2], b[NW];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) a[m] = __builtin_bit_cast(half8, L[(2 * wm + m) * 64]);
+#pragma unroll
+      for (int n = 0; n < NW; ++n) b[n] = __builtin_bit_cast(half8, L[(TM + wn + 2 * n) * 64]);
+      if (ks + PF - 1 < KB) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+      const bool more = ks + PF < KB;
+      uint4 *dst = g_lds + wr * SLOT;
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < NW; ++n) {
+          if (n == 2) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m], b[n], acc[m][n], 0, 0, 0);  // V: rows = tokens
+          else acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[n], a[m], acc[m][n], 0, 0, 0);         // Q, K: rows = features
+          if (m == 0 && n == 1 && more) gemm_glds16(srcA + (int64_t)(ks + PF) * 64, dst + dstA);
+          if (m == 1 && n == 0 && more) gemm_glds16(srcB + (int64_t)(ks + PF) * 64, dst + dstB);
+        }
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      rd = rd + 1 == R ? 0 : rd + 1;
+      wr = wr + 1 == R ? 0 : wr + 1;
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();  // every fragment read of the ring is done
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- the tile as f16 operand fragments in LDS: Q [8][4], K [8][4] (token on lane), V [2][16] (feature on lane) ----
+    uint4 *Qs = g_lds, *Ks = g_lds + 32 * 64, *Vs = g_lds + 64 * 64;
+    const int h = lane >> 5;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int tbl = 2 * wm + m;
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {  // Q (n = 0) and K (n = 1): bias in accumulator order, as gemm_store_tile
+        const float *ba = p.bqk_acc + ((int64_t)(n * NBH + hd * 2 + wn) * 2 + h) * 16;
+#pragma unroll
+        for (int sf = 0; sf < 2; ++sf) {
+          half8 hv;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) hv[j] = (_Float16)(acc[m][n][8 * sf + j] + ba[8 * sf + j]);
+          (n == 0 ? Qs : Ks)[(tbl * 4 + 2 * wn + sf) * 64 + lane] = __builtin_bit_cast(uint4, hv);
+        }
+      }
+      const float bb = p.bv[(hd * 2 + wn) * 32 + (lane & 31)];
+#pragma unroll
+      for (int sf = 0; sf < 2; ++sf) {
+        half8 hv;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hv[j] = (_Float16)(acc[m][2][8 * sf + j] + bb);
+        Vs[(wn * 16 + tbl * 2 + sf) * 64 + lane] = __builtin_bit_cast(uint4, hv);
+      }
+    }
+    __syncthreads();
+    // ---- this wave's query block: u = wave; its sequence's key blocks ----
+    const int u = wave, kb0 = (u / NKB) * NKB;
+    half8 qf[4], kf[NKB][4], vf[NKB][2][2];
+#pragma unroll
+    for (int kd = 0; kd < 4; ++kd) qf[kd] = __builtin_bit_cast(half8, Qs[(u * 4 + kd) * 64 + lane]);
+#pragma unroll
+    for (int kk = 0; kk < NKB; ++kk) {
+#pragma unroll
+      for (int kd = 0; kd < 4; ++kd) kf[kk][kd] = __builtin_bit_cast(half8, Ks[((kb0 + kk) * 4 + kd) * 64 + lane]);
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int sf = 0; sf < 2; ++sf) vf[kk][d][sf] = __builtin_bit_cast(half8, Vs[(d * 16 + (kb0 + kk) * 2 + sf) * 64 + lane]);
+    }
+    __syncthreads();  // the fragments are in registers: the ring may be refilled
+    const int cm = bm, chd = hd;
+    slot += gridDim.x;
+    have = find_tile(slot, bm, hd);
+    if (have) request(bm, hd);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- attention of the query block (k_attention's arithmetic) ----
+    const int64_t tb = (int64_t)cm * TM + u;
+    if (tb < p.TB) {
+      const int64_t tok0 = tb * 32;
+      const int seq = (int)(tok0 / p.Lp), qb = (int)((tok0 % p.Lp) / 32);
+      const int len = p.lens[seq];
+      floatx16 O[2];
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[d][r] = 0.f;
+      float mrun = -__builtin_inff(), l = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < NKB; ++kk) {
+        if (kk * 32 < len) {
+          floatx16 S;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) S[r] = 0.f;
+#pragma unroll
+          for (int kd = 0; kd < 4; ++kd) S = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kk][kd], qf[kd], S, 0, 0, 0);  // rows = keys
+          float mx = -__builtin_inff();
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = kk * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            float sc = S[r] * p.scale;
+            if (p.relbias) sc += p.relbias[(int64_t)chd * (2 * p.rel_span - 1) + (key < len ? key : 0) - (qb * 32 + (lane & 31)) + p.rel_span - 1];
+            S[r] = key < len ? sc : -__builtin_inff();
+            mx = fmaxf(mx, S[r]);
+          }
+          mx = fmaxf(mx, __shfl_xor(mx, 32));
+          const float mn = fmaxf(mrun, mx);
+          const float alpha = __expf(mrun - mn);
+          float ps = 0.f;
+          half8 pf0, pf1;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float ex = __expf(S[r] - mn);
+            ps += ex;
+            if (r < 8) pf0[r] = (_Float16)ex;
+            else pf1[r - 8] = (_Float16)ex;
+          }
+          l = l * alpha + ps;
+          mrun = mn;
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) O[d][r] *= alpha;
+            O[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[kk][d][0], pf0, O[d], 0, 0, 0);  // rows = head features
+            O[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[kk][d][1], pf1, O[d], 0, 0, 0);
+          }
+        }
+      }
+      l += __shfl_xor(l, 32);
+      const float inv = 1.0f / l;
+      const int KBh = p.H / 16;
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int sf = 0; sf < 2; ++sf) {
+          half8 hv;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) hv[j] = (_Float16)(O[d][8 * sf + j] * inv);
+          const int64_t kb = (int64_t)chd * 4 + d * 2 + sf;
+          *reinterpret_cast<half8 *>(p.ctx + ((tb * KBh + kb) * 64 + lane) * 8) = hv;
+        }
+    }
+  }
+}
+
 // ---- pooling + normalisation: one block per sequence, thread per feature -------------------------------
 struct PoolParams {
   const float *res;  // final LayerNorm output, blocked f32
@@ -1335,13 +1559,34 @@ void enqueue_forward(anr_encoder *e, int B, int L, int Lp, bool use_types, int n
     GemmParams gv{};
     gv.act = reinterpret_cast<const uint4 *>(e->act); gv.w = reinterpret_cast<const uint4 *>(l.wv);
     gv.TB = TB; gv.NB = H / 32; gv.KB = KB; gv.bias = l.bv; gv.out = e->vt;
-    if (use_skinny(gq) && use_skinny(gv)) {  // small inputs: both projections in one launch
+    // 64-wide heads and sequences of <= 128 padded tokens at tile-filling sizes: projections + attention in one kernel
+    const bool fused_attn = dh == 64 && (Lp == 32 || Lp == 64 || Lp == 128) && KB % 2 == 0 && TB >= 8 * 16 && !use_skinny(gq);
+    if (fused_attn) {
+      QkvAttnParams qa{};
+      qa.act = reinterpret_cast<const uint4 *>(e->act);
+      qa.wqk = reinterpret_cast<const uint4 *>(l.wqk); qa.wv = reinterpret_cast<const uint4 *>(l.wv);
+      qa.bqk_acc = l.bqk; qa.bv = l.bv;
+      qa.TB = TB; qa.KB = KB; qa.H = H; qa.heads = c.n_heads; qa.Lp = Lp; qa.lens = e->d_lens;
+      qa.scale = 1.0f / sqrtf((float)dh); qa.relbias = e->relbias; qa.rel_span = e->rel_span; qa.ctx = e->ctx;
+      PatchGrid pg = make_patch_grid(ceil_div(TB, 8), c.n_heads);
+      const int64_t n_slots = pg.grid();
+      const int64_t grid = std::min<int64_t>(n_slots, std::max(8, e->n_cu / 8 * 8));
+      constexpr int lds_qa = 8 * 14 * 1024;
+#define ANR_QA(N)                                                                                       \
+  {                                                                                                     \
+    (void)ensure_dynamic_lds(reinterpret_cast<const void *>(&k_qkv_attn<N>), lds_qa);                   \
+    hipLaunchKernelGGL((k_qkv_attn<N>), dim3((unsigned)grid), dim3(512), lds_qa, st, qa, pg, n_slots);  \
+  }
+      if (Lp == 32) ANR_QA(1) else if (Lp == 64) ANR_QA(2) else ANR_QA(4)
+#undef ANR_QA
+    } else if (use_skinny(gq) && use_skinny(gv)) {  // small inputs: both projections in one launch
       const int n_qk = (int)((int64_t)gq.NB * ceil_div(gq.TB, 2)), n_v = (int)((int64_t)gv.NB * ceil_div(gv.TB, 2));
       hipLaunchKernelGGL(k_gemm_skinny_qkv, dim3((unsigned)(n_qk + n_v)), dim3(256), 0, st, gq, gv, n_qk);
     } else {
       launch_gemm<EPI_ACT>(e, gq);
       launch_gemm<EPI_VT>(e, gv);
     }
+    if (!fused_attn) {
     AttnParams ap{};
     ap.qk = reinterpret_cast<const uint4 *>(e->qk); ap.vt = reinterpret_cast<const uint4 *>(e->vt);
     ap.lens = e->d_lens; ap.B = B; ap.Lp = Lp; ap.H = H; ap.heads = c.n_heads; ap.dh = dh;
@@ -1351,6 +1596,7 @@ void enqueue_forward(anr_encoder *e, int B, int L, int Lp, bool use_types, int n
     if (dh == 32) hipLaunchKernelGGL(k_attention<32>, dim3((unsigned)ceil_div(aw, 4)), dim3(256), 0, st, ap);
     else if (dh == 64) hipLaunchKernelGGL(k_attention<64>, dim3((unsigned)ceil_div(aw, 4)), dim3(256), 0, st, ap);
     else hipLaunchKernelGGL(k_attention<128>, dim3((unsigned)ceil_div(aw, 4)), dim3(256), 0, st, ap);
+    }
     GemmParams go{};
     go.act = reinterpret_cast<const uint4 *>(e->ctx); go.w = reinterpret_cast<const uint4 *>(l.wo);
     go.TB = TB; go.NB = H / 32; go.KB = KB; go.bias_acc = l.bo; go.out = e->delta;

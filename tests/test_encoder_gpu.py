@@ -154,6 +154,32 @@ def test_c4_full_shape_bge_base_12_layers_batch256_encode_then_search_1m(tmp_pat
     idx.close()
 
 
+@pytest.mark.parametrize("words,model_type,heads", [((3, 12), "bert", 4), ((20, 40), "bert", 4), ((60, 100), "bert", 4),
+                                                    ((20, 40), "mpnet", 4), ((20, 40), "xlm-roberta", 2)])
+def test_fused_projection_attention_kernel(tmp_path, words, model_type, heads):
+    """k_qkv_attn (Q/K/V projection + attention in one kernel: 64-wide heads, sequences padded to 32 / 64 / 128 tokens,
+    >= 4096 padded tokens in the forward): ragged lengths (masking inside the tile), a last tile that is not full (the
+    token-block count is not a multiple of 8), MPNet's relative position bias, XLM-R positions; same bar as every other
+    encoder test.  The sentence-length ranges put the padded length at 32, 64 and 128."""
+    from anorag_hip.encoder import SentenceEncoder
+    d = oenc.make_synthetic_model(str(tmp_path / "m"), layers=2, hidden=64 * heads, heads=heads, intermediate=256 * heads,
+                                  pooling="mean", model_type=model_type, max_pos=128)
+    n = 250 if words[1] <= 12 else (141 if words[1] <= 40 else 70)
+    sents = oenc.synthetic_sentences(d, n, seed=11, min_words=words[0], max_words=words[1]) + ["a"]
+    ref = oenc.encode(d, sents, batch_size=len(sents), normalize=True)
+    enc = SentenceEncoder(d)
+    ids, lens, _ = enc.tokenize(sents)
+    Lp = (ids.shape[1] + 31) // 32 * 32
+    assert Lp in (32, 64, 128) and ids.shape[0] * Lp >= 4096 and (ids.shape[0] * Lp // 32) % 8 != 0, (ids.shape, Lp)
+    # ONE forward of the whole tokenised batch (encode() would cut the ragged batch into several smaller forwards)
+    use_types = enc._info["hf"].get("type_vocab_size", 1) > 1
+    got = enc._enc.forward(ids, lens, np.zeros_like(ids) if use_types else None, normalize=True)
+    cos = np.sum(got * ref, axis=1)
+    assert cos.min() >= 0.9995, cos.min()
+    assert np.max(np.abs(got - ref)) <= 5e-3
+    enc.close()
+
+
 def test_outlier_features_bge_base_12_layers(tmp_path):
     """The f16 activation / residual stream under OUTLIER FEATURES (trained BERT-family checkpoints carry a few hidden
     dimensions whose LayerNorm gains are tens of times the rest: activations in the tens to hundreds, where f16 resolves
