@@ -9,15 +9,21 @@
 #   5 N-array fusion (C5) kernel stats
 set -e
 R=$GRAFT_REPO_ROOT
-ROUND=${ROUND:-r02}
+ROUND=${ROUND:-r03}
 O=$R/gpurun_out/prof
-rm -rf $O && mkdir -p $O
+STEPS=${STEPS:-12345}   # which parts to run (a gpurun call is limited to 20 minutes: e.g. STEPS=12, then STEPS=345)
+mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
+if [[ $STEPS == *1* ]]; then
 echo "[1] bench" >&2
 python3 $R/bench.py > $O/${ROUND}_bench_1gpu.json 2> $O/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats -- python3 $R/bench.py --no-cpu --recall-queries 0 --no-facade > $O/bench_prof.json 2> $O/bench_prof.err
+# (the profiled run leaves out the extra legs, the CPU legs and the facade leg: every k_scan<false,...> launch in the stats is a
+# 10 M-row launch of the headline workload, so the kernel's average there is comparable with roofline.ms_per_launch)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats -- python3 $R/bench.py --no-cpu --recall-queries 0 --no-facade --no-legs > $O/bench_prof.json 2> $O/bench_prof.err
 cp $(ls $O/kstats/*/*kernel_stats.csv | head -1) $O/${ROUND}_bench_10m_1gpu_kernel_stats.csv
 rm -rf $O/kstats
+fi
+if [[ $STEPS == *2* ]]; then
 echo "[2] pmc traffic" >&2
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- python3 $R/tools/scan_perf.py --rows 10000000 --steps 4 --mode sync > $O/pmc_$c.log 2>&1
@@ -48,19 +54,29 @@ json.dump({"kernel": kernel.replace("void anr::", "").split("(")[0], "rows": row
 print("traffic/algorithmic", traffic / (rows_n * dim * 2))
 PY
 rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
+fi
+if [[ $STEPS == *3* ]]; then
 echo "[3] shard sizes + configs" >&2
 { python3 $R/tools/scan_perf.py --rows 1000000 --steps 60; python3 $R/tools/scan_perf.py --rows 1250000 --steps 60; python3 $R/tools/scan_perf.py --rows 1250000 --steps 60 --clustered; } 2>&1 | grep -v amdgpu > $O/${ROUND}_shard_size_lines.txt
 python3 $R/tools/bench_configs.py > $O/configs.log 2>&1 && cp $R/gpurun_out/configs.json $O/${ROUND}_configs_c1_c2_c4_c5.json
-python3 $R/tools/tiny_perf.py 2>&1 | grep -v amdgpu > $O/${ROUND}_c1_tiny_path.txt
+{ python3 $R/tools/tiny_perf.py; echo "--- K=32"; K=32 python3 $R/tools/tiny_perf.py; echo "--- 20k x 768"; ROWS=20000 DIM=768 python3 $R/tools/tiny_perf.py; echo "--- 100k x 768"; ROWS=100000 DIM=768 python3 $R/tools/tiny_perf.py; } 2>&1 | grep -v amdgpu > $O/${ROUND}_c1_tiny_path.txt
+fi
+if [[ $STEPS == *4* ]]; then
 echo "[4] encoder" >&2
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/enc -- python3 $R/tools/enc_perf.py 256 64 > $O/enc_perf.log 2>&1
 cp $(ls $O/enc/*/*kernel_stats.csv | head -1) $O/${ROUND}_encoder_bge_base_256x64_kernel_stats.csv
+python3 $R/tools/role_times.py $O/enc > $O/${ROUND}_encoder_role_times_fused.txt 2>&1 || true
 rm -rf $O/enc
 { python3 $R/tools/enc_perf.py 256 64; python3 $R/tools/enc_perf.py 64 512; SHAPE=bge-m3 python3 $R/tools/enc_perf.py 256 64; } 2>&1 | grep TFLOP > $O/${ROUND}_encoder_forward_lines.txt
 bash $R/tools/pmc_kernel.sh "k_gemm_pp<1" SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY TCC_HIT_sum TCC_MISS_sum -- $R/tools/enc_perf.py 256 64 > $O/${ROUND}_pmc_k_gemm_pp_ffn_up.txt 2>&1
+fi
+if [[ $STEPS == *5* ]]; then
 echo "[5] fusion" >&2
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/fd -- python3 $R/tools/fuse_dense_perf.py 2>&1 | grep "queries x" > $O/${ROUND}_fuse_dense_c5.txt
 cp $(ls $O/fd/*/*kernel_stats.csv | head -1) $O/${ROUND}_fuse_dense_c5_kernel_stats.csv
 rm -rf $O/fd
+python3 $R/tools/bm25_fuse_perf.py 2>&1 | grep -v amdgpu | tail -3 > $O/${ROUND}_bm25_fuse_pipeline_lines.txt
+python3 $R/tools/gemm_yardstick.py 2>&1 | grep -v amdgpu > $O/${ROUND}_gemm_yardstick.txt
+fi
 ls -la $O >&2
