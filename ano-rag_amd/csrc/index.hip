@@ -110,7 +110,7 @@ struct anr_index {
   unsigned char *tiny_pin = nullptr, *tiny_pin_dev = nullptr;  // pinned: queries | D | I | completion words
   unsigned char *sr_buf = nullptr;                // anr_index_score_rows scratch
   int64_t sr_cap = 0;
-  unsigned long long *tiny_cand = nullptr;        // [kTinyMaxQ][kTinyMaxWG][kTinyMaxK]
+  unsigned long long *tiny_cand = nullptr;        // [kTinyMaxQ][kTinyMaxPrune]: a query's n_wg partial lists of k keys
   unsigned *tiny_ticket = nullptr;                // [kTinyMaxQ]
   unsigned tiny_seq = 0;
   unsigned long long *tiny_stamps = nullptr;      // developer aid: ANORAG_TINY_STAMPS=1 prints the kernel's phase times
@@ -903,7 +903,8 @@ int search_tiny(anr_index *h, const float *q, int64_t nq, int32_t k, float *D, i
     if (hipHostMalloc(reinterpret_cast<void **>(&pin), f_off + 64, hipHostMallocDefault) != hipSuccess ||
         hipHostGetDevicePointer(reinterpret_cast<void **>(&pin_dev), pin, 0) != hipSuccess)
       rc = fail(ANR_EHIP, "tiny search: pinned buffer allocation failed");
-    if (rc == ANR_OK) rc = dev_alloc(&cand, (int64_t)kTinyMaxQ * kTinyMaxMerge, true);
+    static_assert(kTinyMaxPrune >= kTinyMaxMerge, "the partial lists of a query hold up to kTinyMaxPrune keys");
+    if (rc == ANR_OK) rc = dev_alloc(&cand, (int64_t)kTinyMaxQ * kTinyMaxPrune, true);
     if (rc == ANR_OK) rc = dev_alloc(&ticket, kTinyMaxQ, true);
     if (rc != ANR_OK) {
       if (pin) (void)hipHostFree(pin);
@@ -928,11 +929,13 @@ int search_tiny(anr_index *h, const float *q, int64_t nq, int32_t k, float *D, i
   tp.normalize = h->normalize;
   tp.k = k;
   tp.n_rows = h->ntotal;
-  // few enough workgroups that the last one merges <= kTinyMaxMerge entries, enough that every CU slice is short
+  // few enough workgroups that the last one's merge holds them (tiny_workgroups), enough that every CU slice is short
   int n_wg = (int)tiny_workgroups(h, k);
   n_wg = (int)std::min<int64_t>(n_wg, ceil_div(h->ntotal, 16));
   tp.rows_per_wg = (int)ceil_div(h->ntotal, n_wg);
   tp.n_wg = (int)ceil_div(h->ntotal, tp.rows_per_wg);
+  if ((int64_t)tp.n_wg * k > kTinyMaxPrune || (k > kTinySortK && (int64_t)tp.n_wg * k > kTinyMaxMerge) || tp.rows_per_wg > kTinyRowsPerWG)
+    return fail(ANR_EINTERNAL, "tiny search: %d workgroups x k = %d do not fit the merge", tp.n_wg, k);
   tp.cand = h->tiny_cand;
   tp.ticket = h->tiny_ticket;
   tp.R = reinterpret_cast<unsigned long long *>(h->tiny_pin_dev + r_off);
