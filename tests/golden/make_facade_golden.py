@@ -102,6 +102,7 @@ def install_stand_ins():
         def __init__(self, *a, **k):
             self.calls = []          # every list of texts passed to encode, with the keyword arguments
             self.table = {}          # text -> vector
+            self.seen = {}           # text -> vector the stand-in made up for a text outside the table
             self.dim = 8
             self.fail = False
             self.max_seq_length = 512
@@ -119,7 +120,11 @@ def install_stand_ins():
                 if t in self.table:
                     out[i] = self.table[t]
                 else:
-                    out[i] = np.random.default_rng(abs(hash(t)) % (2 ** 32)).standard_normal(self.dim)
+                    import hashlib
+                    seed = int.from_bytes(hashlib.md5(t.encode("utf-8")).digest()[:4], "little")
+                    v = np.random.default_rng(seed).standard_normal(self.dim).astype(np.float32)
+                    out[i] = v / np.linalg.norm(v)
+                    self.seen[t] = out[i].copy()
             return out
 
     stm.SentenceTransformer = SentenceTransformer
@@ -336,6 +341,85 @@ def retriever_cases(rt_mod, em_mod, stm):
     return {"defaults": defaults, "cases": cases}
 
 
+def lifecycle_cases(rt_mod, em_mod, stm):
+    """build_index / add_notes / remove_notes / update_note / get_similar_notes and the TF-IDF "BM25" fallback with the
+    namespace filter (retriever.py:118-184, 514-659, 924-1034; sklearn and the reference's utils/dataset_guard.py are the
+    real ones), every step's observable state recorded"""
+    dg = load_by_path("utils.dataset_guard", os.path.join(REF, "utils", "dataset_guard.py"))
+    sys.modules["utils"].dataset_guard = dg
+    rng = np.random.default_rng(20261103)
+    d = 8
+    em = object.__new__(em_mod.EmbeddingManager)
+    em.model = stm.SentenceTransformer()
+    em.model.dim = d
+    em.model_name, em.batch_size, em.device, em.max_length = "BAAI/bge-m3", 32, "cpu", 512
+    em.normalize_embeddings, em.embedding_dim, em.consistency_checker = True, d, None
+    em_mod.EmbeddingManager._instance = em
+    em_mod.EmbeddingManager._model_loaded = True
+    CONFIG_OVERRIDES.clear()
+    CONFIG_OVERRIDES.update({"vector_store.index_type": "Flat", "vector_store.similarity_metric": "cosine"})
+    import tempfile
+    CONFIG_OVERRIDES["storage.vector_store_path"] = tempfile.mkdtemp(prefix="anr_golden_vs_")
+    CONFIG_OVERRIDES["storage.vector_index_path"] = tempfile.mkdtemp(prefix="anr_golden_vi_")
+    r = rt_mod.VectorRetriever()
+    notes = FakeNotes.make(rng, 30)
+    for i, n in enumerate(notes):
+        if not isinstance(n["content"], str):
+            n["content"] = f"plain content {i} paris river"      # the lifecycle methods call .get('content') as text
+        n["source_info"] = {"file_path": f"/data/{'musique' if i % 3 else 'hotpot'}/q{i % 4}/doc_{i}.json"}
+    steps = []
+
+    def state():
+        return {"n_notes": len(r.atomic_notes), "note_ids": [n.get("note_id") for n in r.atomic_notes],
+                "total_vectors": int(r.vector_index.total_vectors),
+                "embeddings_shape": list(r.note_embeddings.shape) if r.note_embeddings is not None else None,
+                "note_id_to_index": dict(r.note_id_to_index), "index_to_note_id": {str(k): v for k, v in r.index_to_note_id.items()},
+                "tfidf_rows": int(r.tfidf_matrix.shape[0]) if r.tfidf_matrix is not None else None}
+
+    em.model.calls = []
+    ok = r.build_index([dict(n) for n in notes], force_rebuild=True, save_index=False)
+    steps.append({"op": "build_index", "returned": ok, "encoder_texts": em.model.calls[-1]["texts"], "state": state()})
+    steps.append({"op": "build_index_empty", "returned": r.build_index([], force_rebuild=True, save_index=False)})
+    q = ["paris river founded", "gamma delta city", "zzzz qqqq"]
+    steps.append({"op": "_bm25_search", "queries": q, "top_k": 5, "returned": [r._bm25_search(x, top_k=5) for x in q]})
+    em.model.calls = []
+    res = r.search_with_namespace_fallback(q, "musique", "q1", top_k=6, similarity_threshold=-1.0)
+    steps.append({"op": "search_with_namespace_fallback", "queries": q, "dataset": "musique", "qid": "q1", "top_k": 6,
+                  "similarity_threshold": -1.0, "returned": res})
+    res = r.search_with_namespace_fallback(q[:2], "nosuch", "q9", top_k=4, similarity_threshold=-1.0)
+    steps.append({"op": "search_with_namespace_fallback", "queries": q[:2], "dataset": "nosuch", "qid": "q9", "top_k": 4,
+                  "similarity_threshold": -1.0, "returned": res})
+    nid = notes[3]["note_id"]
+    steps.append({"op": "get_similar_notes", "note_id": nid, "top_k": 4, "returned": r.get_similar_notes(nid, top_k=4)})
+    steps.append({"op": "get_similar_notes", "note_id": "missing", "top_k": 4, "returned": r.get_similar_notes("missing", top_k=4)})
+    steps.append({"op": "get_notes_by_ids", "ids": [notes[1]["note_id"], "missing", notes[7]["note_id"]],
+                  "returned": r.get_notes_by_ids([notes[1]["note_id"], "missing", notes[7]["note_id"]])})
+    new = [{"note_id": "new_a", "title": "New A", "content": "alpha beta new content", "entities": ["alpha"], "paragraph_idxs": [1]},
+           {"note_id": "new_b", "title": "New B", "content": "river city founded year", "entities": [], "paragraph_idxs": [2]}]
+    em.model.calls = []
+    ok = r.add_notes([dict(n) for n in new])
+    steps.append({"op": "add_notes", "notes": new, "returned": ok, "encoder_texts": em.model.calls[-1]["texts"], "state": state()})
+    steps.append({"op": "add_notes_empty", "returned": r.add_notes([])})
+    steps.append({"op": "search", "queries": ["river city"], "kwargs": {"top_k": 5, "similarity_threshold": -1.0},
+                  "returned": r.search(["river city"], top_k=5, similarity_threshold=-1.0)})
+    em.model.calls = []
+    ok = r.remove_notes([notes[2]["note_id"], "not_there", "new_a"])
+    steps.append({"op": "remove_notes", "ids": [notes[2]["note_id"], "not_there", "new_a"], "returned": ok,
+                  "encoder_texts": em.model.calls[-1]["texts"] if em.model.calls else None, "state": state()})
+    steps.append({"op": "remove_notes_unknown", "returned": r.remove_notes(["nobody"]), "state": state()})
+    upd = {"note_id": notes[5]["note_id"], "title": "Updated", "content": "completely new text about london", "entities": ["london"],
+           "paragraph_idxs": [9]}
+    em.model.calls = []
+    ok = r.update_note(notes[5]["note_id"], dict(upd))
+    steps.append({"op": "update_note", "note_id": notes[5]["note_id"], "note": upd, "returned": ok,
+                  "encoder_texts": [c["texts"] for c in em.model.calls], "state": state()})
+    steps.append({"op": "update_note_unknown", "returned": r.update_note("nobody", dict(upd))})
+    steps.append({"op": "search", "queries": ["london text"], "kwargs": {"top_k": 3, "similarity_threshold": -1.0},
+                  "returned": r.search(["london text"], top_k=3, similarity_threshold=-1.0)})
+    vectors = {k: [float(t) for t in v] for k, v in em.model.seen.items()}
+    return {"notes": notes, "dim": d, "vectors": vectors, "steps": steps}
+
+
 def embedding_manager_cases(em_mod, stm):
     CONFIG_OVERRIDES.clear()
     em = object.__new__(em_mod.EmbeddingManager)
@@ -411,10 +495,14 @@ def main():
     with open(os.path.join(HERE, "retriever_facade_cases.json"), "w") as f:
         json.dump({"source": "reference vector_store/retriever.py VectorRetriever.search / .retrieve", "note": note,
                    **retriever_cases(rt_mod, em_mod, stm)}, f)
+    with open(os.path.join(HERE, "retriever_lifecycle_cases.json"), "w") as f:
+        json.dump({"source": "reference vector_store/retriever.py build_index / add_notes / remove_notes / update_note / "
+                             "get_similar_notes / _bm25_search / search_with_namespace_fallback (sklearn and the reference's "
+                             "utils/dataset_guard.py are the real ones)", "note": note, **lifecycle_cases(rt_mod, em_mod, stm)}, f)
     with open(os.path.join(HERE, "embedding_manager_facade_cases.json"), "w") as f:
         json.dump({"source": "reference vector_store/embedding_manager.py text assembly / preprocessing / prefix / sentinels",
                    "note": note, **embedding_manager_cases(em_mod, stm)}, f)
-    print("wrote vector_index_facade_cases.json, retriever_facade_cases.json, embedding_manager_facade_cases.json")
+    print("wrote vector_index_facade_cases.json, retriever_facade_cases.json, retriever_lifecycle_cases.json, embedding_manager_facade_cases.json")
 
 
 if __name__ == "__main__":

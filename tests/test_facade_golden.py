@@ -6,6 +6,9 @@ text assembly — not the libraries themselves):
   rows a3 / a4 / a6 / a7  vector_store/embedding_manager.py:374-407, :409-549, :551-584
   rows b5 / b6            vector_store/vector_index.py:226-259, :265-282
   rows c1 / c3 / c5       vector_store/retriever.py:32-116 (defaults), :186-272, :339-512
+  rows c2 / c6 / c7 / c10 vector_store/retriever.py:118-184, :514-659, :924-1034 (build / add / remove / update / similar notes,
+                          the TF-IDF fallback and the namespace filter; incl. the reference's total_vectors that keeps
+                          growing across rebuilds)
 
 CPU tests drive the classes with a numpy index in the place of the device index (host logic only, no compute through
 the C ABI); the `gpu` tests run the same cases through the real FlatIndex."""
@@ -277,6 +280,120 @@ def _run_retriever_cases(make_index, tol):
 
 def test_retriever_search_and_retrieve_match_the_reference_host_logic():
     _run_retriever_cases(_numpy_backend, 1e-6)
+
+
+# ---- retriever.py life cycle: build / add / remove / update / similar notes / TF-IDF fallback + namespace filter ----
+def _namespace_filter_module():
+    """`utils.dataset_guard.filter_notes_by_namespace` is the reference's own helper (it exists in the tree the drop-in
+    is placed into, retriever.py:1009); here a stand-in with the rule of utils/dataset_guard.py:73-101 for the fixture's
+    notes: the source path must hold the dataset and the qid (case-insensitive)"""
+    import sys
+    import types
+    m = types.ModuleType("utils.dataset_guard")
+
+    def filter_notes_by_namespace(notes, dataset, qid):
+        out = []
+        for n in notes or []:
+            path = str(n.get("source_info", {}).get("file_path", "")).replace("\\", "/").lower()
+            if path and dataset and qid and dataset.lower() in path and qid.lower() in path:
+                out.append(n)
+        return out
+
+    m.filter_notes_by_namespace = filter_notes_by_namespace
+    pkg = sys.modules.get("utils") or types.ModuleType("utils")
+    pkg.dataset_guard = m
+    return pkg, m
+
+
+def _run_lifecycle(make_new_index, tol, monkeypatch, tmp_path):
+    import sys
+    from vector_store import embedding_manager as emm
+    from vector_store.retriever import VectorRetriever
+    g = _load("retriever_lifecycle_cases.json")
+    d = g["dim"]
+    table = {k: np.array(v, dtype=np.float32) for k, v in g["vectors"].items()}
+
+    class Strict(dict):  # a text the reference never gave its encoder means the text rules differ: fail loudly
+        def get(self, key, default=None):
+            return self[key]
+
+    em = _manager(d, table=Strict(table))
+    pkg, mod = _namespace_filter_module()
+    monkeypatch.setitem(sys.modules, "utils", pkg)
+    monkeypatch.setitem(sys.modules, "utils.dataset_guard", mod)
+    old = (emm.EmbeddingManager._instance, emm.EmbeddingManager._model_loaded)
+    emm.EmbeddingManager._instance, emm.EmbeddingManager._model_loaded = em, True
+    try:
+        r = VectorRetriever()
+    finally:
+        emm.EmbeddingManager._instance, emm.EmbeddingManager._model_loaded = old
+    r.data_dir = str(tmp_path / "vs")
+    os.makedirs(r.data_dir, exist_ok=True)
+    vi = r.vector_index
+    vi.index_dir = str(tmp_path / "vi")
+    os.makedirs(vi.index_dir, exist_ok=True)
+    vi.index_type, vi.similarity_metric = "Flat", "cosine"
+    if make_new_index is not None:
+        vi._new_index = make_new_index
+
+    def state():
+        return {"n_notes": len(r.atomic_notes), "note_ids": [n.get("note_id") for n in r.atomic_notes],
+                "total_vectors": int(r.vector_index.total_vectors),
+                "embeddings_shape": list(r.note_embeddings.shape) if r.note_embeddings is not None else None,
+                "note_id_to_index": dict(r.note_id_to_index), "index_to_note_id": {str(k): v for k, v in r.index_to_note_id.items()},
+                "tfidf_rows": int(r.tfidf_matrix.shape[0]) if r.tfidf_matrix is not None else None}
+
+    notes = g["notes"]
+    for st in g["steps"]:
+        op, name = st["op"], st["op"]
+        em.model.calls = []
+        if op == "build_index":
+            got = r.build_index([dict(n) for n in notes], force_rebuild=True, save_index=False)
+        elif op == "build_index_empty":
+            got = r.build_index([], force_rebuild=True, save_index=False)
+        elif op == "_bm25_search":
+            got = [r._bm25_search(x, top_k=st["top_k"]) for x in st["queries"]]
+        elif op == "search_with_namespace_fallback":
+            got = r.search_with_namespace_fallback(st["queries"], st["dataset"], st["qid"], top_k=st["top_k"],
+                                                   similarity_threshold=st["similarity_threshold"])
+        elif op == "get_similar_notes":
+            got = r.get_similar_notes(st["note_id"], top_k=st["top_k"])
+        elif op == "get_notes_by_ids":
+            got = r.get_notes_by_ids(st["ids"])
+        elif op == "add_notes":
+            got = r.add_notes([dict(n) for n in st["notes"]])
+        elif op == "add_notes_empty":
+            got = r.add_notes([])
+        elif op == "search":
+            got = r.search(st["queries"], **st["kwargs"])
+        elif op == "remove_notes":
+            got = r.remove_notes(st["ids"])
+        elif op == "remove_notes_unknown":
+            got = r.remove_notes(["nobody"])
+        elif op == "update_note":
+            got = r.update_note(st["note_id"], dict(st["note"]))
+        elif op == "update_note_unknown":
+            got = r.update_note("nobody", {"note_id": "x"})
+        else:
+            raise AssertionError(op)
+        _same(got, st["returned"], tol, name)
+        if "encoder_texts" in st and st["encoder_texts"] is not None:
+            texts = [c["texts"] for c in em.model.calls]
+            exp = st["encoder_texts"] if op == "update_note" else [st["encoder_texts"]]
+            assert texts[-len(exp):] == exp, name
+        if "state" in st:
+            _same(state(), st["state"], 0.0, name + ".state")
+    r.cleanup()
+
+
+def test_retriever_life_cycle_matches_the_reference_host_logic(monkeypatch, tmp_path):
+    from anorag_hip import METRIC_IP
+    _run_lifecycle(lambda d, metric, normalize: _NumpyFlat(d, metric == METRIC_IP, normalize), 1e-6, monkeypatch, tmp_path)
+
+
+@pytest.mark.gpu
+def test_retriever_life_cycle_matches_the_reference_on_the_device(monkeypatch, tmp_path):
+    _run_lifecycle(None, 1e-4, monkeypatch, tmp_path)
 
 
 @pytest.mark.gpu
