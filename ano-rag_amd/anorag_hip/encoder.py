@@ -295,16 +295,16 @@ class SentenceEncoder:
         """length-sorted batches (longest first, as SentenceTransformer.encode), tokenised one batch AHEAD on a worker
         thread: the tokenizer (Rust, releases the GIL) prepares batch i + 1 while the device runs the forward of
         batch i (the ctypes call releases the GIL as well).  The forward size is the device's business
-        (``batch_size`` is accepted and ignored; memory is bounded by ``max_forward_tokens``, see ``_token_slices``): fewer than 256 sentences go in ONE forward (100
-        sentences as four forwards of 32 took 5 ms, as one 2.5 ms — small forwards leave most CUs idle), 256 and more
-        in forwards of 128 (the next is tokenised while one runs: at 256 queries the tokenizer is a third of the time),
-        2048 and more in forwards of 256; a forward also ends where the sorted texts get shorter than 60 % of its
+        (``batch_size`` is accepted and ignored; memory is bounded by ``max_forward_tokens``, see ``_token_slices``): fewer than 512 sentences go in ONE forward (100
+        sentences as four forwards of 32 took 5 ms, as one 2.5 ms — small forwards leave most CUs idle; 256 queries as two
+        forwards of 128 with the second tokenised beside the first: 6.9-7.2 ms, as one: 6.0-6.7 ms, round 3), 512 and more
+        in forwards of 256 (the next is tokenised while one runs); a forward also ends where the sorted texts get shorter than 60 % of its
         first; an embedding does not depend on which sentences share its forward (padding is masked)."""
         n = len(sentences)
         if n == 0:
             return
         order = np.argsort([-len(s) for s in sentences], kind="stable")
-        fb = n if n < 256 else (128 if n < 2048 else 256)
+        fb = n if n < 512 else 256
         # a forward is padded to its longest sentence: cut where the texts (longest first) fall below 60 % of the
         # forward's first one, but never before 16 sentences — mixed-length notes do not pay for the longest of all
         sels, i = [], 0
