@@ -48,6 +48,14 @@ struct DeviceGuard {
 
 int device_cu_count(int device);
 
+// device-wide stable radix sort of (key, u32 value) pairs (radix_sort.hip); temp: radix_sort_temp_bytes(n) bytes of device
+// memory; equal keys keep their input order, also when descending
+size_t radix_sort_temp_bytes(int64_t n);
+int radix_sort_pairs_u64(void *temp, const unsigned long long *k_in, unsigned long long *k_out, const unsigned *v_in,
+                         unsigned *v_out, int64_t n, bool descending, hipStream_t st);
+int radix_sort_pairs_f32(void *temp, const float *k_in, float *k_out, const unsigned *v_in, unsigned *v_out, int64_t n,
+                         bool descending, hipStream_t st);
+
 // top-k beyond the select window (largek.hip): full device sort of one query's exact scores
 struct LargeKScratch {
   unsigned *iota = nullptr, *rows = nullptr;

@@ -1,7 +1,7 @@
 // anr_fuse_rrf_long (include/anorag.h): weighted RRF (retrieval/hybrid_search.py:60-72) over lists of ANY length — the
 // case anr_fuse_lists (4096 entries per query, LDS-resident) and anr_fuse_dense (one full-corpus source) leave: two or
 // three long lists, e.g. a dense score and a bm25 score for every note.  The reference ranks each list by a stable
-// descending sort; here that sort is the device radix sort (hipCUB, stable), per source and query, over the list IN ITS
+// descending sort; here that sort is the stable device radix sort of radix_sort.hip, per source and query, over the list IN ITS
 // OWN ORDER (so equal scores keep their list positions, whatever the id numbering):
 //   keys  = order-preserving 64-bit image of the score, values = the entries' ids
 //   rank_s[id at sorted position r] = r + 1                         (ids outside the list keep rank 0 = absent)
@@ -12,7 +12,6 @@
 // This is the completeness path of HybridSearcher.fuse (two or three lists longer than the LDS kernel holds, method rrf);
 // it is correct first and costs a handful of N-wide sorts per query.  One long source goes through anr_fuse_dense, which
 // counts the ranks it needs in a single streaming pass.
-#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cstring>
@@ -150,12 +149,7 @@ extern "C" int anr_fuse_rrf_long(int32_t device, int64_t nq, const int64_t *ids_
   FuseArena &ar = arenas[device];
   std::lock_guard<std::mutex> lock(ar.mu);
   hipStream_t st = nullptr;
-  size_t temp_bytes = 0;
-  {
-    unsigned long long *k0 = nullptr;
-    unsigned *v0 = nullptr;
-    ANR_HIP(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, temp_bytes, k0, k0, v0, v0, (int)n, 0, 64, st));
-  }
+  const size_t temp_bytes = radix_sort_temp_bytes(n);
   Carve dc, hc;
   const size_t N = (size_t)n, T = (size_t)(total > 0 ? total : 1);
   const size_t d_ids = dc.take(8 * T), d_sc = dc.take(8 * T);
@@ -204,18 +198,15 @@ extern "C" int anr_fuse_rrf_long(int32_t device, int64_t nq, const int64_t *ids_
       }
       unsigned *rank = R + (size_t)s * N;
       hipLaunchKernelGGL(k_rl_keys, dim3(gl), dim3(256), 0, st, sc + o[s], ids + o[s], len, A, C, score_of);
-      size_t tb = temp_bytes;
-      ANR_HIP(hipcub::DeviceRadixSort::SortPairsDescending(temp, tb, A, B, C, Dv, (int)len, 0, 64, st));
+      ANR_TRY(radix_sort_pairs_u64(temp, A, B, C, Dv, len, true, st));
       hipLaunchKernelGGL(k_rl_ranks, dim3(gl), dim3(256), 0, st, Dv, len, rank);
       fp.rank[s] = rank;
     }
     // finals and tie keys of every id; order by (final desc, tie asc): stable sort by tie, then by final
     hipLaunchKernelGGL(k_ra_fuse, dim3(grid), dim3(256), 0, st, fp, A, B, C);
-    size_t tb = temp_bytes;
-    ANR_HIP(hipcub::DeviceRadixSort::SortPairs(temp, tb, B, E, C, Dv, (int)n, 0, 64, st));          // ids by tie: Dv
+    ANR_TRY(radix_sort_pairs_u64(temp, B, E, C, Dv, n, false, st));                                  // ids by tie: Dv
     hipLaunchKernelGGL(k_ra_gather, dim3(grid), dim3(256), 0, st, A, Dv, n, B);                      // their finals: B
-    tb = temp_bytes;
-    ANR_HIP(hipcub::DeviceRadixSort::SortPairsDescending(temp, tb, B, E, Dv, F, (int)n, 0, 64, st));  // final order: F
+    ANR_TRY(radix_sort_pairs_u64(temp, B, E, Dv, F, n, true, st));                                   // final order: F
     ANR_HIP(hipMemcpyAsync(D + d_ptr, arr_q, sizeof arr_q, hipMemcpyHostToDevice, st));
     int64_t *o_ids = reinterpret_cast<int64_t *>(D + d_out);
     double *o_fin = reinterpret_cast<double *>(D + d_out + (size_t)pool * 8);

@@ -1,10 +1,8 @@
 // Top-k beyond the select kernel's 1024-entry window (faiss accepts any k; the reference's retrieve() over-fetches
 // top_k x 3, vector_store/retriever.py:339-512): the exact scores of every row are sorted with the device radix sort
-// (hipCUB, a plain library primitive) and the first k pairs are written out.  Stable sort of (score, row) pairs whose
+// (radix_sort.hip) and the first k pairs are written out.  Stable sort of (score, row) pairs whose
 // rows start in ascending order, so equal scores keep ascending ids — the same tie rule as the select path.  A rare
 // path (k > 1024): ~N log N per query instead of one streaming pass per batch.
-#include <hipcub/hipcub.hpp>
-
 #include "common.hpp"
 
 namespace anr {
@@ -38,19 +36,12 @@ int sort_topk(const float *scores_dev, int64_t n, int k, bool larger_is_better, 
     ANR_HIP(hipMalloc(reinterpret_cast<void **>(&s->rows), (size_t)n * sizeof(unsigned)));
     ANR_HIP(hipMalloc(reinterpret_cast<void **>(&s->keys), (size_t)n * sizeof(float)));
     hipLaunchKernelGGL(k_iota, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, s->iota, n);
-    size_t bytes = 0;
-    ANR_HIP(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, bytes, scores_dev, s->keys, s->iota, s->rows, (int)n, 0,
-                                                         32, st));
+    const size_t bytes = radix_sort_temp_bytes(n);
     ANR_HIP(hipMalloc(&s->temp, bytes));
     s->temp_bytes = bytes;
     s->n = n;
   }
-  size_t bytes = s->temp_bytes;
-  if (larger_is_better)
-    ANR_HIP(hipcub::DeviceRadixSort::SortPairsDescending(s->temp, bytes, scores_dev, s->keys, s->iota, s->rows, (int)n, 0,
-                                                         32, st));
-  else
-    ANR_HIP(hipcub::DeviceRadixSort::SortPairs(s->temp, bytes, scores_dev, s->keys, s->iota, s->rows, (int)n, 0, 32, st));
+  ANR_TRY(radix_sort_pairs_f32(s->temp, scores_dev, s->keys, s->iota, s->rows, n, larger_is_better, st));
   hipLaunchKernelGGL(k_emit_sorted, dim3((unsigned)ceil_div(k, 256)), dim3(256), 0, st, s->keys, s->rows, n, k,
                      larger_is_better ? 1 : 0, id_offset, D_row, I_row);
   ANR_HIP(hipGetLastError());
