@@ -596,6 +596,10 @@ __global__ __launch_bounds__(256) void k_gemm_skinny(GemmParams p) {
   gemm_skinny_body<EPI>(p, (int)blockIdx.x, red);
 }
 
+// (Round 3, measured and dropped: LayerNorm formed INSIDE the skinny GEMM that consumes it — every workgroup normalising
+// its token blocks itself, statistics pass + per-fragment arithmetic — to save the 24 LayerNorm launches of a small
+// forward: the redundant arithmetic in N / 32 workgroups cost more than the launches it saved — one 32-token query
+// 0.57 -> 0.66 ms, 16 x 64 tokens 1.0 -> 1.5 ms.)
 // the Q/K projection and the V projection of a layer in ONE launch (small inputs are a chain of ~100 dependent launches of
 // 4-6 us: one fewer per layer); blocks [0, n_qk) run the first problem, the rest the second — same arithmetic per block
 __global__ __launch_bounds__(256) void k_gemm_skinny_qkv(GemmParams pq, GemmParams pv, int n_qk) {
@@ -1185,27 +1189,41 @@ __global__ __launch_bounds__(256) void k_pool(PoolParams p) {
   const int b = blockIdx.x, tid = threadIdx.x;
   const int len = p.lens[b];
   float *orow = p.out + (int64_t)(p.out_rows ? p.out_rows[b] : b) * p.H;
+  // the row's values stay in registers until they are final (the output may be pinned HOST memory: written once, never
+  // read back); H <= 2048, checked at create
+  constexpr int PER = 8;
+  float val[PER];
   float ss = 0.f;
-  for (int f = tid; f < p.H; f += 256) {
-    const int kb = f / 16, off = f % 16, g = off / 8, hh = (off % 8) / 4, jj = off % 4, j = g * 4 + jj;
-    const int nt = p.pooling == 1 ? 1 : len;
-    float acc = 0.f;
-    for (int t = 0; t < nt; ++t) {
-      const int64_t tok = (int64_t)b * p.Lp + t;
-      acc += p.res[(((tok >> 5) * p.KB + kb) * 64 + (tok & 31) + 32 * hh) * 8 + j];
+#pragma unroll
+  for (int e = 0; e < PER; ++e) {
+    const int f = tid + e * 256;
+    val[e] = 0.f;
+    if (f < p.H) {
+      const int kb = f / 16, off = f % 16, g = off / 8, hh = (off % 8) / 4, jj = off % 4, j = g * 4 + jj;
+      const int nt = p.pooling == 1 ? 1 : len;
+      float acc = 0.f;
+      for (int t = 0; t < nt; ++t) {
+        const int64_t tok = (int64_t)b * p.Lp + t;
+        acc += p.res[(((tok >> 5) * p.KB + kb) * 64 + (tok & 31) + 32 * hh) * 8 + j];
+      }
+      // sentence-transformers: sum / clamp(mask_sum, 1e-9)
+      const float v = p.pooling == 1 ? acc : acc / fmaxf((float)len, 1e-9f);
+      val[e] = v;
+      ss += v * v;
     }
-    // sentence-transformers: sum / clamp(mask_sum, 1e-9)
-    const float v = p.pooling == 1 ? acc : acc / fmaxf((float)len, 1e-9f);
-    orow[f] = v;
-    ss += v * v;
   }
+  float nrm = 1.f;
   if (p.normalize) {
     for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
     if ((tid & 63) == 0) s_red[tid >> 6] = ss;
     __syncthreads();
     // torch.nn.functional.normalize: x / max(||x||, 1e-12)
-    const float nrm = fmaxf(sqrtf(s_red[0] + s_red[1] + s_red[2] + s_red[3]), 1e-12f);
-    for (int f = tid; f < p.H; f += 256) orow[f] /= nrm;
+    nrm = fmaxf(sqrtf(s_red[0] + s_red[1] + s_red[2] + s_red[3]), 1e-12f);
+  }
+#pragma unroll
+  for (int e = 0; e < PER; ++e) {
+    const int f = tid + e * 256;
+    if (f < p.H) orow[f] = p.normalize ? val[e] / nrm : val[e];
   }
 }
 
@@ -1235,14 +1253,19 @@ struct anr_encoder {
   bool finalized = false;
   // workspace
   int64_t ws_tokens = 0;
-  int *d_ids = nullptr, *d_types = nullptr, *d_lens = nullptr, *d_rows = nullptr;
-  int64_t ws_b = 0, ws_bl = 0;
+  int *d_ids = nullptr, *d_types = nullptr, *d_lens = nullptr, *d_rows = nullptr;  // carved from d_in
+  int *d_in = nullptr;      // device block [ids B*L | types B*L | lens B | rows B]
+  int *pin_in = nullptr;    // the same block in pinned host memory: ONE host-to-device copy per forward
+  float *pin_out = nullptr, *pin_out_dev = nullptr;  // small batches: k_pool writes the embeddings straight to pinned host memory
+  int64_t ws_b = 0, ws_in = 0;
   float *res = nullptr, *out = nullptr;  // res: the last LayerNorm's output in f32 (pooling input)
   _Float16 *act = nullptr, *delta = nullptr, *qk = nullptr, *vt = nullptr, *ctx = nullptr, *ffn = nullptr;
   _Float16 *big = nullptr;  // the block qk / vt / ctx / ffn point into
 };
 
 namespace {
+
+constexpr size_t kPinOutBytes = 64 << 10;  // embeddings of a small batch go straight to pinned host memory
 
 template <typename T>
 int enc_alloc(T **p, int64_t n) {
@@ -1399,20 +1422,27 @@ int ensure_ws(anr_encoder *e, int B, int L, int Lp) {
     e->ws_tokens = T;
   }
   if (B > e->ws_b) {
-    enc_free(e->d_lens);
-    enc_free(e->d_rows);
     enc_free(e->out);
-    ANR_TRY(enc_alloc(&e->d_lens, B));
-    ANR_TRY(enc_alloc(&e->d_rows, B));
     ANR_TRY(enc_alloc(&e->out, (int64_t)B * c.hidden));
     e->ws_b = B;
   }
-  if ((int64_t)B * L > e->ws_bl) {
-    enc_free(e->d_ids);
-    enc_free(e->d_types);
-    ANR_TRY(enc_alloc(&e->d_ids, (int64_t)B * L));
-    ANR_TRY(enc_alloc(&e->d_types, (int64_t)B * L));
-    e->ws_bl = (int64_t)B * L;
+  const int64_t n_in = 2 * (int64_t)B * L + 2 * (int64_t)B;
+  if (n_in > e->ws_in) {
+    enc_free(e->d_in);
+    if (e->pin_in) (void)hipHostFree(e->pin_in);
+    e->pin_in = nullptr;
+    e->ws_in = 0;
+    ANR_TRY(enc_alloc(&e->d_in, n_in + n_in / 2));
+    ANR_HIP(hipHostMalloc(reinterpret_cast<void **>(&e->pin_in), (size_t)(n_in + n_in / 2) * sizeof(int), hipHostMallocDefault));
+    e->ws_in = n_in + n_in / 2;
+  }
+  e->d_ids = e->d_in;
+  e->d_types = e->d_in + (int64_t)B * L;
+  e->d_lens = e->d_in + 2 * (int64_t)B * L;
+  e->d_rows = e->d_lens + B;
+  if (!e->pin_out) {
+    ANR_HIP(hipHostMalloc(reinterpret_cast<void **>(&e->pin_out), kPinOutBytes, hipHostMallocDefault));
+    ANR_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&e->pin_out_dev), e->pin_out, 0));
   }
   return ANR_OK;
 }
@@ -1429,6 +1459,7 @@ int anr_encoder_create(const anr_encoder_config *cfg, int32_t device, anr_encode
       c.max_positions <= 0 || c.type_vocab_size <= 0)
     return fail(ANR_EINVAL, "encoder config has non-positive sizes");
   if (c.hidden % 32 || c.intermediate % 32) return fail(ANR_EINVAL, "hidden and intermediate sizes must be multiples of 32");
+  if (c.hidden > 2048) return fail(ANR_EINVAL, "hidden size %d not supported (at most 2048)", c.hidden);
   if (c.hidden % c.n_heads) return fail(ANR_EINVAL, "hidden not divisible by heads");
   const int dh = c.hidden / c.n_heads;
   if (dh != 32 && dh != 64 && dh != 128) return fail(ANR_EINVAL, "head size %d not supported (32, 64, 128)", dh);
@@ -1461,7 +1492,9 @@ int anr_encoder_destroy(anr_encoder *e) {
     enc_free(l.bqk); enc_free(l.bv); enc_free(l.bo); enc_free(l.b1); enc_free(l.b2);
     enc_free(l.ln1g); enc_free(l.ln1b); enc_free(l.ln2g); enc_free(l.ln2b);
   }
-  enc_free(e->d_ids); enc_free(e->d_types); enc_free(e->d_lens); enc_free(e->d_rows);
+  enc_free(e->d_in);
+  if (e->pin_in) (void)hipHostFree(e->pin_in);
+  if (e->pin_out) (void)hipHostFree(e->pin_out);
   enc_free(e->res); enc_free(e->delta); enc_free(e->out);
   enc_free(e->act); enc_free(e->big);
   if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -1642,18 +1675,27 @@ int forward_impl(anr_encoder *e, const int32_t *ids, const int32_t *lengths, con
   const int Lp = (int)round_up(L, 32);
   ANR_TRY(ensure_ws(e, B, L, Lp));
   hipStream_t st = e->stream;
-  ANR_HIP(hipMemcpyAsync(e->d_ids, ids, (size_t)B * L * sizeof(int), hipMemcpyHostToDevice, st));
-  if (type_ids) ANR_HIP(hipMemcpyAsync(e->d_types, type_ids, (size_t)B * L * sizeof(int), hipMemcpyHostToDevice, st));
-  ANR_HIP(hipMemcpyAsync(e->d_lens, lengths, (size_t)B * sizeof(int), hipMemcpyHostToDevice, st));
-  if (out_dev && out_rows) ANR_HIP(hipMemcpyAsync(e->d_rows, out_rows, (size_t)B * sizeof(int), hipMemcpyHostToDevice, st));
-  float *out = out_dev ? out_dev : e->out;
+  // ONE copy from pinned memory carries ids, token types, lengths and output rows (four pageable copies cost ~20 us
+  // each in staging: a seventh of a single-query forward)
+  {
+    const int64_t BL = (int64_t)B * L;
+    std::memcpy(e->pin_in, ids, (size_t)BL * sizeof(int));
+    if (type_ids) std::memcpy(e->pin_in + BL, type_ids, (size_t)BL * sizeof(int));
+    std::memcpy(e->pin_in + 2 * BL, lengths, (size_t)B * sizeof(int));
+    if (out_dev && out_rows) std::memcpy(e->pin_in + 2 * BL + B, out_rows, (size_t)B * sizeof(int));
+    ANR_HIP(hipMemcpyAsync(e->d_in, e->pin_in, (size_t)(2 * BL + 2 * B) * sizeof(int), hipMemcpyHostToDevice, st));
+  }
+  const bool direct_out = out_host && (size_t)B * c.hidden * sizeof(float) <= kPinOutBytes;
+  float *out = out_dev ? out_dev : (direct_out ? e->pin_out_dev : e->out);
   const int *rows = (out_dev && out_rows) ? e->d_rows : nullptr;
   // (Replaying the kernel sequence from a captured hipGraph was tried for small forwards — a query at a time is ~100
   // dependent launches — and changed nothing: 0.80 vs 0.76 ms; the time is inside the tiny kernels, not between them.)
   enqueue_forward(e, B, L, Lp, type_ids != nullptr, normalize, out, rows);
   ANR_HIP(hipGetLastError());
-  if (out_host) ANR_HIP(hipMemcpyAsync(out_host, e->out, (size_t)B * c.hidden * sizeof(float), hipMemcpyDeviceToHost, st));
+  if (out_host && !direct_out)
+    ANR_HIP(hipMemcpyAsync(out_host, e->out, (size_t)B * c.hidden * sizeof(float), hipMemcpyDeviceToHost, st));
   ANR_HIP(hipStreamSynchronize(st));
+  if (direct_out) std::memcpy(out_host, e->pin_out, (size_t)B * c.hidden * sizeof(float));
   return ANR_OK;
 }
 }  // namespace
