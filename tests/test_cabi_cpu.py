@@ -195,3 +195,70 @@ def test_c_result_shaping_builds_the_same_objects_as_the_python_loops():
         exp = [[{"index": i, "score": s, "rank": r, "similarity": m} for r, (i, s, m) in enumerate(zip(a, b, c)) if i != -1]
                for a, b, c in zip(I.tolist(), S.tolist(), sim)]
         assert vim._shape_hits(I, S, cosine) == exp
+
+
+def test_sentence_encoder_token_slices_bound_a_forward():
+    """host logic: a tokenised batch is cut into forwards of at most max_forward_tokens padded tokens (255 long
+    notes under a long-context model must not become one 2 M-token forward)"""
+    from anorag_hip.encoder import SentenceEncoder
+    enc = object.__new__(SentenceEncoder)
+    enc.max_forward_tokens = 1000
+    lens = np.array([500, 400, 100, 90, 33, 10, 5])
+    cuts = list(enc._token_slices(lens))
+    assert cuts == [(0, 1, 500), (1, 3, 400), (3, 7, 90)]
+    for a, b, L in cuts:
+        assert L == lens[a:b].max() and ((b - a) * ((L + 31) // 32 * 32) <= 1000 or b - a == 1)
+    enc.max_forward_tokens = 1 << 18
+    assert list(enc._token_slices(lens)) == [(0, 7, 500)]
+    assert list(enc._token_slices(np.array([], dtype=np.int64))) == []
+    enc.max_forward_tokens = 1          # a single sentence always goes through
+    assert list(enc._token_slices(np.array([40, 30]))) == [(0, 1, 40), (1, 2, 30)]
+
+
+@pytest.mark.parametrize("sizes,pool,method", [((5000, 5000, 900, 0), 50, "linear"), ((5000, 5000, 900, 300), 50, "linear"),
+                                               ((4100, 700, 600, 500), 80, "linear"), ((6000, 10, 5, 3), 1500, "linear"),
+                                               ((6000, 10, 5, 3), 1500, "rrf"), ((5000, 900, 0, 0), 50, "rrf"),
+                                               ((5000, 1200, 0, 0), 50, "rrf"), ((5000, 10, 0, 5), 50, "rrf")])
+def test_fuse_long_routing_respects_the_kernel_limits(monkeypatch, sizes, pool, method):
+    """host logic of HybridSearcher._fuse_long (no device): which sources go to anr_fuse_dense as arrays — the call must
+    satisfy the limits the C side checks (short-list entries <= 1024, n_arr * (pool + 2 m) + m <= 4096, pool <= 1024, rrf:
+    one array with a non-negative weight) or go to the sorting path / the rounds"""
+    from retrieval import hybrid_search as hsm
+    calls = []
+
+    class FakeArray:
+        def __init__(self, a):
+            self.a, self.row_max, self.nq, self.n, self.dtype = a, None, a.shape[0], a.shape[1], a.dtype
+
+        @classmethod
+        def from_numpy(cls, a, device=0, with_max=False):
+            return cls(np.asarray(a))
+
+        def free(self):
+            pass
+
+    def fake_fuse_dense(m, weights, rrf_k, pl, nq, sources, device=0, want_stats=False):
+        n_arr = sum(isinstance(v, FakeArray) for v in sources.values())
+        short = sum(len(v[0][0]) for v in sources.values() if not isinstance(v, FakeArray))
+        calls.append((m, pl, n_arr, short))
+        assert pl <= 1024 and short <= 1024 and n_arr * (pl + 2 * short) + short <= 4096 and n_arr >= 1
+        if m == "rrf":
+            assert n_arr == 1
+        return (np.full((1, pl), -1, np.int64), np.zeros((1, pl)), np.zeros((1, pl, 4)), np.zeros(1, np.int32))
+
+    monkeypatch.setattr(hsm, "DeviceArray", FakeArray)
+    monkeypatch.setattr(hsm, "fuse_dense", fake_fuse_dense)
+    sorted_path = []
+    monkeypatch.setattr(hsm.HybridSearcher, "_fuse_rrf_long", lambda self, dicts, pl: sorted_path.append(pl) or [])
+    rng = np.random.default_rng(1)
+    lists = []
+    for m in sizes:
+        ids = rng.choice(9000, m, replace=False)
+        lists.append([(f"n{int(i)}", float(s)) for i, s in zip(ids, rng.random(m))])
+    hs = hsm.HybridSearcher({"retrieval": {"candidate_pool": pool, "hybrid": {"fusion_method": method, "rrf_k": 60,
+                                                                               "weights": {"dense": 1.0, "bm25": 0.5, "graph": 0.5, "path": 0.1}}}})
+    assert hs._fuse_long(tuple(lists), pool) == []
+    if method == "rrf" and (pool > 1024 or sizes[1] > 1024):
+        assert sorted_path and not calls          # several long lists / a big pool: ranked by device sorts
+    else:
+        assert calls and not sorted_path
