@@ -311,7 +311,10 @@ class SentenceEncoder:
         while i < n:
             first = max(len(sentences[order[i]]), 1)
             j = i + 1
-            while j < n and j - i < fb and (j - i < 16 or len(sentences[order[j]]) * 10 >= first * 6):
+            # (short texts are not cut: a forward is padded to a multiple of 32 tokens anyway, and below ~100 tokens a
+            # second, smaller forward costs more than the padding it saves — 256 queries of 17-33 words: 8.2 ms cut in
+            # two, 6.0-6.7 ms as one)
+            while j < n and j - i < fb and (j - i < 16 or first < 512 or len(sentences[order[j]]) * 10 >= first * 6):
                 j += 1
             sels.append(order[i:j])
             i = j
