@@ -56,7 +56,8 @@ class SearchStats(C.Structure):
 class FuseSource(C.Structure):
     _fields_ = [("array_dev", C.c_void_p), ("array_len", C.c_int64), ("array_dtype", C.c_int32),
                 ("list_ids", C.c_void_p), ("list_scores", C.c_void_p), ("list_offs", C.c_void_p),
-                ("array_max_dev", C.c_void_p)]
+                ("array_max_dev", C.c_void_p), ("sparse_ids_dev", C.c_void_p), ("sparse_scores_dev", C.c_void_p),
+                ("sparse_count_dev", C.c_void_p), ("sparse_cap", C.c_int64)]
 
 
 class FuseDenseStats(C.Structure):
@@ -151,6 +152,8 @@ SIGNATURES = {
                                       C.c_void_p]),
     "anr_bm25_combine_fields": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32,
                                           C.c_void_p, C.c_void_p]),
+    "anr_bm25_sparse_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "anr_bm25_create": (C.c_int, [C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.POINTER(C.c_void_p)]),
     "anr_bm25_destroy": (C.c_int, [C.c_void_p]),

@@ -110,6 +110,30 @@ class DeviceBM25:
                                                  C.c_void_p(out.ptr), C.c_void_p(out.row_max.ptr)), "anr_bm25_scores_dev")
         return out
 
+    SPARSE_CAP = 6144  # documents one query's postings may touch on the sparse path (kSpMaxCap, csrc/bm25.hip)
+
+    def scores_sparse_device(self, queries: Sequence[Sequence[str]], normalize: bool = True, cap: int = SPARSE_CAP,
+                             allow_overflow: bool = False):
+        """the same scores as ``scores_device`` in SPARSE form (``anorag_hip.fusion.SparseRows``): per query the
+        documents its postings touch and their scores, left in device memory for ``fuse_dense`` — the N-vector is never
+        formed.  A query that touches more than `cap` documents cannot be held: with ``allow_overflow`` its row is
+        marked (``counts[i] == -1``: score that query with ``scores_device``), otherwise None is returned."""
+        from .fusion import SparseRows
+        indptr, terms = self._encode_queries(queries)
+        nq = len(queries)
+        out = SparseRows(nq, self.doc_count, cap, self.device)
+        cnt = np.empty((nq,), dtype=np.int32)
+        _lib.check(self._lib.anr_bm25_sparse_dev(self._h, nq, indptr.ctypes.data_as(C.c_void_p),
+                                                 terms.ctypes.data_as(C.c_void_p), int(bool(normalize)), int(cap),
+                                                 C.c_void_p(out.ids_ptr), C.c_void_p(out.scores_ptr),
+                                                 C.c_void_p(out.count_ptr), C.c_void_p(out.max_ptr),
+                                                 cnt.ctypes.data_as(C.c_void_p)), "anr_bm25_sparse_dev")
+        if nq and int(cnt.min()) < 0 and not allow_overflow:
+            out.free()
+            return None
+        out.counts = cnt
+        return out
+
     def nonzero_batch(self, queries: Sequence[Sequence[str]], normalize: bool = True, cap: int = 4096):
         """per query: (doc ids, scores) of the documents with a non-zero score, best first, at most `cap`"""
         indptr, terms = self._encode_queries(queries)

@@ -87,9 +87,91 @@ class DeviceArray:
             pass
 
 
+class SparseRows:
+    """[nq] rows over ``n`` ids in SPARSE form, in device memory: per row up to ``cap`` explicit (id, value) entries
+    (uint32 / float64, any order, ids distinct), every other id holds 0.0 — ``anr_fuse_source.sparse_*``.  What
+    ``DeviceBM25.scores_sparse_device`` returns; ``fuse_dense`` takes it wherever it takes a ``DeviceArray`` and gives
+    the same results without streaming n scores per query."""
+
+    def __init__(self, nq: int, n: int, cap: int, device: int = 0):
+        self.nq, self.n, self.cap, self.device = int(nq), int(n), int(cap), int(device)
+        self._bufs = []
+        lib = _lib.load()
+        for nbytes in (self.nq * self.cap * 4, self.nq * self.cap * 8, self.nq * 4, self.nq * 8):
+            p = C.c_void_p()
+            _lib.check(lib.anr_device_malloc(self.device, max(nbytes, 8), C.byref(p)), "anr_device_malloc")
+            self._bufs.append(p.value)
+        self.ids_ptr, self.scores_ptr, self.count_ptr, self.max_ptr = self._bufs
+        self.counts: Optional[np.ndarray] = None  # host copy of the row lengths, when the producer returned them
+
+    @classmethod
+    def wrap(cls, ids_ptr: int, scores_ptr: int, count_ptr: int, nq: int, n: int, cap: int, device: int = 0) -> "SparseRows":
+        """a view of device buffers owned by someone else (uint32 [nq, cap], float64 [nq, cap], int32 [nq]): never freed here"""
+        self = object.__new__(cls)
+        self.nq, self.n, self.cap, self.device = int(nq), int(n), int(cap), int(device)
+        self._bufs = []
+        self.ids_ptr, self.scores_ptr, self.count_ptr, self.max_ptr = int(ids_ptr), int(scores_ptr), int(count_ptr), None
+        self.counts = None
+        return self
+
+    @classmethod
+    def from_numpy(cls, rows: Sequence[Tuple[np.ndarray, np.ndarray]], n: int, cap: Optional[int] = None,
+                   device: int = 0) -> "SparseRows":
+        """rows[i] = (ids, values) of row i"""
+        nq = len(rows)
+        cap = int(cap or max([len(a) for a, _ in rows] + [1]))
+        ids = np.zeros((nq, cap), dtype=np.uint32)
+        val = np.zeros((nq, cap), dtype=np.float64)
+        cnt = np.zeros((nq,), dtype=np.int32)
+        for i, (a, b) in enumerate(rows):
+            if len(a) > cap:
+                raise ValueError(f"row {i} holds {len(a)} entries, cap is {cap}")
+            ids[i, :len(a)] = np.asarray(a, dtype=np.uint32)
+            val[i, :len(a)] = np.asarray(b, dtype=np.float64)
+            cnt[i] = len(a)
+        out = cls(nq, n, cap, device)
+        lib = _lib.load()
+        for ptr, arr in ((out.ids_ptr, ids), (out.scores_ptr, val), (out.count_ptr, cnt)):
+            if arr.nbytes:
+                _lib.check(lib.anr_device_copy(device, C.c_void_p(ptr), arr.ctypes.data_as(C.c_void_p), arr.nbytes, 0),
+                           "anr_device_copy")
+        out.counts = cnt
+        return out
+
+    def numpy(self) -> List[Tuple[np.ndarray, np.ndarray]]:
+        """the rows back on the host, each sorted by id"""
+        lib = _lib.load()
+        ids = np.empty((self.nq, self.cap), dtype=np.uint32)
+        val = np.empty((self.nq, self.cap), dtype=np.float64)
+        cnt = np.empty((self.nq,), dtype=np.int32)
+        for ptr, arr in ((self.ids_ptr, ids), (self.scores_ptr, val), (self.count_ptr, cnt)):
+            if arr.nbytes:
+                _lib.check(lib.anr_device_copy(self.device, arr.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), arr.nbytes, 1),
+                           "anr_device_copy")
+        out = []
+        for i in range(self.nq):
+            k = max(int(cnt[i]), 0)
+            order = np.argsort(ids[i, :k], kind="stable")
+            out.append((ids[i, :k][order].astype(np.int64), val[i, :k][order]))
+        return out
+
+    def free(self) -> None:
+        for b in getattr(self, "_bufs", []):
+            if b:
+                _lib.load().anr_device_free(self.device, C.c_void_p(b))
+        self._bufs = []
+
+    def __del__(self):  # pragma: no cover - best effort
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 def fuse_dense(method: str, weights: Dict[str, float], rrf_k: float, pool: int, nq: int,
                sources: Dict[str, Any], device: int = 0, want_stats: bool = False):
-    """sources[name] is a ``DeviceArray`` ([nq, N]: every id < N present, NaN = absent), or a sequence of nq
+    """sources[name] is a ``DeviceArray`` ([nq, N]: every id < N present, NaN = absent), a ``SparseRows`` (the same
+    rows given by their non-zero entries; one source at most, the others lists), or a sequence of nq
     ``(ids int64[], scores float64[])`` short lists (the caller's order), or None / missing.
     Returns (ids [nq, pool] int64 (-1 padded), finals [nq, pool] float64, src [nq, pool, 4] float64 (NaN = absent),
     counts [nq] int32[, stats dict])."""
@@ -99,6 +181,15 @@ def fuse_dense(method: str, weights: Dict[str, float], rrf_k: float, pool: int, 
     for si, name in enumerate(SOURCES):
         v = sources.get(name)
         if v is None:
+            continue
+        if isinstance(v, SparseRows):
+            if v.nq != nq:
+                raise ValueError(f"{name}: {v.nq} sparse rows, expected {nq}")
+            src[si].array_len = v.n
+            src[si].sparse_ids_dev = v.ids_ptr
+            src[si].sparse_scores_dev = v.scores_ptr
+            src[si].sparse_count_dev = v.count_ptr
+            src[si].sparse_cap = v.cap
             continue
         if isinstance(v, DeviceArray):
             if v.nq != nq:

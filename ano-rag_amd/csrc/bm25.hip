@@ -114,6 +114,101 @@ __global__ __launch_bounds__(1024) void k_bm25(Bm25Params p) {
   }
 }
 
+// The same scoring without the N-vector: one workgroup accumulates its query in an LDS hash table keyed by the
+// document (open addressing, linear probing).  Tokens in query order with a barrier between them and every document at
+// most once per token: a document's additions happen in the reference's order, one at a time -> the same float64 sums
+// as k_bm25.  Output: the touched documents, unordered, for anr_fuse_dense's sparse source.
+constexpr int kSpTable = 8192;    // slots (a power of two)
+constexpr int kSpMaxCap = 6144;   // documents a row may hold: the table stays below 7/8 full even when every thread of
+                                  // the round that crosses the limit inserts one more
+constexpr unsigned kSpEmpty = 0xffffffffu;
+struct Bm25SparseParams {
+  const int64_t *indptr;
+  const int32_t *docs;
+  const double *weights;
+  int64_t n_docs;
+  const int64_t *q_indptr;
+  const int32_t *q_terms;
+  int normalize;
+  int cap;
+  unsigned *out_id;    // [nq][cap]
+  double *out_val;     // [nq][cap]
+  int *out_cnt;        // [nq]: documents written, or -1 (more than cap: the row is unusable)
+  double *max_out;     // [nq] or nullptr
+};
+
+__global__ __launch_bounds__(1024) void k_bm25_sparse(Bm25SparseParams p) {
+  extern __shared__ unsigned char bm_smem[];
+  double *vals = reinterpret_cast<double *>(bm_smem);
+  unsigned *keys = reinterpret_cast<unsigned *>(bm_smem + (size_t)kSpTable * 8);
+  __shared__ double s_red[16];
+  __shared__ double s_max;
+  __shared__ int s_cnt, s_out;
+  const int q = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < kSpTable; i += 1024) {
+    keys[i] = kSpEmpty;
+    vals[i] = 0.0;
+  }
+  if (tid == 0) {
+    s_cnt = 0;
+    s_out = 0;
+  }
+  __syncthreads();
+  for (int64_t t = p.q_indptr[q]; t < p.q_indptr[q + 1]; ++t) {
+    const int term = p.q_terms[t];
+    const int64_t lo = p.indptr[term], hi = p.indptr[term + 1];
+    for (int64_t e = lo + tid; e < hi; e += 1024) {
+      if (*reinterpret_cast<volatile int *>(&s_cnt) > p.cap) break;  // overflow: the row is given up below
+      const unsigned doc = (unsigned)p.docs[e];
+      unsigned slot = (doc * 2654435761u) >> 19;  // 13 bits
+      for (;;) {
+        const unsigned old = atomicCAS(&keys[slot], kSpEmpty, doc);
+        if (old == kSpEmpty) {
+          atomicAdd(&s_cnt, 1);
+          break;
+        }
+        if (old == doc) break;
+        slot = (slot + 1) & (kSpTable - 1);
+      }
+      vals[slot] += p.weights[e];  // this token's only posting of the document
+    }
+    __syncthreads();
+  }
+  const int count = s_cnt;
+  if (count > p.cap) {
+    if (tid == 0) {
+      p.out_cnt[q] = -1;
+      if (p.max_out) p.max_out[q] = __builtin_nan("");
+    }
+    return;
+  }
+  // the row's maximum over all n_docs scores: the touched ones, and 0.0 when a document was left untouched
+  double m = (int64_t)count < p.n_docs ? 0.0 : -__builtin_inf();
+  for (int i = tid; i < kSpTable; i += 1024)
+    if (keys[i] != kSpEmpty) m = fmax(m, vals[i]);
+  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+  if ((tid & 63) == 0) s_red[tid >> 6] = m;
+  __syncthreads();
+  if (tid == 0) {
+    double mm = s_red[0];
+    for (int w = 1; w < 16; ++w) mm = fmax(mm, s_red[w]);
+    s_max = mm;
+  }
+  __syncthreads();
+  const double mx = s_max;
+  const bool divide = p.normalize && mx > 0.0;
+  for (int i = tid; i < kSpTable; i += 1024)
+    if (keys[i] != kSpEmpty) {
+      const int pos = atomicAdd(&s_out, 1);
+      p.out_id[(int64_t)q * p.cap + pos] = keys[i];
+      p.out_val[(int64_t)q * p.cap + pos] = divide ? vals[i] / mx : vals[i];
+    }
+  if (tid == 0) {
+    p.out_cnt[q] = count;
+    if (p.max_out) p.max_out[q] = divide ? 1.0 : mx;
+  }
+}
+
 // compaction of the non-zero scores of each query: (doc, score) pairs, unordered
 struct NzParams {
   const double *scores;
@@ -232,10 +327,11 @@ int validate_queries(const anr_bm25 *h, int64_t nq, const int64_t *q_indptr, con
 
 // runs the scoring of one chunk of queries into the handle's score buffer (*d_scores points into it: valid until the
 // next call on the handle) or, when `into` is given, into that caller-owned device buffer
-int score_chunk(anr_bm25 *h, int64_t nq, const int64_t *q_indptr, const int32_t *q_terms, int normalize,
-                double **d_scores, double *into = nullptr, double *max_into = nullptr) {
+// the queries' offsets (made relative) and terms into the handle's device buffer, on its stream; `rel` must outlive the copy
+int upload_queries(anr_bm25 *h, int64_t nq, const int64_t *q_indptr, const int32_t *q_terms, std::vector<int64_t> &rel,
+                   int64_t **dq_out, int32_t **dt_out) {
   const int64_t nt = q_indptr[nq] - q_indptr[0];
-  std::vector<int64_t> rel(nq + 1);
+  rel.resize(nq + 1);
   for (int64_t i = 0; i <= nq; ++i) rel[i] = q_indptr[i] - q_indptr[0];
   const int64_t q_bytes = (nq + 1) * 8 + (nt > 0 ? nt : 1) * 4;
   if (q_bytes > h->q_cap) {
@@ -246,6 +342,20 @@ int score_chunk(anr_bm25 *h, int64_t nq, const int64_t *q_indptr, const int32_t 
   }
   int64_t *dq = reinterpret_cast<int64_t *>(h->q_buf);
   int32_t *dt = reinterpret_cast<int32_t *>(h->q_buf + (nq + 1) * 8);
+  hipError_t e = hipMemcpyAsync(dq, rel.data(), (size_t)(nq + 1) * 8, hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess && nt > 0)
+    e = hipMemcpyAsync(dt, q_terms + q_indptr[0], (size_t)nt * 4, hipMemcpyHostToDevice, h->stream);
+  if (e != hipSuccess) return fail(ANR_EHIP, "bm25 query upload failed: %s", hipGetErrorString(e));
+  *dq_out = dq;
+  *dt_out = dt;
+  return ANR_OK;
+}
+
+int score_chunk(anr_bm25 *h, int64_t nq, const int64_t *q_indptr, const int32_t *q_terms, int normalize,
+                double **d_scores, double *into = nullptr, double *max_into = nullptr) {
+  std::vector<int64_t> rel;
+  int64_t *dq = nullptr;
+  int32_t *dt = nullptr;
   if (into) {
     *d_scores = into;
   } else {
@@ -257,10 +367,8 @@ int score_chunk(anr_bm25 *h, int64_t nq, const int64_t *q_indptr, const int32_t 
     }
     *d_scores = h->score_buf;
   }
-  hipError_t e = hipMemcpyAsync(dq, rel.data(), (size_t)(nq + 1) * 8, hipMemcpyHostToDevice, h->stream);
-  if (e == hipSuccess && nt > 0)
-    e = hipMemcpyAsync(dt, q_terms + q_indptr[0], (size_t)nt * 4, hipMemcpyHostToDevice, h->stream);
-  if (e == hipSuccess) e = hipMemsetAsync(*d_scores, 0, (size_t)nq * h->n_docs * 8, h->stream);
+  ANR_TRY(upload_queries(h, nq, q_indptr, q_terms, rel, &dq, &dt));
+  hipError_t e = hipMemsetAsync(*d_scores, 0, (size_t)nq * h->n_docs * 8, h->stream);
   if (e == hipSuccess) {
     Bm25Params p{h->indptr, h->docs, h->weights, h->n_docs, dq, dt, *d_scores, normalize, max_into};
     hipLaunchKernelGGL(k_bm25, dim3((unsigned)nq), dim3(1024), 0, h->stream, p);
@@ -362,6 +470,31 @@ int anr_bm25_scores_dev(anr_bm25 *h, int64_t nq, const int64_t *q_indptr, const 
   std::lock_guard<std::mutex> lk(h->mu);
   double *d = nullptr;
   return score_chunk(h, nq, q_indptr, q_terms, normalize, &d, out_dev, max_dev);
+}
+
+int anr_bm25_sparse_dev(anr_bm25 *h, int64_t nq, const int64_t *q_indptr, const int32_t *q_terms, int32_t normalize,
+                        int32_t cap, uint32_t *ids_dev, double *scores_dev, int32_t *count_dev, double *max_dev,
+                        int32_t *out_count_host) {
+  ANR_TRY(validate_queries(h, nq, q_indptr, q_terms));
+  if (cap <= 0 || cap > kSpMaxCap) return fail(ANR_EINVAL, "cap must be in [1, %d]", kSpMaxCap);
+  if (!ids_dev || !scores_dev || !count_dev) return fail(ANR_EINVAL, "null output arrays");
+  if (nq == 0) return ANR_OK;
+  DeviceGuard g(h->device);
+  std::lock_guard<std::mutex> lk(h->mu);
+  std::vector<int64_t> rel;
+  int64_t *dq = nullptr;
+  int32_t *dt = nullptr;
+  ANR_TRY(upload_queries(h, nq, q_indptr, q_terms, rel, &dq, &dt));
+  const int lds = kSpTable * 12;
+  ANR_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_bm25_sparse), lds));
+  Bm25SparseParams p{h->indptr, h->docs, h->weights, h->n_docs, dq, dt, normalize, cap, ids_dev, scores_dev, count_dev, max_dev};
+  hipLaunchKernelGGL(k_bm25_sparse, dim3((unsigned)nq), dim3(1024), (size_t)lds, h->stream, p);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess && out_count_host)
+    e = hipMemcpyAsync(out_count_host, count_dev, (size_t)nq * 4, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (e != hipSuccess) return fail(ANR_EHIP, "bm25 sparse scoring failed: %s", hipGetErrorString(e));
+  return ANR_OK;
 }
 
 int anr_bm25_combine_fields(int32_t device, int32_t n_fields, const double *const *field_scores_dev, const double *weights,

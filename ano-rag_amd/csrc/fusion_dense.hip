@@ -62,6 +62,20 @@ struct FdSrc {
   const double *known_max;  // device [nq_total] maxima supplied by the caller, or nullptr (k_fd_max computes them)
 };
 
+// An array source handed over in SPARSE form (anr_fuse_source.sparse_*): explicit (id, value) entries, every other id of
+// the row is 0.0.  Kept out of FdSrc so that the streaming scan's code and registers do not change.
+constexpr int kFsSpMax = 8192;  // explicit entries per row
+struct FdSparse {
+  int src;              // the source (0..2) given in this form, -1: none
+  int cap;
+  const unsigned *in_id;   // the caller's rows [nq_total][cap], any order (indexed by q0 + q)
+  const double *in_val;
+  const int *in_cnt;
+  unsigned *id;         // [nq][cap] this sub-batch's rows sorted by id (k_fs_sort), values beside them
+  double *val;
+  int *cnt;             // [nq]
+};
+
 struct FdParams {
   int method;     // 0 linear, 1 rrf
   int r1_src;     // rrf: the one array source (0..2), ranked by raw value; -1 for linear
@@ -97,12 +111,31 @@ struct FdParams {
   int *o_rank;
   int64_t *o_offs;               // [nq][5]
   double *o_smax;                // [nq][4]
+  FdSparse sp;
 };
+
+__device__ __forceinline__ bool fd_is_array(const FdParams &p, int s) { return p.src[s].arr != nullptr || s == p.sp.src; }
 
 __device__ __forceinline__ bool fd_val(const FdSrc &s, int64_t q, int64_t i, double &v) {
   if (!s.arr || i >= s.len) return false;
   v = s.dtype == 0 ? reinterpret_cast<const double *>(s.arr)[q * s.len + i]
                    : (double)reinterpret_cast<const float *>(s.arr)[q * s.len + i];
+  return v == v;
+}
+// the value source s holds for id i of the sub-batch's query q (dense array or sparse rows; false: absent)
+__device__ __forceinline__ bool fd_val_any(const FdParams &p, int s, int q, int64_t i, double &v) {
+  if (s != p.sp.src) return fd_val(p.src[s], p.q0 + q, i, v);
+  if (i >= p.src[s].len) return false;
+  const unsigned *ids = p.sp.id + (int64_t)q * p.sp.cap;
+  int lo = 0, hi = p.sp.cnt[q];  // first entry with id >= i
+  const int n = hi;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if ((int64_t)ids[mid] < i) lo = mid + 1;
+    else hi = mid;
+  }
+  v = 0.0;  // not listed: an implicit zero
+  if (lo < n && (int64_t)ids[lo] == i) v = p.sp.val[(int64_t)q * p.sp.cap + lo];
   return v == v;
 }
 
@@ -331,12 +364,11 @@ __global__ __launch_bounds__(kFdThreads) void k_fd_prep(FdParams p) {
   }
   if (p.method != 1) return;
   // rrf: (key, id) of the unique ids present in the array source, descending by (value, lower id first)
-  const FdSrc &a = p.src[p.r1_src];
   for (int i = tid; i < kFdMaxSparse; i += kFdThreads) {
     unsigned long long k = 0ull;
     unsigned id = 0xffffffffu;
     double v;
-    if (i < mu && fd_val(a, p.q0 + q, (int64_t)su[i], v)) {
+    if (i < mu && fd_val_any(p, p.r1_src, q, (int64_t)su[i], v)) {
       k = d2ord(v);
       id = su[i];
     }
@@ -1034,7 +1066,7 @@ __global__ __launch_bounds__(kFdThreads) void k_fd_build(FdParams p) {
     const unsigned b0 = s_off[s];
     if (tid == 0) sh.cnt = 0;
     __syncthreads();
-    if (!p.src[s].arr) {
+    if (!fd_is_array(p, s)) {
       const int m = (int)(off[s + 1] - off[s]);
       for (int i = tid; i < m; i += kFdThreads) {
         oi[b0 + i] = p.l_ids[off[s] + i];
@@ -1048,7 +1080,7 @@ __global__ __launch_bounds__(kFdThreads) void k_fd_build(FdParams p) {
       for (int r0 = 0; r0 < n; r0 += kFdThreads) {
         const int r = r0 + tid;
         double v = 0.0;
-        const bool have = r < n && fd_val(p.src[s], p.q0 + q, (int64_t)s_id[r], v);
+        const bool have = r < n && fd_val_any(p, s, q, (int64_t)s_id[r], v);
         const unsigned long long hm = __ballot(have);
         if (hm) {
           unsigned wbase = 0;
@@ -1066,7 +1098,7 @@ __global__ __launch_bounds__(kFdThreads) void k_fd_build(FdParams p) {
       for (int j0 = 0; j0 < mu; j0 += kFdThreads) {
         const int j = j0 + tid;
         double v = 0.0;
-        bool have = j < mu && fd_val(p.src[s], p.q0 + q, (int64_t)su[j], v);
+        bool have = j < mu && fd_val_any(p, s, q, (int64_t)su[j], v);
         int rank = 0;
         if (have) {
           const unsigned id = su[j];
@@ -1108,12 +1140,228 @@ __global__ __launch_bounds__(kFdThreads) void k_fd_build(FdParams p) {
   if (tid < 5) p.o_offs[(int64_t)q * 5 + tid] = (int64_t)q * kFuseMax + s_off[tid];
   if (tid < 4) {
     double m = __builtin_nan("");
-    if (p.method == 0 && tid < 3 && p.src[tid].arr) {
+    if (p.method == 0 && tid < 3 && fd_is_array(p, tid)) {
       const unsigned long long o = p.smax_ord[(int64_t)q * 4 + tid];
       m = o ? ord2d(o) : -__builtin_inf();
     }
     p.o_smax[(int64_t)q * 4 + tid] = m;
   }
+}
+
+// ---- the sparse form of an array source ------------------------------------------------------------------------
+// A BM25 row over N notes has a few thousand non-zero scores.  Given as (id, value) entries the stream over N ids is not
+// needed at all; what k_fd_build consumes is produced from the entries:
+//   k_fs_sort   the row's entries sorted by id (bitonic, LDS) -> the lookup table fd_val_any bisects; linear: the row's
+//               maximum (an implicit zero takes part when the row has one)
+//   k_fs_stage  candidates = every explicit entry + the K' lowest ids that are NOT listed (implicit zeros: after the
+//               positive entries the best zero-valued ids are the lowest ones), keyed exactly as the scan keys them;
+//               rrf: the rank histogram H — explicit non-zero entries by bisection of the short-list keys, the N - nnz
+//               zeros by interval arithmetic between the zero-valued short-list ids (a zero entry with id i is beaten by
+//               the z_lo positive short-list keys and by the zero-valued ones with a lower id).
+// Same FdParams outputs as k_fd_max + k_fd_scan (smax_ord, c_hi / c_id / c_cnt, H), so k_fd_build and k_fuse<true> — and
+// the bit-exactness argument at the top of this file — carry over unchanged.
+__global__ __launch_bounds__(kFdThreads) void k_fs_sort(FdParams p, int P2max) {
+  extern __shared__ unsigned char fd_smem[];
+  unsigned *ids = reinterpret_cast<unsigned *>(fd_smem);
+  unsigned *idx = ids + P2max;
+  __shared__ double s_best[kFdThreads / 64];
+  __shared__ int s_any[kFdThreads / 64];
+  const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cap = p.sp.cap;
+  int nnz = p.sp.in_cnt[p.q0 + q];
+  nnz = nnz < 0 ? 0 : (nnz > cap ? cap : nnz);
+  int P2 = 2;
+  while (P2 < nnz) P2 <<= 1;
+  const unsigned *gi = p.sp.in_id + (p.q0 + q) * (int64_t)cap;
+  const double *gv = p.sp.in_val + (p.q0 + q) * (int64_t)cap;
+  for (int i = tid; i < P2; i += kFdThreads) {
+    ids[i] = i < nnz ? gi[i] : 0xffffffffu;
+    idx[i] = (unsigned)i;
+  }
+  __syncthreads();
+  for (int k2 = 2; k2 <= P2; k2 <<= 1)
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < P2; i += kFdThreads) {
+        const int x = i ^ j;
+        if (x > i) {
+          const unsigned a = ids[i], b = ids[x], ia = idx[i], ib = idx[x];
+          const bool b_first = b < a || (b == a && ib < ia), a_first = a < b || (a == b && ia < ib);
+          if (((i & k2) == 0) ? b_first : a_first) {
+            ids[i] = b; ids[x] = a;
+            idx[i] = ib; idx[x] = ia;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  double best = 0.0;
+  bool any = false;
+  for (int i = tid; i < nnz; i += kFdThreads) {
+    const double v = gv[idx[i]];
+    p.sp.id[(int64_t)q * cap + i] = ids[i];
+    p.sp.val[(int64_t)q * cap + i] = v;
+    if (v == v) {
+      best = (!any || v > best) ? v : best;
+      any = true;
+    }
+  }
+  if (tid == 0) p.sp.cnt[q] = nnz;
+  if (p.method != 0) return;
+  for (int o = 32; o > 0; o >>= 1) {
+    const double t = __shfl_xor(best, o);
+    const bool ta = __shfl_xor((int)any, o) != 0;
+    best = (ta && (!any || t > best)) ? t : best;
+    any = any || ta;
+  }
+  if (lane == 0) {
+    s_best[wave] = best;
+    s_any[wave] = any ? 1 : 0;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < kFdThreads / 64; ++w)
+      if (s_any[w] && (!any || s_best[w] > best)) {
+        best = s_best[w];
+        any = true;
+      }
+    if ((int64_t)nnz < p.src[p.sp.src].len) {  // an id that is not listed holds 0.0
+      best = (!any || 0.0 > best) ? 0.0 : best;
+      any = true;
+    }
+    p.smax_ord[(int64_t)q * 4 + p.sp.src] = any ? d2ord(best) : 0ull;
+  }
+}
+
+struct FsStageShared {
+  unsigned sid[kFsSpMax];
+  unsigned long long sk_hi[kFdMaxSparse];
+  unsigned sk_id[kFdMaxSparse];
+  unsigned H[kFdMaxSparse + 1];
+  unsigned nzc[kFdMaxSparse + 1];  // listed entries that are not zeros, per interval of the zero-valued short-list ids
+};
+
+__global__ __launch_bounds__(kFdThreads) void k_fs_stage(FdParams p) {
+  extern __shared__ unsigned char fd_smem[];
+  FsStageShared &sh = *reinterpret_cast<FsStageShared *>(fd_smem);
+  const int q = blockIdx.x, tid = threadIdx.x;
+  const int s = p.sp.src, cap = p.sp.cap;
+  const int nnz = p.sp.cnt[q], kp = p.kprime[q];
+  const int64_t N = p.src[s].len;
+  const unsigned *gid = p.sp.id + (int64_t)q * cap;
+  const double *gval = p.sp.val + (int64_t)q * cap;
+  const unsigned long long kzero = 0x8000000000000000ull;  // d2ord(0.0)
+  for (int i = tid; i < nnz; i += kFdThreads) sh.sid[i] = gid[i];
+  int skn = 0;
+  if (p.method == 1) {
+    skn = p.sk_n[q];
+    for (int i = tid; i < skn; i += kFdThreads) {
+      sh.sk_hi[i] = p.sk_hi[(int64_t)q * kFdMaxSparse + i];
+      sh.sk_id[i] = p.sk_id[(int64_t)q * kFdMaxSparse + i];
+    }
+    for (int i = tid; i <= skn; i += kFdThreads) {
+      sh.H[i] = 0;
+      sh.nzc[i] = 0;
+    }
+  }
+  __syncthreads();
+  // the value an id contributes to the ordering of the ids outside the short lists: linear — the fused value in the
+  // scan's order of operations (fd_scan_chunk; the absent sources add w * 0.0 only for the path term); rrf — the raw value
+  double sm = 0.0;
+  if (p.method == 0) {
+    const unsigned long long o = p.smax_ord[(int64_t)q * 4 + s];
+    sm = o ? ord2d(o) : 0.0;
+  }
+  auto key_of = [&](double x) -> unsigned long long {
+    if (x != x) return 1ull;  // an absent id: below every number (k_fd_build drops it)
+    if (p.method == 1) return d2ord(x);
+    double r = x == 0.0 ? (sm < 0.0 ? -x : x) : x / sm;
+    if (sm == 0.0) r = 0.0;
+    double f = 0.0 + p.w[s] * r;
+    f = f + p.w[3] * 0.0;
+    return d2ord(f);
+  };
+  auto emit = [&](int pos, unsigned long long key, unsigned id) {
+    const int64_t at = ((int64_t)q * p.n_chunks + pos / p.lcap) * p.lcap + pos % p.lcap;
+    p.c_hi[at] = key;
+    p.c_id[at] = id;
+  };
+  for (int i = tid; i < nnz; i += kFdThreads) emit(i, key_of(gval[i]), sh.sid[i]);
+  // the j-th id that is not listed = j + (listed ids below it): the first i with sid[i] - i > j
+  const int64_t missing = N - nnz;
+  const int nz = (int)(missing < kp ? (missing > 0 ? missing : 0) : kp);
+  const unsigned long long kz = key_of(0.0);
+  for (int j = tid; j < nz; j += kFdThreads) {
+    int lo = 0, hi = nnz;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if ((int64_t)sh.sid[mid] - mid > j) hi = mid;
+      else lo = mid + 1;
+    }
+    emit(nnz + j, kz, (unsigned)(j + lo));
+  }
+  const int total = nnz + nz;
+  for (int c = tid; c < p.n_chunks; c += kFdThreads) {
+    const int left = total - c * p.lcap;
+    p.c_cnt[(int64_t)q * p.n_chunks + c] = (unsigned)(left < 0 ? 0 : (left > p.lcap ? p.lcap : left));
+  }
+  if (p.method != 1) return;
+  // ---- rrf: how many of the N array entries beat each short-list key ----
+  // sorted short-list keys: [0, z_lo) positive, [z_lo, z_hi) zero-valued (ids ascending), [z_hi, skn) negative
+  int z_lo, z_hi;
+  {
+    int lo = 0, hi = skn;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (sh.sk_hi[mid] > kzero) lo = mid + 1;
+      else hi = mid;
+    }
+    z_lo = lo;
+    hi = skn;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (sh.sk_hi[mid] >= kzero) lo = mid + 1;
+      else hi = mid;
+    }
+    z_hi = lo;
+  }
+  const int m = z_hi - z_lo;
+  const unsigned *Z = sh.sk_id + z_lo;
+  for (int i = tid; i < nnz; i += kFdThreads) {
+    const double v = gval[i];
+    const unsigned id = sh.sid[i];
+    if (v == 0.0) continue;  // counted with the zeros below
+    int lo = 0, hi = m;      // zero-valued short-list ids below this id
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (Z[mid] < id) lo = mid + 1;
+      else hi = mid;
+    }
+    atomicAdd(&sh.nzc[lo], 1u);
+    if (v != v) continue;    // absent: no entry at all
+    const unsigned long long k = d2ord(v);
+    lo = 0;
+    hi = skn;                // short-list keys that beat (k, id)
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      const bool beats = sh.sk_hi[mid] > k || (sh.sk_hi[mid] == k && sh.sk_id[mid] < id);
+      if (beats) lo = mid + 1;
+      else hi = mid;
+    }
+    atomicAdd(&sh.H[lo], 1u);
+  }
+  __syncthreads();
+  // zero entries: the ids of interval t — [0, Z[0]], (Z[t-1], Z[t]], (Z[m-1], N - 1] — minus the listed non-zeros in it
+  for (int t = tid; t <= m; t += kFdThreads) {
+    int64_t span;
+    if (m == 0) span = N;
+    else if (t == 0) span = (int64_t)Z[0] + 1;
+    else if (t < m) span = (int64_t)Z[t] - (int64_t)Z[t - 1];
+    else span = N - 1 - (int64_t)Z[m - 1];
+    const int64_t zeros = span - (int64_t)sh.nzc[t];
+    sh.H[z_lo + t] += (unsigned)(zeros > 0 ? zeros : 0);
+  }
+  __syncthreads();
+  for (int i = tid; i <= skn; i += kFdThreads) p.H[(int64_t)q * (kFdMaxSparse + 1) + i] = sh.H[i];
 }
 
 }  // namespace anr
@@ -1144,10 +1392,21 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
   if (method != 0 && method != 1) return fail(ANR_EINVAL, "method must be 0 (linear) or 1 (rrf)");
   if (pool > kFdMaxSparse) return fail(ANR_EINVAL, "pool must be <= %d", kFdMaxSparse);
   if (nq == 0) return ANR_OK;
-  int n_arr = 0, r1 = -1;
+  int n_arr = 0, r1 = -1, sp_src = -1;
   int64_t U = 0;
   for (int s = 0; s < 4; ++s) {
-    if (src[s].array_dev) {
+    if (src[s].sparse_ids_dev) {
+      if (src[s].array_dev || src[s].list_offs) return fail(ANR_EINVAL, "source %d is given in two forms", s);
+      if (s == 3 || sp_src >= 0) return fail(ANR_EINVAL, "one of dense / bm25 / graph may be given in sparse form");
+      if (!src[s].sparse_scores_dev || !src[s].sparse_count_dev) return fail(ANR_EINVAL, "source %d: null sparse arrays", s);
+      if (src[s].sparse_cap <= 0 || src[s].sparse_cap > kFsSpMax)
+        return fail(ANR_EINVAL, "source %d: sparse_cap must be in [1, %d]", s, kFsSpMax);
+      if (src[s].array_len <= 0 || src[s].array_len > 0xfffffff0ll) return fail(ANR_EINVAL, "source %d: bad array length", s);
+      sp_src = s;
+      ++n_arr;
+      U = std::max<int64_t>(U, src[s].array_len);
+      r1 = s;
+    } else if (src[s].array_dev) {
       if (src[s].list_offs) return fail(ANR_EINVAL, "source %d is given both as an array and as lists", s);
       if (src[s].array_len <= 0 || src[s].array_len > 0xfffffff0ll) return fail(ANR_EINVAL, "source %d: bad array length", s);
       if (src[s].array_dtype != 0 && src[s].array_dtype != 1) return fail(ANR_EINVAL, "source %d: dtype must be 0 (f64) or 1 (f32)", s);
@@ -1160,6 +1419,8 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
     }
   }
   if (n_arr == 0) return fail(ANR_EINVAL, "no array source: use anr_fuse_lists");
+  if (sp_src >= 0 && n_arr != 1)
+    return fail(ANR_EINVAL, "a sparse source stands alone: the other sources must be short lists (%d arrays given)", n_arr);
   if (method == 1 && n_arr != 1)
     return fail(ANR_EINVAL, "rrf handles ONE array source (its ranks are counted in the stream); %d given", n_arr);
   if (method == 1) {
@@ -1179,7 +1440,7 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
     const int64_t start = (int64_t)lids.size();
     for (int s = 0; s < 4; ++s) {
       offs[q * 5 + s] = (int64_t)lids.size();
-      if (!src[s].array_dev && src[s].list_offs) {
+      if (!src[s].array_dev && !src[s].sparse_ids_dev && src[s].list_offs) {
         const int64_t a = src[s].list_offs[q], b = src[s].list_offs[q + 1];
         if (b < a) return fail(ANR_EINVAL, "source %d: offsets must be non-decreasing", s);
         for (int64_t e = a; e < b; ++e) {
@@ -1202,8 +1463,13 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
   if (device < 0 || device >= kFuseMaxDevices) return fail(ANR_EINVAL, "device %d out of range", device);
   DeviceGuard g(device);
   if (!g.ok) return fail(ANR_EHIP, "hipSetDevice(%d) failed", device);
-  const int n_chunks = (int)ceil_div(U, kFsChunk);
   const int lcap = (int)std::max<int64_t>(256, round_up(std::min<int64_t>(kFdMaxK, pool + kFdMaxSparse), 64));
+  const bool sparse = sp_src >= 0;
+  const int sp_cap = sparse ? (int)src[sp_src].sparse_cap : 0;
+  // (sparse: the "chunks" are just consecutive runs of the staged candidates — the entries and up to K' unlisted ids)
+  const int n_chunks = sparse ? (int)ceil_div(sp_cap + kFdMaxK, lcap) : (int)ceil_div(U, kFsChunk);
+  int sp_p2 = 2;
+  while (sp_p2 < sp_cap) sp_p2 <<= 1;
   // query sub-batches so that the candidate lists stay below ~1 GiB
   const int64_t per_q = (int64_t)n_chunks * lcap * 12;
   const int64_t QB = std::max<int64_t>(1, std::min<int64_t>(nq, ((int64_t)1 << 30) / std::max<int64_t>(per_q, 1)));
@@ -1225,6 +1491,7 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
                d_cid = dc.take((size_t)QB * n_chunks * lcap * 4), d_oi = dc.take((size_t)QB * kFuseMax * 8),
                d_os = dc.take((size_t)QB * kFuseMax * 8), d_or = dc.take((size_t)QB * kFuseMax * 4),
                d_oo = dc.take((size_t)QB * 5 * 8), d_om = dc.take((size_t)QB * 4 * 8);
+  const size_t d_spi = dc.take((size_t)QB * sp_cap * 4), d_spv = dc.take((size_t)QB * sp_cap * 8), d_spc = dc.take((size_t)QB * 4);
   // results of a sub-batch, downloaded with one copy: [ids | final | per-source | count]
   const size_t out_bytes = (size_t)QB * ((size_t)pool * 48 + 4);
   const size_t d_out = dc.take(out_bytes);
@@ -1238,6 +1505,10 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
   ANR_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_fd_scan<1, 0>), (int)sizeof(FsShared)));
   ANR_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_fd_scan<1, 1>), (int)sizeof(FsShared)));
   ANR_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_fd_build), (int)sizeof(FdShared)));
+  if (sparse) {
+    ANR_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_fs_sort), sp_p2 * 8));
+    ANR_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_fs_stage), (int)sizeof(FsStageShared)));
+  }
   ANR_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_fuse<true>), (int)sizeof(FuseShared)));
   hipEvent_t ev[2] = {nullptr, nullptr};
   const bool timed = stats != nullptr;
@@ -1268,9 +1539,19 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
     for (int s = 0; s < 4; ++s) {
       p.src[s].arr = src[s].array_dev;
       p.src[s].dtype = src[s].array_dtype;
-      p.src[s].len = src[s].array_dev ? src[s].array_len : 0;
+      p.src[s].len = (src[s].array_dev || s == sp_src) ? src[s].array_len : 0;
       p.src[s].known_max = src[s].array_dev ? src[s].array_max_dev : nullptr;
       p.w[s] = weights[s];
+    }
+    p.sp.src = sp_src;
+    if (sparse) {
+      p.sp.cap = sp_cap;
+      p.sp.in_id = src[sp_src].sparse_ids_dev;
+      p.sp.in_val = src[sp_src].sparse_scores_dev;
+      p.sp.in_cnt = src[sp_src].sparse_count_dev;
+      p.sp.id = reinterpret_cast<unsigned *>(D + d_spi);
+      p.sp.val = reinterpret_cast<double *>(D + d_spv);
+      p.sp.cnt = reinterpret_cast<int *>(D + d_spc);
     }
     p.rrf_k = rrf_k;
     p.U = U;
@@ -1303,23 +1584,32 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
       rc = fail(ANR_EHIP, "fuse_dense setup failed: %s", hipGetErrorString(e));
       break;
     }
-    hipLaunchKernelGGL(k_fd_prep, dim3((unsigned)nb), dim3(kFdThreads), 0, st, p);
-    if (timed) (void)hipEventRecord(ev[0], st);
-    if (method == 0) {
-      bool need_pass = false;  // a max pass over the arrays only for the sources whose maxima the caller did not supply
-      for (int s = 0; s < 3; ++s) need_pass = need_pass || (p.src[s].arr && !p.src[s].known_max);
-      const int64_t n8 = ceil_div(U, kFdChunk);
-      const int64_t gx = need_pass ? std::max<int64_t>(1, std::min<int64_t>(n8, ceil_div(4 * (int64_t)n_cu, nb))) : 1;
-      hipLaunchKernelGGL(k_fd_max, dim3((unsigned)gx, (unsigned)nb), dim3(kFdThreads), 0, st, p);
-    }
-    p.chunk0 = 0;
-    p.prefix = 1;
-    launch_scan(method, (unsigned)std::min<int64_t>(nb, 2 * n_cu), st, p, nb);
-    if (n_chunks > 1) {
-      p.chunk0 = 1;
-      p.prefix = 0;
-      const int64_t items = nb * (int64_t)(n_chunks - 1);
-      launch_scan(method, (unsigned)std::min<int64_t>(items, 2 * n_cu), st, p, items);
+    if (sparse) {
+      // the entries replace the stream: sort them by id (the lookup table of prep / build), then stage what the scan
+      // would have left — candidates, the rank histogram, the row maximum
+      if (timed) (void)hipEventRecord(ev[0], st);
+      hipLaunchKernelGGL(k_fs_sort, dim3((unsigned)nb), dim3(kFdThreads), (size_t)sp_p2 * 8, st, p, sp_p2);
+      hipLaunchKernelGGL(k_fd_prep, dim3((unsigned)nb), dim3(kFdThreads), 0, st, p);
+      hipLaunchKernelGGL(k_fs_stage, dim3((unsigned)nb), dim3(kFdThreads), sizeof(FsStageShared), st, p);
+    } else {
+      hipLaunchKernelGGL(k_fd_prep, dim3((unsigned)nb), dim3(kFdThreads), 0, st, p);
+      if (timed) (void)hipEventRecord(ev[0], st);
+      if (method == 0) {
+        bool need_pass = false;  // a max pass over the arrays only for the sources whose maxima the caller did not supply
+        for (int s = 0; s < 3; ++s) need_pass = need_pass || (p.src[s].arr && !p.src[s].known_max);
+        const int64_t n8 = ceil_div(U, kFdChunk);
+        const int64_t gx = need_pass ? std::max<int64_t>(1, std::min<int64_t>(n8, ceil_div(4 * (int64_t)n_cu, nb))) : 1;
+        hipLaunchKernelGGL(k_fd_max, dim3((unsigned)gx, (unsigned)nb), dim3(kFdThreads), 0, st, p);
+      }
+      p.chunk0 = 0;
+      p.prefix = 1;
+      launch_scan(method, (unsigned)std::min<int64_t>(nb, 2 * n_cu), st, p, nb);
+      if (n_chunks > 1) {
+        p.chunk0 = 1;
+        p.prefix = 0;
+        const int64_t items = nb * (int64_t)(n_chunks - 1);
+        launch_scan(method, (unsigned)std::min<int64_t>(items, 2 * n_cu), st, p, items);
+      }
     }
     if (timed) (void)hipEventRecord(ev[1], st);
     hipLaunchKernelGGL(k_fd_build, dim3((unsigned)nb), dim3(kFdThreads), sizeof(FdShared), st, p);
@@ -1358,6 +1648,7 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
       int64_t bytes = 0;
       for (int s = 0; s < 4; ++s)
         if (src[s].array_dev) bytes += src[s].array_len * (src[s].array_dtype == 0 ? 8 : 4);
+      if (sparse) bytes = (int64_t)sp_cap * 12;  // (an upper bound: the rows' capacity, not their fill)
       stats->scan_bytes += bytes * nb;
       stats->n_queries += nb;
       std::vector<unsigned> cc((size_t)nb * n_chunks);

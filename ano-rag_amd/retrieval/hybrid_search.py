@@ -309,7 +309,8 @@ class HybridSearcher:
     def fuse_arrays(self, nq: int, dense=None, bm25=None, graph=None, path=None, note_ids: Sequence[Any] | None = None,
                     want_stats: bool = False):
         """EXTENSION (same arithmetic, integer ids): batch fusion where a source is either a ``DeviceArray`` [nq, N]
-        (the score of EVERY note 0..N-1, e.g. ``DeviceBM25.scores_device``) or, per query, a short
+        (the score of EVERY note 0..N-1, e.g. ``DeviceBM25.scores_device``), the same rows by their non-zero entries
+        (``SparseRows``, e.g. ``DeviceBM25.scores_sparse_device``) or, per query, a short
         ``(ids, scores)`` pair (e.g. the dense top-k of ``VectorIndex``).  Returns the reference's list of result
         dicts per query (``note_id`` = ``note_ids[i]`` when given, else the integer id)."""
         if not self.enabled:
@@ -323,6 +324,35 @@ class HybridSearcher:
         o_ids, o_fin, o_src, o_cnt = out[:4]
         results = _shape_fused(o_ids, o_fin, o_src, o_cnt, note_ids)
         return (results, out[4]) if want_stats else results
+
+
+    def fuse_bm25(self, corpus, queries: Sequence[Sequence[str]], dense=None, graph=None, path=None,
+                  note_ids: Sequence[Any] | None = None):
+        """EXTENSION: BM25 scoring and fusion back to back on the device — ``bm25_scores`` (utils/bm25_search.py:286-340)
+        feeding ``fuse`` (hybrid_search.py:34-103) for a batch of tokenised queries, same results as
+        ``fuse_arrays(bm25=corpus.scores_device(queries))``.  A query whose postings touch at most
+        ``corpus.SPARSE_CAP`` documents is handed over in sparse form (its N-vector is never formed); the others take
+        the N-vector path.  ``corpus``: a ``DeviceBM25``; dense / graph / path: per query ``(ids, scores)`` or None."""
+        nq = len(queries)
+        if not self.enabled or int(self.candidate_pool) <= 0 or nq == 0:
+            return [[] for _ in range(nq)]
+        rows = corpus.scores_sparse_device(queries, normalize=True, allow_overflow=True)
+        try:
+            results = self.fuse_arrays(nq, dense=dense, bm25=rows, graph=graph, path=path, note_ids=note_ids)
+            heavy = [i for i in range(nq) if rows.counts[i] < 0]
+        finally:
+            rows.free()
+        if heavy:
+            sub = lambda lists: None if lists is None else [lists[i] for i in heavy]
+            vec = corpus.scores_device([queries[i] for i in heavy], normalize=True)
+            try:
+                again = self.fuse_arrays(len(heavy), dense=sub(dense), bm25=vec, graph=sub(graph), path=sub(path),
+                                         note_ids=note_ids)
+            finally:
+                vec.free()
+            for i, r in zip(heavy, again):
+                results[i] = r
+        return results
 
 
 def _shape_fused_py(o_ids, o_fin, o_src, o_cnt, note_ids=None):

@@ -210,6 +210,16 @@ typedef struct anr_fuse_source {
                                   when the producer knows it (anr_bm25_scores_dev, anr_bm25_combine_fields): linear
                                   then needs no max pass over the array.  Must be exact — it is the reference's
                                   max(scores) normaliser (hybrid_search.py:26-32) */
+  /* SPARSE form of an array source (array_dev NULL, array_len = N > 0): row q is given by its explicit entries
+   * (sparse_ids_dev[q][i], sparse_scores_dev[q][i]), i < sparse_count_dev[q] <= sparse_cap, in any order, ids distinct and
+   * < N; every other id < N holds 0.0 (an explicit NaN marks an absent id) — what anr_bm25_sparse_dev leaves on the device
+   * for a query whose postings touch a few thousand of the N notes.  Results are bit-identical to the same row handed
+   * over as a dense array; the corpus-wide stream is replaced by work proportional to the entries.  At most ONE source
+   * may be sparse (dense / bm25 / graph), the others are then short lists; sparse_cap <= 8192. */
+  const uint32_t *sparse_ids_dev;   /* device [nq][sparse_cap], or NULL */
+  const double *sparse_scores_dev;  /* device [nq][sparse_cap]          */
+  const int32_t *sparse_count_dev;  /* device [nq]                      */
+  int64_t sparse_cap;
 } anr_fuse_source;
 typedef struct anr_fuse_dense_stats {
   int64_t n_queries;
@@ -317,6 +327,15 @@ int anr_bm25_scores_dev(anr_bm25 *h, int64_t nq, const int64_t *q_indptr, const 
 int anr_bm25_combine_fields(int32_t device, int32_t n_fields, const double *const *field_scores_dev,
                             const double *weights, int64_t nq, int64_t n_docs, int32_t normalize, double *out_dev,
                             double *max_dev);
+/* The scores of anr_bm25_scores_dev in SPARSE form, left on the device for anr_fuse_dense (anr_fuse_source.sparse_*): per
+ * query the documents its postings touch, unordered — ids_dev / scores_dev [nq][cap] (cap <= 6144), count_dev [nq], max_dev
+ * [nq] (may be NULL; the maximum over all n_docs scores, the untouched zeros included).  The N-vector is never
+ * materialised: a workgroup accumulates its query in an LDS table, additions in the reference's token order, so every
+ * score equals anr_bm25_scores' bit for bit.  A query that touches more than cap documents gets count -1 (its row is
+ * unusable: score that query with anr_bm25_scores_dev).  out_count_host (may be NULL): the counts, copied back. */
+int anr_bm25_sparse_dev(anr_bm25 *h, int64_t nq, const int64_t *q_indptr, const int32_t *q_terms, int32_t normalize,
+                        int32_t cap, uint32_t *ids_dev, double *scores_dev, int32_t *count_dev, double *max_dev,
+                        int32_t *out_count_host);
 /* sparse form for the fusion: the documents with a non-zero score, unordered; out_count may exceed cap
  * (the lists are then truncated) */
 int anr_bm25_nonzero(anr_bm25 *h, int64_t nq, const int64_t *q_indptr, const int32_t *q_terms, int32_t normalize,

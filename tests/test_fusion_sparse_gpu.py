@@ -1,0 +1,247 @@
+"""GPU parity of the SPARSE hand-off BM25 -> fusion (anr_bm25_sparse_dev -> anr_fuse_source.sparse_*): a BM25 row over N
+notes given by the few thousand documents its postings touch instead of as an N-vector.
+
+Pinned three ways: the reference-run golden cases of the N-array fusion whose bm25 vector is zero-filled
+(tests/golden/fusion_long_cases.json, produced by the reference's own HybridSearcher.fuse), equality with the dense-array
+form of the same rows on adversarial random rows (explicit zeros, negatives, an absent id, short lists overlapping the
+entries and the implicit zeros), and the BM25 producer against anr_bm25_scores.  Bar: bit-exact float64, identical ids."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _cases():
+    with open(os.path.join(GOLD, "fusion_long_cases.json")) as f:
+        return [c for c in json.load(f)["cases"]
+                if c["bm25_vec"] is not None and c["dense_vec"] is None and c["bm25_vec"]["fill"] == 0.0]
+
+
+def _pairs(lst):
+    if lst is None:
+        return None
+    return (np.array([p[0] for p in lst], dtype=np.int64), np.array([p[1] for p in lst], dtype=np.float64))
+
+
+@pytest.mark.parametrize("case", _cases(), ids=lambda c: c["name"])
+def test_sparse_bm25_rows_match_reference_golden(case):
+    from anorag_hip.fusion import SparseRows
+    from retrieval.hybrid_search import HybridSearcher
+    from test_fusion_dense_gpu import _compare
+    hs = HybridSearcher(case["config"])
+    v = case["bm25_vec"]
+    rows = SparseRows.from_numpy([(np.asarray(v["idx"], dtype=np.int64), np.asarray(v["val"], dtype=np.float64))], v["n"])
+    got = hs.fuse_arrays(1, dense=[_pairs(case["dense"])], bm25=rows, graph=[_pairs(case["graph"])],
+                         path=[_pairs(case["path"])])[0]
+    rows.free()
+    _compare(got, case["expected"], hs.candidate_pool, hs.fusion_method)
+
+
+def _random_rows(rng, nq, n, nnz_max, kinds):
+    """rows with the entries the stage kernel treats differently: positives, explicit zeros, negatives, ties, a NaN"""
+    rows = []
+    for q in range(nq):
+        nnz = int(rng.integers(0, min(nnz_max, n) + 1)) if q else min(nnz_max, n)
+        ids = rng.choice(n, size=nnz, replace=False)
+        val = np.abs(rng.standard_normal(nnz))
+        if "ties" in kinds and nnz:
+            val = np.round(val * 4) / 4                     # many equal values (and some exact zeros)
+        if "zeros" in kinds and nnz:
+            val[rng.random(nnz) < 0.1] = 0.0
+            val[rng.random(nnz) < 0.02] = -0.0
+        if "neg" in kinds and nnz:
+            neg = rng.random(nnz) < 0.2
+            val[neg] = -val[neg]
+        if "nan" in kinds and nnz > 3:
+            val[rng.integers(0, nnz)] = np.nan
+        rows.append((ids.astype(np.int64), val))
+    return rows
+
+
+def _dense_of(rows, n):
+    a = np.zeros((len(rows), n), dtype=np.float64)
+    for i, (ids, val) in enumerate(rows):
+        a[i, ids] = val
+    return a
+
+
+def _short_lists(rng, rows, n, m, nq):
+    """per query a short list that holds listed ids (zero-valued ones too), unlisted low ids (implicit zeros that are
+    candidates) and unlisted high ids"""
+    out = []
+    for q in range(nq):
+        ids, val = rows[q]
+        pick = []
+        if len(ids):
+            pick += rng.choice(ids, size=min(len(ids), m // 3), replace=False).tolist()
+            z = ids[val == 0.0]
+            pick += z[: m // 6].tolist()
+        pick += rng.integers(0, min(n, 64), size=m // 4).tolist()
+        pick += rng.integers(0, n, size=m // 4).tolist()
+        pick = list(dict.fromkeys(int(x) for x in pick))[:m]
+        rng.shuffle(pick)
+        sc = np.sort(rng.standard_normal(len(pick)))[::-1].copy()
+        out.append((np.asarray(pick, dtype=np.int64), sc))
+    return out
+
+
+@pytest.mark.parametrize("method", ["linear", "rrf"])
+@pytest.mark.parametrize("n,nnz_max,pool,m,kinds", [
+    (1_000_000, 3000, 80, 100, ("zeros",)),            # the C5 shape
+    (50_000, 6000, 50, 300, ("zeros", "neg", "ties")),
+    (5000, 5000, 200, 600, ("zeros", "neg", "nan")),   # rows that list every id
+    (300, 300, 1024, 40, ("ties", "neg")),             # pool beyond N
+    (7, 5, 10, 6, ("zeros",)),
+    (1, 1, 5, 1, ()),
+    (4096, 0, 30, 50, ()),                             # rows without a single entry
+    (200_000, 8192, 100, 1000, ("zeros", "neg", "ties", "nan")),   # the largest row, the longest short lists
+])
+def test_sparse_rows_fuse_like_the_dense_array(method, n, nnz_max, pool, m, kinds):
+    from anorag_hip.fusion import DeviceArray, SparseRows, fuse_dense
+    rng = np.random.default_rng(n + pool + (1 if method == "rrf" else 0))
+    nq = 5
+    rows = _random_rows(rng, nq, n, nnz_max, kinds)
+    dense = _short_lists(rng, rows, n, m, nq)
+    graph = _short_lists(rng, rows, n, max(m // 8, 1), nq)
+    w = {"dense": 1.0, "bm25": 0.5, "graph": 0.5, "path": 0.1}
+    arr = DeviceArray.from_numpy(_dense_of(rows, n))
+    sp = SparseRows.from_numpy(rows, n, cap=max(nnz_max, 1))
+    for src in ({"dense": dense, "bm25": None, "graph": graph}, {"dense": dense, "bm25": None}, {"bm25": None}):
+        a = fuse_dense(method, w, 60.0, pool, nq, {**src, "bm25": arr})
+        b = fuse_dense(method, w, 60.0, pool, nq, {**src, "bm25": sp})
+        assert np.array_equal(a[3], b[3])
+        assert np.array_equal(a[0], b[0])
+        assert a[1].tobytes() == b[1].tobytes()
+        assert np.array_equal(a[2], b[2], equal_nan=True)
+    arr.free()
+    sp.free()
+
+
+def test_sparse_source_in_the_dense_and_graph_slots_and_argument_errors():
+    from anorag_hip import _lib
+    from anorag_hip.fusion import DeviceArray, SparseRows, fuse_dense
+    rng = np.random.default_rng(3)
+    n, nq = 20_000, 3
+    rows = _random_rows(rng, nq, n, 500, ("zeros", "neg"))
+    lists = _short_lists(rng, rows, n, 60, nq)
+    w = {"dense": 0.7, "bm25": 0.4, "graph": 0.9, "path": 0.2}
+    arr = DeviceArray.from_numpy(_dense_of(rows, n))
+    sp = SparseRows.from_numpy(rows, n)
+    for slot in ("dense", "graph"):
+        for method in ("linear", "rrf"):
+            other = "bm25"
+            a = fuse_dense(method, w, 10.0, 40, nq, {slot: arr, other: lists})
+            b = fuse_dense(method, w, 10.0, 40, nq, {slot: sp, other: lists})
+            assert np.array_equal(a[0], b[0]) and a[1].tobytes() == b[1].tobytes()
+            assert np.array_equal(a[2], b[2], equal_nan=True) and np.array_equal(a[3], b[3])
+    with pytest.raises(_lib.AnoragError):      # a sparse source beside a dense array
+        fuse_dense("linear", w, 10.0, 40, nq, {"dense": arr, "bm25": sp})
+    with pytest.raises(_lib.AnoragError):      # the path source is a list
+        fuse_dense("linear", w, 10.0, 40, nq, {"path": sp})
+    sp2 = SparseRows.from_numpy(rows, n)
+    with pytest.raises(_lib.AnoragError):      # two sparse sources
+        fuse_dense("linear", w, 10.0, 40, nq, {"dense": sp2, "bm25": sp})
+    for x in (arr, sp, sp2):
+        x.free()
+
+
+def _corpus(rng, n_docs, n_vocab, max_len):
+    vocab = [f"w{i}" for i in range(n_vocab)]
+    probs = 1.0 / np.arange(1, n_vocab + 1)
+    probs /= probs.sum()
+    notes = [{"title": "", "content": " ".join(rng.choice(vocab, size=rng.integers(0, max_len), p=probs))}
+             for _ in range(n_docs)]
+    return vocab, probs, notes
+
+
+def test_bm25_sparse_rows_equal_the_dense_scores_bit_for_bit():
+    from anorag_hip import bm25_search as dbm
+    rng = np.random.default_rng(11)
+    vocab, probs, notes = _corpus(rng, 30_000, 20_000, 30)
+    dev = dbm.build_bm25_corpus(notes, lambda n: f"{n.get('title', '')} {n.get('content', '')}")
+    # rare words only (ranks >= 200): every query touches fewer than 6144 documents
+    queries = [" ".join(rng.choice(vocab[200:], size=rng.integers(1, 9))) for _ in range(60)]
+    queries += [f"{vocab[300]} {vocab[300]} {vocab[301]}", "zzz", ""]
+    toks = [dbm.tokenize_text(q) for q in queries]
+    for normalize in (True, False):
+        full = dev.scores_batch(toks, normalize=normalize)
+        sp = dev.scores_sparse_device(toks, normalize=normalize)
+        assert sp is not None
+        got = sp.numpy()
+        for i in range(len(queries)):
+            ids, val = got[i]
+            assert len(set(ids.tolist())) == len(ids) == int(sp.counts[i])
+            assert set(np.nonzero(full[i])[0].tolist()) <= set(ids.tolist())
+            assert val.tobytes() == full[i][ids].tobytes()
+            mask = np.ones(full.shape[1], dtype=bool)
+            mask[ids] = False
+            assert not full[i][mask].any()
+        sp.free()
+    # a frequent word touches more documents than a row holds: the caller is told to take the dense path
+    assert dev.scores_sparse_device([[vocab[0]]] + toks[:3]) is None
+    dev.close()
+
+
+@pytest.mark.parametrize("method", ["linear", "rrf"])
+def test_bm25_to_fusion_without_the_n_vector(method):
+    """DeviceBM25.scores_sparse_device -> HybridSearcher.fuse_arrays == the same through scores_device"""
+    from anorag_hip import bm25_search as dbm
+    from retrieval.hybrid_search import HybridSearcher
+    rng = np.random.default_rng(12)
+    vocab, probs, notes = _corpus(rng, 40_000, 30_000, 25)
+    dev = dbm.build_bm25_corpus(notes, lambda n: f"{n.get('title', '')} {n.get('content', '')}")
+    queries = [" ".join(rng.choice(vocab[300:], size=rng.integers(1, 7))) for _ in range(24)] + ["zzz"]
+    toks = [dbm.tokenize_text(q) for q in queries]
+    nq = len(queries)
+    dense = []
+    for _ in range(nq):
+        ids = rng.choice(len(notes), size=100, replace=False).astype(np.int64)
+        dense.append((ids, np.sort(rng.random(100))[::-1].copy()))
+    hs = HybridSearcher({"retrieval": {"candidate_pool": 80, "hybrid": {
+        "enabled": True, "fusion_method": method, "rrf_k": 60,
+        "weights": {"dense": 1.0, "bm25": 0.5, "graph": 0.5, "path": 0.1}}}})
+    full = dev.scores_device(toks, normalize=True)
+    sp = dev.scores_sparse_device(toks, normalize=True)
+    assert sp is not None
+    a = hs.fuse_arrays(nq, dense=dense, bm25=full)
+    b = hs.fuse_arrays(nq, dense=dense, bm25=sp)
+    assert a == b
+    assert any(r["scores"]["bm25"] for res in b for r in res)
+    full.free()
+    sp.free()
+    dev.close()
+
+
+@pytest.mark.parametrize("method", ["linear", "rrf"])
+def test_fuse_bm25_sends_heavy_queries_down_the_vector_path(method):
+    """HybridSearcher.fuse_bm25: queries under the row capacity go sparse, a frequent word's query takes the N-vector;
+    every result equals the all-vector pipeline's"""
+    from anorag_hip import bm25_search as dbm
+    from retrieval.hybrid_search import HybridSearcher
+    rng = np.random.default_rng(13)
+    vocab, probs, notes = _corpus(rng, 40_000, 5_000, 25)
+    dev = dbm.build_bm25_corpus(notes, lambda n: f"{n.get('title', '')} {n.get('content', '')}")
+    queries = [" ".join(rng.choice(vocab[100:], size=rng.integers(1, 5))) for _ in range(10)]
+    queries[2] = f"{vocab[0]} {vocab[700]}"       # the most frequent word: tens of thousands of documents
+    queries[7] = f"{vocab[1]} {vocab[2]}"
+    toks = [dbm.tokenize_text(q) for q in queries]
+    nq = len(queries)
+    dense = []
+    for _ in range(nq):
+        ids = rng.choice(len(notes), size=60, replace=False).astype(np.int64)
+        dense.append((ids, np.sort(rng.random(60))[::-1].copy()))
+    hs = HybridSearcher({"retrieval": {"candidate_pool": 50, "hybrid": {
+        "enabled": True, "fusion_method": method, "rrf_k": 60,
+        "weights": {"dense": 1.0, "bm25": 0.5, "graph": 0.5, "path": 0.1}}}})
+    rows = dev.scores_sparse_device(toks, allow_overflow=True)
+    assert rows.counts[2] == -1 and rows.counts[7] == -1 and (rows.counts >= 0).sum() >= 6
+    rows.free()
+    full = dev.scores_device(toks, normalize=True)
+    exp = hs.fuse_arrays(nq, dense=dense, bm25=full)
+    full.free()
+    assert hs.fuse_bm25(dev, toks, dense=dense) == exp
+    dev.close()

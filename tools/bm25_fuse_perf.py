@@ -22,7 +22,8 @@ corpus_tokens = [words[toks[offs[i]:offs[i + 1]]].tolist() for i in range(NN)]
 bm = dbm.DeviceBM25(corpus_tokens)
 print(f"corpus: {NN} notes, {int(lens.sum())} tokens, vocabulary {len(bm.vocab)}; built in {time.perf_counter() - t0:.1f} s (host)")
 # queries: rarer terms (ranks 50..5000), as content words are
-queries = [[f"w{int(t)}" for t in rng.integers(50, 5000, size=5)] for _ in range(NQ)]
+QLO, QHI = int(os.environ.get("QLO", 50)), int(os.environ.get("QHI", 5000))
+queries = [[f"w{int(t)}" for t in rng.integers(QLO, QHI, size=5)] for _ in range(NQ)]
 dense = [(rng.choice(NN, 100, replace=False).astype(np.int64), np.sort(rng.random(100))[::-1].copy()) for _ in range(NQ)]
 W = {"dense": 1.0, "bm25": 0.5, "graph": 0.5, "path": 0.1}
 for method in ("linear", "rrf"):
@@ -41,4 +42,22 @@ for method in ("linear", "rrf"):
     print(f"{method:6s} {NQ} queries: BM25 scoring {best[0]*1e3:.2f} ms + fusion {best[1]*1e3:.2f} ms + free {best[2]*1e3:.2f} ms "
           f"= {sum(best)*1e3:.2f} ms = {NQ/sum(best):.0f} queries/s (tokenised queries in, result dicts out; "
           f"{nnz:.0f} of 80 results carry a BM25 hit; streaming kernels {st['scan_ms']:.2f} ms, {st['n_candidates']/NQ:.0f} candidates/query)")
+    # the sparse hand-off: rows of at most 6144 touched documents stay (id, score) entries; heavier queries take the vector
+    best = None
+    for it in range(4):
+        t0 = time.perf_counter()
+        got2 = hs.fuse_bm25(bm, queries, dense=dense)
+        t1 = time.perf_counter()
+        if it and (best is None or t1 - t0 < best): best = t1 - t0
+    rows = bm.scores_sparse_device(queries, allow_overflow=True)
+    heavy = int((rows.counts < 0).sum()); light = rows.counts[rows.counts >= 0]
+    rows.free()
+    print(f"{method:6s} fuse_bm25 (sparse rows, {heavy} of {NQ} queries over the row capacity -> vector path; the others hold "
+          f"{float(light.mean()) if len(light) else 0:.0f} documents on average): {best*1e3:.2f} ms = {NQ/best:.0f} queries/s; identical results: {got2 == got}")
+if os.environ.get("PROFILE"):
+    import cProfile, pstats
+    pr = cProfile.Profile(); pr.enable()
+    for _ in range(5): hs.fuse_bm25(bm, queries, dense=dense)
+    pr.disable()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
 bm.close()
