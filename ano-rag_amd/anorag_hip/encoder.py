@@ -17,6 +17,7 @@ from __future__ import annotations
 import ctypes as C
 import json
 import os
+import threading
 from typing import Dict, Optional, Sequence
 
 import numpy as np
@@ -268,6 +269,8 @@ class SentenceEncoder:
         self._pad = info["pad_token_id"]
         self.device = device
         self._pool = None  # tokeniser worker (created on first multi-batch encode)
+        self._tok_lock = threading.Lock()
+        self._tok_max_len = None
         # padded tokens (sequences x padded length) one forward may hold: the workspace is 16 H + 2 I bytes per token
         # (6.4 GB at this budget for XLM-R large) — the role SentenceTransformer.encode's batch_size plays as a memory knob
         self.max_forward_tokens = 1 << 18
@@ -278,9 +281,16 @@ class SentenceEncoder:
     def tokenize(self, texts: Sequence[str]):
         tok = self.tokenizer
         max_len = int(min(self.max_seq_length, self._enc.max_positions))
-        tok.enable_truncation(max_length=max_len)
-        tok.no_padding()
-        encs = tok.encode_batch([str(t) for t in texts])
+        # One tokenisation at a time, and the truncation / padding settings touched only when max_seq_length changed: the
+        # reference encodes from ThreadPoolExecutor workers that share the model (main_musique.py:487-494), and a
+        # `tokenizers` object that is reconfigured while another thread encodes raises "Already borrowed"
+        # (encode_batch is parallel inside, so nothing is lost by taking turns).
+        with self._tok_lock:
+            if self._tok_max_len != max_len:
+                tok.enable_truncation(max_length=max_len)
+                tok.no_padding()
+                self._tok_max_len = max_len
+            encs = tok.encode_batch([str(t) for t in texts])
         lists = [e.ids for e in encs]  # ONE conversion per sentence (each `.ids` / `.type_ids` access builds a new list)
         lens = np.fromiter((len(x) for x in lists), dtype=np.int32, count=len(lists))
         L = int(lens.max())

@@ -1160,12 +1160,67 @@ __global__ __launch_bounds__(kFdThreads) void k_fd_build(FdParams p) {
 //               the z_lo positive short-list keys and by the zero-valued ones with a lower id).
 // Same FdParams outputs as k_fd_max + k_fd_scan (smax_ord, c_hi / c_id / c_cnt, H), so k_fd_build and k_fuse<true> — and
 // the bit-exactness argument at the top of this file — carry over unchanged.
-__global__ __launch_bounds__(kFdThreads) void k_fs_sort(FdParams p, int P2max) {
+// Bitonic sort of P2 (a power of two) 64-bit keys in LDS, ascending, by kFsSortThreads threads.  A 1024-thread network
+// with a workgroup barrier after each of its ~70 passes spent 1.3 us per pass at the barrier (86 us per row of 2048);
+// four waves without barriers were bound by the LDS latency of their eight pairs per pass (61 us).  Here each of the W
+// active waves owns a contiguous segment of P2 / W keys: a pass whose stride stays inside a segment
+// needs no workgroup barrier (a wave's LDS operations complete in order), only the few passes with a longer stride do.
+constexpr int kFsSortThreads = 1024;
+__device__ __forceinline__ void fs_bitonic_u64(unsigned long long *key, int P2) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int W = P2 / 128;  // active waves: segments of >= 128 keys (a short row: one wave, no barrier at all)
+  W = W < 1 ? 1 : (W > kFsSortThreads / 64 ? kFsSortThreads / 64 : W);
+  const int seg = P2 / W, half = seg >> 1;
+  const bool active = wave < W;
+  auto pass = [&](int k2, int j, int p0, int p1, int step) {
+    constexpr int U = 4;  // pairs in flight per lane: with one wave per SIMD nothing else hides the LDS latency
+    int pp = p0 + lane;
+    for (; pp + (U - 1) * step < p1; pp += U * step) {
+      int i[U];
+      unsigned long long a[U], b[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int q = pp + u * step;
+        i[u] = ((q & ~(j - 1)) << 1) | (q & (j - 1));
+        a[u] = key[i[u]];
+        b[u] = key[i[u] + j];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool sw = ((i[u] & k2) == 0) ? (b[u] < a[u]) : (a[u] < b[u]);
+        key[i[u]] = sw ? b[u] : a[u];
+        key[i[u] + j] = sw ? a[u] : b[u];
+      }
+    }
+    for (; pp < p1; pp += step) {
+      const int i = ((pp & ~(j - 1)) << 1) | (pp & (j - 1)), x = i + j;
+      const unsigned long long a = key[i], b = key[x];
+      const bool up = (i & k2) == 0;
+      if (up ? (b < a) : (a < b)) {
+        key[i] = b;
+        key[x] = a;
+      }
+    }
+  };
+  for (int k2 = 2; k2 <= P2; k2 <<= 1)
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+      if (j < seg) {  // inside the wave's own segment
+        if (active) pass(k2, j, wave * half, (wave + 1) * half, 64);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+      } else {        // across segments (W > 1): every active wave takes its share of the pairs, barriers on both sides
+        __syncthreads();
+        if (active) pass(k2, j, wave * (P2 / 2 / W), (wave + 1) * (P2 / 2 / W), 64);
+        __syncthreads();
+      }
+    }
+}
+
+__global__ __launch_bounds__(kFsSortThreads) void k_fs_sort(FdParams p, int P2max) {
   extern __shared__ unsigned char fd_smem[];
-  unsigned *ids = reinterpret_cast<unsigned *>(fd_smem);
-  unsigned *idx = ids + P2max;
-  __shared__ double s_best[kFdThreads / 64];
-  __shared__ int s_any[kFdThreads / 64];
+  unsigned long long *key = reinterpret_cast<unsigned long long *>(fd_smem);  // (id << 32) | position in the caller's row
+  __shared__ double s_best[kFsSortThreads / 64];
+  __shared__ int s_any[kFsSortThreads / 64];
   const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cap = p.sp.cap;
   int nnz = p.sp.in_cnt[p.q0 + q];
@@ -1174,31 +1229,17 @@ __global__ __launch_bounds__(kFdThreads) void k_fs_sort(FdParams p, int P2max) {
   while (P2 < nnz) P2 <<= 1;
   const unsigned *gi = p.sp.in_id + (p.q0 + q) * (int64_t)cap;
   const double *gv = p.sp.in_val + (p.q0 + q) * (int64_t)cap;
-  for (int i = tid; i < P2; i += kFdThreads) {
-    ids[i] = i < nnz ? gi[i] : 0xffffffffu;
-    idx[i] = (unsigned)i;
-  }
+  for (int i = tid; i < P2; i += kFsSortThreads)
+    key[i] = i < nnz ? ((unsigned long long)gi[i] << 32) | (unsigned)i : ~0ull;
   __syncthreads();
-  for (int k2 = 2; k2 <= P2; k2 <<= 1)
-    for (int j = k2 >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < P2; i += kFdThreads) {
-        const int x = i ^ j;
-        if (x > i) {
-          const unsigned a = ids[i], b = ids[x], ia = idx[i], ib = idx[x];
-          const bool b_first = b < a || (b == a && ib < ia), a_first = a < b || (a == b && ia < ib);
-          if (((i & k2) == 0) ? b_first : a_first) {
-            ids[i] = b; ids[x] = a;
-            idx[i] = ib; idx[x] = ia;
-          }
-        }
-      }
-      __syncthreads();
-    }
+  fs_bitonic_u64(key, P2);
+  __syncthreads();
   double best = 0.0;
   bool any = false;
-  for (int i = tid; i < nnz; i += kFdThreads) {
-    const double v = gv[idx[i]];
-    p.sp.id[(int64_t)q * cap + i] = ids[i];
+  for (int i = tid; i < nnz; i += kFsSortThreads) {
+    const unsigned long long k = key[i];
+    const double v = gv[(unsigned)k];
+    p.sp.id[(int64_t)q * cap + i] = (unsigned)(k >> 32);
     p.sp.val[(int64_t)q * cap + i] = v;
     if (v == v) {
       best = (!any || v > best) ? v : best;
@@ -1219,7 +1260,7 @@ __global__ __launch_bounds__(kFdThreads) void k_fs_sort(FdParams p, int P2max) {
   }
   __syncthreads();
   if (tid == 0) {
-    for (int w = 1; w < kFdThreads / 64; ++w)
+    for (int w = 1; w < kFsSortThreads / 64; ++w)
       if (s_any[w] && (!any || s_best[w] > best)) {
         best = s_best[w];
         any = true;
@@ -1588,7 +1629,7 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
       // the entries replace the stream: sort them by id (the lookup table of prep / build), then stage what the scan
       // would have left — candidates, the rank histogram, the row maximum
       if (timed) (void)hipEventRecord(ev[0], st);
-      hipLaunchKernelGGL(k_fs_sort, dim3((unsigned)nb), dim3(kFdThreads), (size_t)sp_p2 * 8, st, p, sp_p2);
+      hipLaunchKernelGGL(k_fs_sort, dim3((unsigned)nb), dim3(kFsSortThreads), (size_t)sp_p2 * 8, st, p, sp_p2);
       hipLaunchKernelGGL(k_fd_prep, dim3((unsigned)nb), dim3(kFdThreads), 0, st, p);
       hipLaunchKernelGGL(k_fs_stage, dim3((unsigned)nb), dim3(kFdThreads), sizeof(FsStageShared), st, p);
     } else {

@@ -327,3 +327,41 @@ def test_streamed_and_sharded_builds_equal_the_one_shot_build(cfg, model_dir, tm
     one.close()
     idx.close()
     EmbeddingManager._reset_singleton()
+
+
+def test_worker_threads_share_the_encoder_the_index_and_the_fusion(cfg, model_dir):
+    """The reference answers questions from ThreadPoolExecutor workers that share the EmbeddingManager singleton
+    (main_musique.py:487-494, embedding_manager.py:64-70): encode -> search -> BM25 -> fuse from eight threads at once
+    must give every thread the single-threaded answer."""
+    from concurrent.futures import ThreadPoolExecutor
+    from anorag_hip import bm25_search as dbm
+    from retrieval.hybrid_search import HybridSearcher
+    from vector_store import EmbeddingManager, VectorRetriever
+    EmbeddingManager._reset_singleton()
+    cfg.set("embedding.model_path", model_dir)
+    cfg.set("embedding.max_length", 64)
+    cfg.set("embedding.batch_size", 16)
+    cfg.set("vector_store.similarity_threshold", 0.0001)
+    words = oenc.synthetic_sentences(model_dir, 300, seed=21, min_words=4, max_words=14)
+    notes = [{"note_id": f"n{i}", "title": f"t{i}", "content": w, "entities": []} for i, w in enumerate(words)]
+    vr = VectorRetriever()
+    assert vr.build_index(notes) is True
+    corpus = dbm.build_bm25_corpus(notes, lambda n: n["content"])
+    hs = HybridSearcher({"retrieval": {"candidate_pool": 20, "hybrid": {
+        "enabled": True, "fusion_method": "linear", "weights": {"dense": 1.0, "bm25": 0.5, "graph": 0.5, "path": 0.1}}}})
+    queries = [words[i] for i in range(0, 240, 5)]
+
+    def answer(q):
+        hits = vr.search([q], top_k=10)[0]
+        dense = [(h["note_id"], h["retrieval_info"]["similarity"]) for h in hits]
+        sc = dbm.bm25_scores(corpus, notes, q)
+        bm = [(notes[i]["note_id"], s) for i, s in enumerate(sc) if s > 0][:200]
+        return [(r["note_id"], r["final_similarity"]) for r in hs.fuse(dense=dense, bm25=bm)]
+
+    expected = [answer(q) for q in queries]
+    assert all(len(e) > 0 for e in expected)
+    for _ in range(3):
+        with ThreadPoolExecutor(max_workers=8) as ex:
+            got = list(ex.map(answer, queries))
+        assert got == expected
+    corpus.close()

@@ -7,7 +7,10 @@ dev = torch.device("cuda", 0)
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 shapes = [("qk", 1536, 768), ("v/out", 768, 768), ("ffn-up", 3072, 768), ("ffn-down", 768, 3072),
           ("m3 qk", 2048, 1024), ("m3 ffn-up", 4096, 1024), ("m3 ffn-down", 1024, 4096)]
-for name, N, K in shapes:
+# the library's best case on this chip (large square-ish GEMMs): the practical ceiling the 2.5 PFLOP/s figure derates to
+shapes = [(n, N, K, T) for n, N, K in shapes] + [("8k cube", 8192, 8192, 8192), ("16k x 8k x 8k", 8192, 8192, 16384),
+                                               ("self-join block 100k x 100k x 768", 100_096, 768, 100_096 // 2)]
+for name, N, K, T in shapes:
     a = torch.randn((T, K), device=dev, dtype=torch.float16)
     w = torch.randn((N, K), device=dev, dtype=torch.float16)
     for _ in range(10): c = a @ w.t()
