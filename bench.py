@@ -9,9 +9,9 @@ batch of 64 queries answered end to end (query prep, scan, select, exact re-scor
 
 N = 1: the whole corpus sits on one MI355X (fp32 rows + blocked f16 image = 46 GB).
 N > 1 (launched by torch.distributed.run, one rank per GPU): the corpus is row-sharded, every rank
-scans its shard for the same batch, the [64,100] partial top-k (score f32 + global id i64) are
-all-gathered over RCCL and merged — each batch only after anr_index_wait() has made it final on its shard
-(certificate recovery included); strong scaling (total corpus fixed).
+scans its shard for the same batch, the [64,100] partial top-k (score f32 + global id i64) of two consecutive
+batches are all-gathered over RCCL in one collective and merged — each batch only after anr_index_wait() has made it
+final on its shard (certificate recovery included); strong scaling (total corpus fixed).
 
 Rank 0 prints ONE JSON line.  `value` = queries/s of the whole job with the corpus resident in HBM.
 `roofline` is for the dominant kernel (k_scan): algorithmic bytes = rows x 768 x 2 B (the f16 image
@@ -62,6 +62,8 @@ def parse():
     ap.add_argument("--serial-launches", type=int, default=20,
                     help="serialised batches after the timed region from which the kernel-only scan time is taken")
     ap.add_argument("--no-facade", action="store_true", help="skip the VectorIndex.search (host in, dicts out) leg")
+    ap.add_argument("--exchange-group", type=int, default=2,
+                    help="N > 1: batches whose partial top-k lists travel in one all-gather")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsal)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--force-dist", action="store_true",
@@ -468,67 +470,88 @@ def main():
     gq.manual_seed(4321)
     Q = torch.randn((nb + n_serial, args.batch, args.dim), generator=gq, device=dev, dtype=torch.float32)
     # steps are issued asynchronously and overlap (the small kernels of neighbouring batches run beside the scan):
-    # NSLOT rotating sets of output buffers and streams
-    NSLOT = 3
+    # NSLOT rotating sets of output buffers and streams.
+    # N > 1: the partial lists of G consecutive batches travel in ONE all-gather (fewer, larger collectives: at shard
+    # size a per-batch exchange added a serial ~44 us to a 345-us batch — measured with the world-size-1 rehearsal), and
+    # only once they are FINAL on this shard (anr_index_wait: certificate recovery done), LAG batches behind the search
+    # front so the device never idles on the host.
+    LAG = 2
+    G = max(1, args.exchange_group) if dist_on else 1
+    NSLOT = (LAG + G + G - 1) // G * G if dist_on else 3
     streams = [torch.cuda.Stream(device=dev) for _ in range(NSLOT)]
-    # per slot one packed result buffer [B*k f32 | B*k i64]: the index writes both halves, and for N > 1 the
-    # partial top-k lists of all ranks travel in ONE all-gather
+    # per slot one packed result buffer [B*k f32 | pad | B*k i64] (the index writes both halves); the slots are
+    # contiguous, so a group of G of them is one send buffer
     from anorag_hip.sharded import packed_layout
     nres = args.batch * args.k
     id_off, part = packed_layout(nres)  # [nres f32 | pad to 8 B | nres i64]
-    Pl = [torch.empty(part, device=dev, dtype=torch.uint8) for _ in range(NSLOT)]
+    P_all = torch.empty(NSLOT * part, device=dev, dtype=torch.uint8)
+    Pl = [P_all[s * part:(s + 1) * part] for s in range(NSLOT)]
     Dl = [p[: nres * 4].view(torch.float32).view(args.batch, args.k) for p in Pl]
     Il = [p[id_off:].view(torch.int64).view(args.batch, args.k) for p in Pl]
     if dist_on:
         from anorag_hip._lib import OPT_ID_OFFSET
         idx.set_option(OPT_ID_OFFSET, row0)  # the shard returns global ids (no -1 padding: every shard holds >= k rows)
-        Pg = [torch.empty(world * part, device=dev, dtype=torch.uint8) for _ in range(NSLOT)]
+        Pg = [torch.empty(world * G * part, device=dev, dtype=torch.uint8) for _ in range(NSLOT // G)]
         Dm = [torch.empty_like(Dl[0]) for _ in range(NSLOT)]
         Im = [torch.empty_like(Il[0]) for _ in range(NSLOT)]
+        slot_free = [None] * NSLOT  # event after which a slot's send buffer may be overwritten by a later batch
     lib = _lib.load()
     torch.cuda.synchronize()
 
-    # N > 1: the exchange of batch i runs only once batch i is FINAL on its shard (anr_index_wait: certificate
-    # recovery done), LAG batches behind the search front so the device never idles on the host
-    LAG = NSLOT - 1
-    pending = []
+    pending = []   # (batch index, slot) issued and not yet exchanged, oldest first
+    issued = [0]   # batches issued since the last finish(): slot = issued % NSLOT, so groups start on multiples of G
     merged = {}
 
-    def exchange(i):
-        s = i % NSLOT
-        st = streams[s]
+    def exchange(group):
+        """all-gather + merge of consecutive batches whose slots are contiguous (len(group) <= G)"""
+        n = len(group)
+        s0 = group[0][1]
+        st = streams[group[-1][1]]
         idx.wait(len(pending))  # everything older than the still-pending batches is final
+        recv = Pg[s0 // G][: world * n * part]
         with torch.cuda.stream(st):
             if args.backend == "nccl":
-                dist.all_gather_into_tensor(Pg[s], Pl[s])
+                dist.all_gather_into_tensor(recv, P_all[s0 * part:(s0 + n) * part])
             else:  # rehearsal path (gloo has no all_gather_into_tensor for device tensors)
                 st.synchronize()
-                ph = [torch.empty(part, dtype=torch.uint8) for _ in range(world)]
-                dist.all_gather(ph, Pl[s].cpu())
-                Pg[s].copy_(torch.cat(ph))
-            _lib.check(lib.anr_merge_topk_strided_dev(
-                local_rank, C.c_void_p(Pg[s].data_ptr()), C.c_void_p(Pg[s].data_ptr() + id_off),
-                part // 4, part // 8, world, args.batch, args.k, 1,
-                C.c_void_p(Dm[s].data_ptr()), C.c_void_p(Im[s].data_ptr()),
-                C.c_void_p(st.cuda_stream)), "anr_merge_topk_strided_dev")
-        merged["last"] = (Dm[s], Im[s])
+                ph = [torch.empty(n * part, dtype=torch.uint8) for _ in range(world)]
+                dist.all_gather(ph, P_all[s0 * part:(s0 + n) * part].cpu())
+                recv.copy_(torch.cat(ph))
+            for t, (_, s) in enumerate(group):  # rank r's list of batch t sits at r * n * part + t * part
+                base = recv.data_ptr() + t * part
+                _lib.check(lib.anr_merge_topk_strided_dev(
+                    local_rank, C.c_void_p(base), C.c_void_p(base + id_off), n * part // 4, n * part // 8, world,
+                    args.batch, args.k, 1, C.c_void_p(Dm[s].data_ptr()), C.c_void_p(Im[s].data_ptr()),
+                    C.c_void_p(st.cuda_stream)), "anr_merge_topk_strided_dev")
+            ev = torch.cuda.Event()
+            ev.record(st)
+        for _, s in group:
+            slot_free[s] = ev
+        merged["last"] = (Dm[group[-1][1]], Im[group[-1][1]])
 
     def step(i):
-        s = i % NSLOT
+        s = issued[0] % NSLOT
+        issued[0] += 1
+        if dist_on and slot_free[s] is not None:  # the group that last sent this slot was gathered on another stream
+            streams[s].wait_event(slot_free[s])
+            slot_free[s] = None
         idx.search_device_async(Q[i].data_ptr(), args.batch, args.k, Dl[s].data_ptr(), Il[s].data_ptr(),
                                 streams[s].cuda_stream)
         if dist_on:
-            pending.append(i)
-            if len(pending) > LAG:
-                exchange(pending.pop(0))
+            pending.append((i, s))
+            if len(pending) >= LAG + G:
+                grp = [pending.pop(0) for _ in range(G)]
+                exchange(grp)
         else:
             merged["last"] = (Dl[s], Il[s])
 
     def finish():
         idx.sync()              # retires every batch; runs the exact path where a certificate failed
         while pending:
-            exchange(pending.pop(0))
+            grp = [pending.pop(0) for _ in range(min(G, len(pending)))]
+            exchange(grp)
         torch.cuda.synchronize()
+        issued[0] = 0
 
     # clocks and first touches settle over the first few dozen batches of a process (the driver's 5-step warm-up left the
     # scan ~4 % slower than steady state in round 2): a fixed untimed pre-warm-up before the W warm-up steps
@@ -640,7 +663,8 @@ def main():
                 "dim": args.dim,
                 "batch": args.batch,
                 "k": args.k,
-                "parallelism": f"row-shard x{world}" if world > 1 else "single GPU",
+                "parallelism": (f"row-shard x{world}, partial top-k of {G} batches per RCCL all-gather" if dist_on
+                                else "single GPU"),
             },
             "recall_at_k": recall,
             "recall_queries": (args.batch if args.recall_queries < 0 else args.recall_queries),
