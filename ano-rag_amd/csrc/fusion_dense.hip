@@ -19,6 +19,8 @@
 //   k_fd_build   per query: the K' best of all chunk lists, ordered; composes SHORT lists (candidates + short-list
 //                ids, raw scores, whole-source maxima / ranks as overrides)
 //   k_fuse<true> the reference arithmetic on those short lists (the kernel anr_fuse_lists uses; golden-pinned)
+// An array source may also arrive in SPARSE form (its explicit entries, every other id 0.0 — a BM25 row): k_fs_sort +
+// k_fs_stage then stand in for k_fd_max + k_fd_scan and nothing of length N is read (see "the sparse form" below).
 // Exactness: an id outside the short lists has the same fused value in the stream as in the reference (all its
 // terms come from arrays), so the best `pool` of those are among the stream's K' best; ids of the short lists are
 // always candidates.  Ties: final desc, then the reference's order (rrf: ranks-dict insertion; linear: lower id,

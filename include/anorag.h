@@ -223,9 +223,11 @@ typedef struct anr_fuse_source {
 } anr_fuse_source;
 typedef struct anr_fuse_dense_stats {
   int64_t n_queries;
-  int64_t scan_bytes;        /* algorithmic bytes of the streaming pass: sum of array_len * sizeof(element) per query */
+  int64_t scan_bytes;        /* algorithmic bytes of the streaming pass: sum of array_len * sizeof(element) per query
+                                (a sparse source: sparse_cap * 12 per query, the rows' capacity)                      */
   int64_t n_candidates;      /* ids the streaming pass kept, summed over queries                                    */
-  float scan_ms;             /* HIP-event time of the streaming kernels (max pass + scan) over all sub-batches       */
+  float scan_ms;             /* HIP-event time of the streaming kernels (max pass + scan; a sparse source: sort + prep
+                                + stage) over all sub-batches                                                          */
 } anr_fuse_dense_stats;
 int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const anr_fuse_source *sources /*[4]*/,
                    const double *weights /*[4]*/, double rrf_k, int32_t pool, int64_t *out_ids, double *out_final,
