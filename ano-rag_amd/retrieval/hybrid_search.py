@@ -338,8 +338,11 @@ class HybridSearcher:
             return [[] for _ in range(nq)]
         rows = corpus.scores_sparse_device(queries, normalize=True, allow_overflow=True)
         try:
-            results = self.fuse_arrays(nq, dense=dense, bm25=rows, graph=graph, path=path, note_ids=note_ids)
-            heavy = [i for i in range(nq) if rows.counts[i] < 0]
+            heavy = np.flatnonzero(rows.counts < 0).tolist()
+            if 2 * len(heavy) > nq:  # mostly frequent-word queries: one pass down the N-vector path for all of them
+                heavy, results = list(range(nq)), [None] * nq
+            else:
+                results = self.fuse_arrays(nq, dense=dense, bm25=rows, graph=graph, path=path, note_ids=note_ids)
         finally:
             rows.free()
         if heavy:

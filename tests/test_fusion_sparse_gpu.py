@@ -244,4 +244,10 @@ def test_fuse_bm25_sends_heavy_queries_down_the_vector_path(method):
     exp = hs.fuse_arrays(nq, dense=dense, bm25=full)
     full.free()
     assert hs.fuse_bm25(dev, toks, dense=dense) == exp
+    # mostly frequent-word queries: the whole batch takes the N-vector path
+    toks2 = [dbm.tokenize_text(f"{vocab[i % 3]} {vocab[50 + i]}") for i in range(6)] + toks[:2]
+    full2 = dev.scores_device(toks2, normalize=True)
+    exp2 = hs.fuse_arrays(len(toks2), dense=dense[:len(toks2)], bm25=full2)
+    full2.free()
+    assert hs.fuse_bm25(dev, toks2, dense=dense[:len(toks2)]) == exp2
     dev.close()

@@ -76,7 +76,7 @@ cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/fd -- python3 $R/tools/fuse_dense_perf.py 2>&1 | grep "queries x" > $O/${ROUND}_fuse_dense_c5.txt
 cp $(ls $O/fd/*/*kernel_stats.csv | head -1) $O/${ROUND}_fuse_dense_c5_kernel_stats.csv
 rm -rf $O/fd
-python3 $R/tools/bm25_fuse_perf.py 2>&1 | grep -v amdgpu | tail -3 > $O/${ROUND}_bm25_fuse_pipeline_lines.txt
+{ python3 $R/tools/bm25_fuse_perf.py; echo "--- rare-term queries (vocabulary ranks 1000..30000)"; QLO=1000 QHI=30000 python3 $R/tools/bm25_fuse_perf.py; } 2>&1 | grep -v amdgpu > $O/${ROUND}_bm25_fuse_pipeline_lines.txt
 python3 $R/tools/gemm_yardstick.py 2>&1 | grep -v amdgpu > $O/${ROUND}_gemm_yardstick.txt
 fi
 ls -la $O >&2
