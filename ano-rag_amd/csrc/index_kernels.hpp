@@ -342,8 +342,13 @@ __device__ __forceinline__ void scan_emit(const floatx16 &acc, float tau, int lv
   if (lvl + 3 < kLadder && cc) atomicAdd(lds_pend + q * kLadder + lvl + 3, cc);
 }
 
+#if defined(ANR_SCAN_VGPR_CAP)  // experiment: cap the scan's registers so that a side kernel's wave fits beside three of its waves
+#define ANR_SCAN_ATTR __attribute__((amdgpu_waves_per_eu(512 / ANR_SCAN_VGPR_CAP, 512 / ANR_SCAN_VGPR_CAP)))
+#else
+#define ANR_SCAN_ATTR
+#endif
 template <bool DENSE, int CH, int NT, bool STREAM>
-__global__ __launch_bounds__(NT) void k_scan(ScanParams p) {
+__global__ __launch_bounds__(NT) ANR_SCAN_ATTR void k_scan(ScanParams p) {
   // LDS: Q operand image [2][kb][64] | ladder [64][L] | list lengths [64] | level [64] | pending [64][L]
   extern __shared__ uint4 lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
