@@ -7,6 +7,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import gc
 
 import numpy as np
 
@@ -21,11 +22,27 @@ def _f32_matrix(a, d, what):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
+_heap_settled = False
+
+
+def _settle_interpreter_heap() -> None:
+    """Once per process, when the first index is created: one full collection of the interpreter's heap.  A per-query
+    search is ~30 us, and the collector's first generation-2 pass over everything the imports left behind (numpy,
+    tokenizers, ...) is ~38 ms in the middle of one of them — the 188th and 317th call of a fresh process in
+    tools/first_calls.py, none with the collector off.  After an explicit full collection CPython skips further full
+    passes until a quarter more long-lived objects exist."""
+    global _heap_settled
+    if not _heap_settled:
+        _heap_settled = True
+        gc.collect()
+
+
 class FlatIndex:
     """Exact inner-product / squared-L2 index resident on one MI355X."""
 
     def __init__(self, d: int, metric: int = METRIC_IP, normalize: bool = False, device: int = 0):
         self._lib = _lib.load()
+        _settle_interpreter_heap()
         self.d = int(d)
         self.metric = int(metric)
         self.normalize = bool(normalize)

@@ -29,8 +29,9 @@ def timeit(f, reps=400):
     for i in range(reps): f(i % 512)
     return (time.perf_counter() - t0) / reps * 1e6
 res = {}
-# the first few hundred calls of a process are 4-5x slower (cold clocks / first touches): 171 us per call over the first
-# 400 vs 36 us afterwards — warm up before timing anything
+# the first 400 calls of a process, timed on their own (rounds 1-2: 131-171 us per call — two stalls of ~1 ms and ~38 ms
+# in calls 188 and 317 that were Python's collector making its first full passes, tools/first_calls.py; FlatIndex now
+# runs one full collection when the first index of a process is created)
 idx.set_option(OPT_TINY, int(os.environ.get("TINY_MODE", "1")))  # 2 = wherever the path is able
 t0 = time.perf_counter()
 for i in range(400): wrapper(i % 512)
