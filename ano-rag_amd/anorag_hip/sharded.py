@@ -44,6 +44,40 @@ def packed_layout(nres: int) -> Tuple[int, int]:
     return id_off, id_off + int(nres) * 8
 
 
+class ExchangePlan:
+    """Book-keeping of a pipelined search loop whose batches are exchanged (all-gather + merge) in GROUPS, `lag` batches
+    behind the search front (bench.py, N > 1): which send-buffer slot a batch writes, and which batches travel together.
+
+    Slots rotate over ``nslot = lag + group`` rounded up to a multiple of `group`; batch number j of a run (counted from
+    the last ``drain``) writes slot ``j % nslot``, so every group starts on a multiple of `group` and its slots are
+    consecutive: with the slots laid out back to back, a group is ONE contiguous send buffer.  A slot is handed out again
+    only after the group that last used it has been returned by ``issue`` / ``drain`` (the caller then orders the new
+    write behind that group's collective with an event)."""
+
+    def __init__(self, lag: int = 2, group: int = 2):
+        if lag < 0 or group < 1:
+            raise ValueError("lag >= 0 and group >= 1")
+        self.lag, self.group = int(lag), int(group)
+        self.nslot = (self.lag + self.group + self.group - 1) // self.group * self.group
+        self.pending: List[Tuple[int, int]] = []  # (batch, slot) issued and not yet handed back, oldest first
+        self.issued = 0
+
+    def issue(self, batch: int) -> Tuple[int, Optional[List[Tuple[int, int]]]]:
+        """-> (slot of this batch, the group to exchange now or None)"""
+        slot = self.issued % self.nslot
+        self.issued += 1
+        self.pending.append((batch, slot))
+        if len(self.pending) >= self.lag + self.group:
+            return slot, [self.pending.pop(0) for _ in range(self.group)]
+        return slot, None
+
+    def drain(self):
+        """the groups still owed at the end of a run (the last one may be short); the slot counter starts over"""
+        while self.pending:
+            yield [self.pending.pop(0) for _ in range(min(self.group, len(self.pending)))]
+        self.issued = 0
+
+
 def merge_topk_host(Dp: np.ndarray, Ip: np.ndarray, k: int, larger_is_better: bool = True):
     """numpy statement of the merge.  Dp/Ip: [P, B, k'] partial lists (global ids, -1 padded) -> (D [B,k], I [B,k])."""
     P, B, kk = Dp.shape

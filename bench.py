@@ -475,9 +475,11 @@ def main():
     # size a per-batch exchange added a serial ~44 us to a 345-us batch — measured with the world-size-1 rehearsal), and
     # only once they are FINAL on this shard (anr_index_wait: certificate recovery done), LAG batches behind the search
     # front so the device never idles on the host.
+    from anorag_hip.sharded import ExchangePlan
     LAG = 2
     G = max(1, args.exchange_group) if dist_on else 1
-    NSLOT = (LAG + G + G - 1) // G * G if dist_on else 3
+    plan = ExchangePlan(LAG, G)  # slot rotation and grouping (CPU-tested: tests/test_sharded_cpu.py)
+    NSLOT = plan.nslot if dist_on else 3
     streams = [torch.cuda.Stream(device=dev) for _ in range(NSLOT)]
     # per slot one packed result buffer [B*k f32 | pad | B*k i64] (the index writes both halves); the slots are
     # contiguous, so a group of G of them is one send buffer
@@ -498,8 +500,7 @@ def main():
     lib = _lib.load()
     torch.cuda.synchronize()
 
-    pending = []   # (batch index, slot) issued and not yet exchanged, oldest first
-    issued = [0]   # batches issued since the last finish(): slot = issued % NSLOT, so groups start on multiples of G
+    issued = [0]   # N = 1: batches issued since the last finish()
     merged = {}
 
     def exchange(group):
@@ -507,7 +508,7 @@ def main():
         n = len(group)
         s0 = group[0][1]
         st = streams[group[-1][1]]
-        idx.wait(len(pending))  # everything older than the still-pending batches is final
+        idx.wait(len(plan.pending))  # everything older than the still-pending batches is final
         recv = Pg[s0 // G][: world * n * part]
         with torch.cuda.stream(st):
             if args.backend == "nccl":
@@ -530,26 +531,27 @@ def main():
         merged["last"] = (Dm[group[-1][1]], Im[group[-1][1]])
 
     def step(i):
-        s = issued[0] % NSLOT
-        issued[0] += 1
-        if dist_on and slot_free[s] is not None:  # the group that last sent this slot was gathered on another stream
+        if not dist_on:
+            s = issued[0] % NSLOT
+            issued[0] += 1
+            idx.search_device_async(Q[i].data_ptr(), args.batch, args.k, Dl[s].data_ptr(), Il[s].data_ptr(),
+                                    streams[s].cuda_stream)
+            merged["last"] = (Dl[s], Il[s])
+            return
+        s, grp = plan.issue(i)
+        if slot_free[s] is not None:  # the group that last sent this slot was gathered on another stream
             streams[s].wait_event(slot_free[s])
             slot_free[s] = None
         idx.search_device_async(Q[i].data_ptr(), args.batch, args.k, Dl[s].data_ptr(), Il[s].data_ptr(),
                                 streams[s].cuda_stream)
-        if dist_on:
-            pending.append((i, s))
-            if len(pending) >= LAG + G:
-                grp = [pending.pop(0) for _ in range(G)]
-                exchange(grp)
-        else:
-            merged["last"] = (Dl[s], Il[s])
+        if grp is not None:
+            exchange(grp)
 
     def finish():
         idx.sync()              # retires every batch; runs the exact path where a certificate failed
-        while pending:
-            grp = [pending.pop(0) for _ in range(min(G, len(pending)))]
-            exchange(grp)
+        if dist_on:
+            for grp in plan.drain():
+                exchange(grp)
         torch.cuda.synchronize()
         issued[0] = 0
 

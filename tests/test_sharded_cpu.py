@@ -69,3 +69,43 @@ def test_shard_bounds_and_merge_edges():
     assert I.tolist() == [[3, 7, 11, 2]] and D.tolist()[0][:2] == [np.float32(0.9)] * 2
     D, I = merge_topk_host(Dp[:, :, :2], Ip[:, :, :2], 6, False)
     assert I.tolist() == [[2, 11, 3, 7, -1, -1]] and D[0, 4] == orc.FLT_MAX
+
+
+@pytest.mark.parametrize("lag,group", [(2, 1), (2, 2), (2, 3), (2, 4), (0, 1), (1, 2), (3, 2)])
+def test_exchange_plan_groups_are_contiguous_and_slots_are_never_overwritten_early(lag, group):
+    """bench.py's N > 1 loop: every batch is exchanged exactly once, a group's slots are consecutive and start on a
+    multiple of the group size (one contiguous send buffer), a slot is handed out again only after the group that last
+    used it has been returned, and at most lag + group - 1 batches are owed after any step"""
+    from anorag_hip.sharded import ExchangePlan
+    rng = np.random.default_rng(lag * 10 + group)
+    plan = ExchangePlan(lag, group)
+    assert plan.nslot % group == 0 and plan.nslot >= lag + group
+    batch = 0
+    for run in range(6):
+        n = int(rng.integers(0, 40))
+        owner = {}            # slot -> batch whose result still sits in it (not yet exchanged)
+        exchanged = []
+        issued_here = []
+
+        def take(grp):
+            assert 1 <= len(grp) <= group
+            slots = [s for _, s in grp]
+            assert slots == list(range(slots[0], slots[0] + len(grp))) and slots[0] % group == 0
+            assert slots[-1] < plan.nslot
+            for b, s in grp:
+                assert owner.pop(s) == b
+                exchanged.append(b)
+
+        for _ in range(n):
+            slot, grp = plan.issue(batch)
+            assert slot not in owner, "a slot was handed out while its previous batch was still owed"
+            owner[slot] = batch
+            issued_here.append(batch)
+            batch += 1
+            if grp is not None:
+                assert len(grp) == group
+                take(grp)
+            assert len(plan.pending) <= lag + group - 1
+        for grp in plan.drain():
+            take(grp)
+        assert exchanged == issued_here and not owner and not plan.pending and plan.issued == 0
