@@ -87,13 +87,14 @@ enc = SentenceEncoder(md)
 prefix = "Represent this sentence for searching relevant passages: "
 sents = [prefix + s for s in oenc.synthetic_sentences(md, 256, seed=7, min_words=8, max_words=24)]
 ids, lens, _ = enc.tokenize(sents)
-enc.encode(sents[:64], batch_size=64, normalize_embeddings=True)
-t0 = time.perf_counter()
-for _ in range(5): E = enc.encode(sents, batch_size=256, normalize_embeddings=True)
-t_enc = (time.perf_counter() - t0) / 5
-t0 = time.perf_counter()
-for _ in range(5): ids, lens, types = enc.tokenize(sents)
-t_tok = (time.perf_counter() - t0) / 5
+for _ in range(2): enc.encode(sents, batch_size=256, normalize_embeddings=True)   # warm-up at the timed shape
+def _median_s(fn, n=9):  # calls timed one by one: the median is not moved by a host hiccup
+    ts = []
+    for _ in range(n):
+        t0 = time.perf_counter(); r = fn(); ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)), r
+t_enc, E = _median_s(lambda: enc.encode(sents, batch_size=256, normalize_embeddings=True))
+t_tok, (ids, lens, types) = _median_s(lambda: enc.tokenize(sents))
 tokens = int(ids.shape[0] * ((ids.shape[1] + 31) // 32 * 32))
 flops = 12 * (2 * tokens * (4 * 768 * 768 + 2 * 768 * 3072)) + 12 * 4 * ids.shape[0] * (ids.shape[1] ** 2) * 768
 t0 = time.perf_counter()
