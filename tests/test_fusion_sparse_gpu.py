@@ -251,3 +251,32 @@ def test_fuse_bm25_sends_heavy_queries_down_the_vector_path(method):
     full2.free()
     assert hs.fuse_bm25(dev, toks2, dense=dense[:len(toks2)]) == exp2
     dev.close()
+
+
+def test_sparse_producer_and_consumer_refuse_what_they_cannot_hold():
+    from anorag_hip import _lib, bm25_search as dbm
+    from anorag_hip.fusion import SparseRows, fuse_dense
+    rng = np.random.default_rng(14)
+    vocab, probs, notes = _corpus(rng, 2000, 500, 12)
+    dev = dbm.build_bm25_corpus(notes, lambda n: n["content"])
+    toks = [dbm.tokenize_text(vocab[20])]
+    with pytest.raises(_lib.AnoragError):          # more than the LDS table can take
+        dev.scores_sparse_device(toks, cap=dev.SPARSE_CAP + 1)
+    with pytest.raises(_lib.AnoragError):
+        dev.scores_sparse_device(toks, cap=0)
+    assert dev.scores_sparse_device([], cap=16).nq == 0          # no queries: nothing to do
+    rows = dev.scores_sparse_device(toks, cap=4)                  # a capacity the query does not fit
+    assert rows is None
+    rows = dev.scores_sparse_device(toks, cap=4, allow_overflow=True)
+    assert rows.counts.tolist() == [-1]
+    rows.free()
+    dev.close()
+    w = {"dense": 1.0, "bm25": 0.5, "graph": 0.5, "path": 0.1}
+    big = SparseRows(1, 100_000, 8193)             # beyond the fusion's 8192 entries per row
+    with pytest.raises(_lib.AnoragError):
+        fuse_dense("linear", w, 60.0, 10, 1, {"bm25": big})
+    big.free()
+    far = SparseRows.from_numpy([(np.array([5]), np.array([1.0]))], 2**28)   # rrf ranks are packed into 28 bits
+    with pytest.raises(_lib.AnoragError):
+        fuse_dense("rrf", w, 60.0, 10, 1, {"bm25": far})
+    far.free()
