@@ -348,11 +348,135 @@ class ShardedSearcher:
         Ip = np.stack([p[id_off:].numpy().view(np.int64).reshape(B, k) for p in parts])
         return merge_topk_host_c(Dp, Ip, self.larger)
 
+    def stream(self, nq: int, k: int, lag: int = 2, group: int = 2) -> "ShardedStream":
+        """pipelined searches of a stream of [nq, dim] batches, `group` batches per exchange (``ShardedStream``)"""
+        return ShardedStream(self, nq, k, lag, group)
+
     def search(self, q: np.ndarray, k: int):
         q = np.asarray(q)
         if self.index is not None and self.backend == "nccl" and (self.world > 1 or self.force_device):
             return self._search_device(q, int(k))
         return self._search_host(q, int(k))
+
+
+class ShardedStream:
+    """The pipelined form of ``ShardedSearcher.search`` for a STREAM of equal-shape query batches (bench.py, N > 1; a
+    serving loop): ``submit`` launches this shard's search of one batch and returns at once; the partial lists of
+    `group` consecutive batches travel in ONE all-gather, `lag` batches behind the search front and only once they are
+    final on this shard; ``submit`` / ``flush`` hand back the merges that completed, as ``(tag, D, I)``.
+
+    Device form (FlatIndex + nccl, or force_device): nothing leaves the GPU — D / I are torch CUDA tensors [nq, k], ordered
+    on the caller's current stream and valid until ``nslot`` further submits; queries are a CUDA tensor (or a numpy array, uploaded).  Host form (gloo, or a
+    callable shard search): the shard search is synchronous, the grouped exchange and the merge run on the host, D / I
+    are numpy arrays."""
+
+    def __init__(self, searcher: "ShardedSearcher", nq: int, k: int, lag: int = 2, group: int = 2):
+        self.s = searcher
+        self.nq, self.k = int(nq), int(k)
+        self.plan = ExchangePlan(lag, group)
+        self.nres = self.nq * self.k
+        self.id_off, self.part = packed_layout(self.nres)
+        s = searcher
+        self.device_form = s.index is not None and s.backend == "nccl" and (s.world > 1 or s.force_device)
+        G, ns = self.plan.group, self.plan.nslot
+        if self.device_form:
+            import torch
+            self.torch = torch
+            dev = torch.device("cuda", s.index.device)
+            self.dev = dev
+            self.streams = [torch.cuda.Stream(device=dev) for _ in range(ns)]
+            # the slots' send buffers are contiguous, so a group of them is one send buffer
+            self.send = torch.empty(ns * self.part, device=dev, dtype=torch.uint8)
+            self.recv = [torch.empty(s.world * G * self.part, device=dev, dtype=torch.uint8) for _ in range(ns // G)]
+            self.Dm = [torch.empty((self.nq, self.k), device=dev, dtype=torch.float32) for _ in range(ns)]
+            self.Im = [torch.empty((self.nq, self.k), device=dev, dtype=torch.int64) for _ in range(ns)]
+            self.slot_free = [None] * ns  # event behind the collective that last read a slot
+            self._keep = [None] * ns      # uploaded queries stay alive until their slot comes round again
+        else:
+            self.send_h = np.zeros((ns, self.part), dtype=np.uint8)
+
+    # -- one group: all-gather + merge ---------------------------------------------------------------------------
+    def _exchange_device(self, grp):
+        from . import _lib
+        torch, s = self.torch, self.s
+        n, s0 = len(grp), grp[0][1]
+        st = self.streams[grp[-1][1]]
+        s.index.wait(len(self.plan.pending))  # everything older than the still-pending batches is final on this shard
+        recv = self.recv[s0 // self.plan.group][: s.world * n * self.part]
+        out = []
+        with torch.cuda.stream(st):
+            s.dist.all_gather_into_tensor(recv, self.send[s0 * self.part:(s0 + n) * self.part], group=s.group)
+            for t, (tag, slot) in enumerate(grp):  # rank r's list of batch t sits at r * n * part + t * part
+                base = recv.data_ptr() + t * self.part
+                _lib.check(_lib.load().anr_merge_topk_strided_dev(
+                    s.index.device, C.c_void_p(base), C.c_void_p(base + self.id_off), n * self.part // 4,
+                    n * self.part // 8, s.world, self.nq, self.k, int(s.larger), C.c_void_p(self.Dm[slot].data_ptr()),
+                    C.c_void_p(self.Im[slot].data_ptr()), C.c_void_p(st.cuda_stream)), "anr_merge_topk_strided_dev")
+                out.append((tag, self.Dm[slot], self.Im[slot]))
+            ev = torch.cuda.Event()
+            ev.record(st)
+        for _, slot in grp:
+            self.slot_free[slot] = ev
+        # the caller's stream sees the merged lists complete (a device-side wait: nothing blocks on the host)
+        torch.cuda.current_stream(self.dev).wait_event(ev)
+        return out
+
+    def _exchange_host(self, grp):
+        import torch
+        s = self.s
+        n, s0 = len(grp), grp[0][1]
+        mine = torch.from_numpy(self.send_h[s0:s0 + n].reshape(-1).copy())
+        if s.world > 1:
+            parts = [torch.empty_like(mine) for _ in range(s.world)]
+            s.dist.all_gather(parts, mine, group=s.group)
+        else:
+            parts = [mine]
+        out = []
+        for t, (tag, _) in enumerate(grp):
+            lo = t * self.part
+            Dp = np.stack([p[lo:lo + self.nres * 4].numpy().view(np.float32).reshape(self.nq, self.k) for p in parts])
+            Ip = np.stack([p[lo + self.id_off:lo + self.part].numpy().view(np.int64).reshape(self.nq, self.k) for p in parts])
+            D, I = merge_topk_host_c(Dp, Ip, s.larger)
+            out.append((tag, D, I))
+        return out
+
+    # -- the stream --------------------------------------------------------------------------------------------
+    def submit(self, q, tag=None):
+        """launch this shard's search of one [nq, dim] batch; -> the merges that completed, [(tag, D, I), ...]"""
+        s = self.s
+        if self.device_form:
+            torch = self.torch
+            slot, grp = self.plan.issue(tag)
+            if self.slot_free[slot] is not None:  # the group that last sent this slot was gathered on another stream
+                self.streams[slot].wait_event(self.slot_free[slot])
+                self.slot_free[slot] = None
+            if isinstance(q, np.ndarray):
+                q = torch.from_numpy(np.ascontiguousarray(q, dtype=np.float32)).to(self.dev)
+                self._keep[slot] = q
+            base = self.send.data_ptr() + slot * self.part
+            s.index.search_device_async(q.data_ptr(), self.nq, self.k, base, base + self.id_off,
+                                        self.streams[slot].cuda_stream)
+            return self._exchange_device(grp) if grp is not None else []
+        if hasattr(q, "detach"):
+            q = q.detach().cpu().numpy()
+        q = np.asarray(q)
+        if s.index is not None:
+            D, I = s.index.search(q, self.k)  # global ids (ANR_OPT_ID_OFFSET)
+        else:
+            D, I = s.local_search(q, self.k)
+            I = np.where(I >= 0, I + s.row_offset, -1)
+        slot, grp = self.plan.issue(tag)
+        row = self.send_h[slot]
+        row[: self.nres * 4] = np.ascontiguousarray(D, dtype=np.float32).reshape(-1).view(np.uint8)
+        row[self.id_off:] = np.ascontiguousarray(I, dtype=np.int64).reshape(-1).view(np.uint8)
+        return self._exchange_host(grp) if grp is not None else []
+
+    def flush(self):
+        """the merges still owed (device form: call after the index has retired every batch — ``FlatIndex.sync``)"""
+        out = []
+        for grp in self.plan.drain():
+            out += self._exchange_device(grp) if self.device_form else self._exchange_host(grp)
+        return out
 
 
 def merge_topk_device(device: int, Dg, Ig, k: int, larger_is_better: bool, D_out, I_out, stream: int = 0) -> None:

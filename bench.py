@@ -471,89 +471,48 @@ def main():
     gq = torch.Generator(device=dev)
     gq.manual_seed(4321)
     Q = torch.randn((nb + n_serial, args.batch, args.dim), generator=gq, device=dev, dtype=torch.float32)
-    # steps are issued asynchronously and overlap (the small kernels of neighbouring batches run beside the scan):
-    # NSLOT rotating sets of output buffers and streams.
-    # N > 1: the partial lists of G consecutive batches travel in ONE all-gather (fewer, larger collectives: at shard
-    # size a per-batch exchange added a serial ~44 us to a 345-us batch — measured with the world-size-1 rehearsal), and
-    # only once they are FINAL on this shard (anr_index_wait: certificate recovery done), LAG batches behind the search
-    # front so the device never idles on the host.
-    from anorag_hip.sharded import ExchangePlan
+    # steps are issued asynchronously and overlap (the small kernels of neighbouring batches run beside the scan).
+    # N = 1: three rotating sets of output buffers and streams.
+    # N > 1: anorag_hip.sharded.ShardedStream — the shard's search of a batch is launched and left in flight; the partial
+    # lists of G consecutive batches travel in ONE all-gather (fewer, larger collectives: at shard size a per-batch
+    # exchange added a serial ~44 us to a 345-us batch — measured with the world-size-1 rehearsal), only once they are
+    # FINAL on this shard (anr_index_wait: certificate recovery done) and LAG batches behind the search front, so the
+    # device never idles on the host; the merge runs out of the receive buffer on the device.
     LAG = 2
     G = max(1, args.exchange_group) if dist_on else 1
-    plan = ExchangePlan(LAG, G)  # slot rotation and grouping (CPU-tested: tests/test_sharded_cpu.py)
-    NSLOT = plan.nslot if dist_on else 3
+    NSLOT = 3
     streams = [torch.cuda.Stream(device=dev) for _ in range(NSLOT)]
-    # per slot one packed result buffer [B*k f32 | pad | B*k i64] (the index writes both halves); the slots are
-    # contiguous, so a group of G of them is one send buffer
-    from anorag_hip.sharded import packed_layout
-    nres = args.batch * args.k
-    id_off, part = packed_layout(nres)  # [nres f32 | pad to 8 B | nres i64]
-    P_all = torch.empty(NSLOT * part, device=dev, dtype=torch.uint8)
-    Pl = [P_all[s * part:(s + 1) * part] for s in range(NSLOT)]
-    Dl = [p[: nres * 4].view(torch.float32).view(args.batch, args.k) for p in Pl]
-    Il = [p[id_off:].view(torch.int64).view(args.batch, args.k) for p in Pl]
+    Dl = [torch.empty((args.batch, args.k), device=dev, dtype=torch.float32) for _ in range(NSLOT)]
+    Il = [torch.empty((args.batch, args.k), device=dev, dtype=torch.int64) for _ in range(NSLOT)]
+    stream = None
     if dist_on:
-        from anorag_hip._lib import OPT_ID_OFFSET
-        idx.set_option(OPT_ID_OFFSET, row0)  # the shard returns global ids (no -1 padding: every shard holds >= k rows)
-        Pg = [torch.empty(world * G * part, device=dev, dtype=torch.uint8) for _ in range(NSLOT // G)]
-        Dm = [torch.empty_like(Dl[0]) for _ in range(NSLOT)]
-        Im = [torch.empty_like(Il[0]) for _ in range(NSLOT)]
-        slot_free = [None] * NSLOT  # event after which a slot's send buffer may be overwritten by a later batch
-    lib = _lib.load()
+        from anorag_hip.sharded import ShardedSearcher
+        # (the searcher makes the shard return global ids: ANR_OPT_ID_OFFSET = row0; every shard holds >= k rows)
+        searcher = ShardedSearcher(idx, row0, force_device=(world == 1 and args.backend == "nccl"))
+        stream = searcher.stream(args.batch, args.k, lag=LAG, group=G)
     torch.cuda.synchronize()
 
     issued = [0]   # N = 1: batches issued since the last finish()
     merged = {}
 
-    def exchange(group):
-        """all-gather + merge of consecutive batches whose slots are contiguous (len(group) <= G)"""
-        n = len(group)
-        s0 = group[0][1]
-        st = streams[group[-1][1]]
-        idx.wait(len(plan.pending))  # everything older than the still-pending batches is final
-        recv = Pg[s0 // G][: world * n * part]
-        with torch.cuda.stream(st):
-            if args.backend == "nccl":
-                dist.all_gather_into_tensor(recv, P_all[s0 * part:(s0 + n) * part])
-            else:  # rehearsal path (gloo has no all_gather_into_tensor for device tensors)
-                st.synchronize()
-                ph = [torch.empty(n * part, dtype=torch.uint8) for _ in range(world)]
-                dist.all_gather(ph, P_all[s0 * part:(s0 + n) * part].cpu())
-                recv.copy_(torch.cat(ph))
-            for t, (_, s) in enumerate(group):  # rank r's list of batch t sits at r * n * part + t * part
-                base = recv.data_ptr() + t * part
-                _lib.check(lib.anr_merge_topk_strided_dev(
-                    local_rank, C.c_void_p(base), C.c_void_p(base + id_off), n * part // 4, n * part // 8, world,
-                    args.batch, args.k, 1, C.c_void_p(Dm[s].data_ptr()), C.c_void_p(Im[s].data_ptr()),
-                    C.c_void_p(st.cuda_stream)), "anr_merge_topk_strided_dev")
-            ev = torch.cuda.Event()
-            ev.record(st)
-        for _, s in group:
-            slot_free[s] = ev
-        merged["last"] = (Dm[group[-1][1]], Im[group[-1][1]])
-
     def step(i):
-        if not dist_on:
+        if stream is None:
             s = issued[0] % NSLOT
             issued[0] += 1
             idx.search_device_async(Q[i].data_ptr(), args.batch, args.k, Dl[s].data_ptr(), Il[s].data_ptr(),
                                     streams[s].cuda_stream)
             merged["last"] = (Dl[s], Il[s])
             return
-        s, grp = plan.issue(i)
-        if slot_free[s] is not None:  # the group that last sent this slot was gathered on another stream
-            streams[s].wait_event(slot_free[s])
-            slot_free[s] = None
-        idx.search_device_async(Q[i].data_ptr(), args.batch, args.k, Dl[s].data_ptr(), Il[s].data_ptr(),
-                                streams[s].cuda_stream)
-        if grp is not None:
-            exchange(grp)
+        done = stream.submit(Q[i], tag=i)
+        if done:
+            merged["last"] = done[-1][1:]
 
     def finish():
         idx.sync()              # retires every batch; runs the exact path where a certificate failed
-        if dist_on:
-            for grp in plan.drain():
-                exchange(grp)
+        if stream is not None:
+            done = stream.flush()
+            if done:
+                merged["last"] = done[-1][1:]
         torch.cuda.synchronize()
         issued[0] = 0
 
@@ -602,7 +561,7 @@ def main():
     recall = None
     if args.recall_queries != 0:
         nrq = args.batch if args.recall_queries < 0 else min(args.recall_queries, args.batch)
-        I_gpu = Ires[:nrq].cpu().numpy()
+        I_gpu = torch.as_tensor(Ires)[:nrq].cpu().numpy()  # (numpy already in the gloo rehearsal)
         qh = Q[nb - 1, :nrq].cpu().numpy()
 
         def shards():

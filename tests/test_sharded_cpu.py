@@ -109,3 +109,47 @@ def test_exchange_plan_groups_are_contiguous_and_slots_are_never_overwritten_ear
         for grp in plan.drain():
             take(grp)
         assert exchanged == issued_here and not owner and not plan.pending and plan.issued == 0
+
+
+def _stream_worker(rank, world, port, n, d, nq, k, n_batches, group, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    x = orc.preprocess_vectors(np.random.default_rng(1234).standard_normal((n, d), dtype=np.float32))
+    x[n // 2 + 3] = x[5]
+    lo, hi = shard_bounds(n, world, rank)
+    shard = x[lo:hi]
+    s = ShardedSearcher(lambda qq, kk: orc.flat_search(qq, shard, kk, "ip"), lo, True)
+    stream = s.stream(nq, k, lag=2, group=group)
+    qs = np.random.default_rng(99).standard_normal((n_batches, nq, d), dtype=np.float32)
+    got, order = {}, []
+    for b in range(n_batches):
+        for tag, D, I in stream.submit(orc.preprocess_vectors(qs[b]), tag=b):
+            got[tag] = (D.copy(), I.copy())
+            order.append(tag)
+        assert len(stream.plan.pending) <= 2 + group - 1
+    for tag, D, I in stream.flush():
+        got[tag] = (D.copy(), I.copy())
+        order.append(tag)
+    assert order == list(range(n_batches))            # every batch once, in submission order
+    np.savez(os.path.join(out_dir, f"s{rank}.npz"), D=np.stack([got[b][0] for b in range(n_batches)]),
+             I=np.stack([got[b][1] for b in range(n_batches)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_batches,group", [(7, 2), (5, 3), (4, 1), (1, 2)])
+def test_sharded_stream_groups_the_exchange_and_matches_the_single_index(tmp_path, n_batches, group):
+    """ShardedStream (bench.py's N > 1 loop): `group` batches per all-gather, a short last group, results per batch
+    identical to the single-index oracle on both ranks"""
+    n, d, world, nq, k = 3001, 48, 2, 5, 9
+    port = _free_port()
+    mp.spawn(_stream_worker, args=(world, port, n, d, nq, k, n_batches, group, str(tmp_path)), nprocs=world, join=True)
+    x = orc.preprocess_vectors(np.random.default_rng(1234).standard_normal((n, d), dtype=np.float32))
+    x[n // 2 + 3] = x[5]
+    qs = np.random.default_rng(99).standard_normal((n_batches, nq, d), dtype=np.float32)
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), f"s{r}.npz"))
+        for b in range(n_batches):
+            Dr, Ir = orc.flat_search(orc.preprocess_vectors(qs[b]), x, k, "ip")
+            assert np.array_equal(got["I"][b], Ir) and np.array_equal(got["D"][b], Dr)

@@ -251,6 +251,26 @@ def test_sharded_searcher_device_path_under_an_nccl_group_of_one():
             s64 = orc.exact_scores(qn, xn, "ip")
             assert orc.near_tie_equal(I - off, Ir, s64, k, 1e-6), (B, k)
             assert np.max(np.abs(D - Dr)) <= SCORE_TOL
+        # the pipelined form (bench.py's N > 1 loop): searches left in flight, two and three batches per all-gather, a
+        # short last group; device tensors out
+        for B, k, group, n_batches in ((64, 100, 2, 9), (3, 7, 3, 7), (5, 1, 1, 4)):
+            stream = srch.stream(B, k, lag=2, group=group)
+            qs = np.random.default_rng(200 + B).standard_normal((n_batches, B, d), dtype=np.float32)
+            qd = torch.from_numpy(qs).cuda()
+            got = {}
+            for b in range(n_batches):
+                for tag, Dt, It in stream.submit(qd[b] if b % 2 else qs[b], tag=b):   # device tensors and numpy arrays
+                    got[tag] = (Dt.cpu().numpy(), It.cpu().numpy())
+            idx.sync()
+            for tag, Dt, It in stream.flush():
+                got[tag] = (Dt.cpu().numpy(), It.cpu().numpy())
+            assert sorted(got) == list(range(n_batches))
+            for b in range(n_batches):
+                qn = orc.preprocess_vectors(qs[b])
+                Dr, Ir = orc.flat_search(qn, xn, k, "ip")
+                s64 = orc.exact_scores(qn, xn, "ip")
+                assert orc.near_tie_equal(got[b][1] - off, Ir, s64, k, 1e-6), (B, k, b)
+                assert np.max(np.abs(got[b][0] - Dr)) <= SCORE_TOL
         idx.close()
     finally:
         dist.destroy_process_group()
