@@ -22,6 +22,7 @@ three streams and the same events also span the wait for the previous batch's sc
 figure is kept as `ms_per_launch_overlapped`; in round 2 it was reported as the kernel time and exceeded
 ms_per_step).  `cpu_baseline` is the oracle (numpy sgemm + argpartition restatement of the reference's
 faiss-flat path) timed on this box's host cores on a bounded row sample and scaled linearly to the full corpus.
+The interpreter's cyclic garbage collector is switched off once the corpus is built (as `timeit` does).
 `legs` (N = 1 only, untimed extras, never `value`): the other BASELINE.json configurations measured in the same
 driver-run process — the 1.25 M-row shard and the 1 M-row C2 pipeline, the C4 encoder forward (MFMA roofline),
 the C5 N-array fusion (HBM roofline).
@@ -30,6 +31,7 @@ from __future__ import annotations
 
 import argparse
 import ctypes as C
+import gc
 import json
 import os
 import sys
@@ -465,6 +467,11 @@ def main():
     del xb
     torch.cuda.empty_cache()
     idx.set_option(OPT_TIMING, 1)
+    # Python's cyclic collector stays off from here on, as `timeit` runs its statements: a generation-2 pass over the heap
+    # torch and numpy leave behind takes 40-70 ms — one landed inside a 60-batch leg and turned 0.35 ms per batch into 1.57
+    # (reference counting still frees everything the loops allocate)
+    gc.collect()
+    gc.disable()
 
     nb = args.steps + args.warmup
     n_serial = max(0, args.serial_launches)
