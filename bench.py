@@ -24,7 +24,7 @@ ms_per_step).  `cpu_baseline` is the oracle (numpy sgemm + argpartition restatem
 faiss-flat path) timed on this box's host cores on a bounded row sample and scaled linearly to the full corpus.
 The interpreter's cyclic garbage collector is switched off once the corpus is built (as `timeit` does).
 `legs` (N = 1 only, untimed extras, never `value`): the other BASELINE.json configurations measured in the same
-driver-run process — the 1.25 M-row shard and the 1 M-row C2 pipeline, the C4 encoder forward (MFMA roofline),
+driver-run process — the 1.25 M-row shard and the 1 M-row C2 pipeline, C1 (one query at a time), the C4 encoder forward (MFMA roofline),
 the C5 N-array fusion (HBM roofline).
 """
 from __future__ import annotations
@@ -335,6 +335,37 @@ def c4_leg(dev, rows=1_000_000, dim=768, k=100):
     return out
 
 
+def c1_leg(dev, rows=10_000, dim=384, k=10):
+    """C1, the reference's own regime: one query at a time over a small corpus, host buffers in and out, synchronous
+    (FlatIndex.search -> the single-launch path); numpy on the host beside it"""
+    from anorag_hip import FlatIndex, METRIC_IP
+    x = np.random.default_rng(1234).standard_normal((rows, dim), dtype=np.float32)
+    q = np.random.default_rng(4321).standard_normal((512, dim), dtype=np.float32)
+    idx = FlatIndex(dim, METRIC_IP, normalize=True, device=dev.index)
+    idx.add(x)
+    for i in range(300):
+        idx.search(q[i:i + 1], k)
+    ts = []
+    for i in range(1000):
+        t0 = time.perf_counter()
+        D, I = idx.search(q[i % 512:i % 512 + 1], k)
+        ts.append(time.perf_counter() - t0)
+    idx.close()
+    xn = x / np.linalg.norm(x, axis=1, keepdims=True)
+    tc = []
+    for i in range(200):
+        t0 = time.perf_counter()
+        qq = q[i:i + 1] / np.linalg.norm(q[i:i + 1])
+        s = qq @ xn.T
+        part = np.argpartition(-s, k - 1, axis=1)[:, :k]
+        np.argsort(-np.take_along_axis(s, part, 1), axis=1)
+        tc.append(time.perf_counter() - t0)
+    return {"rows": rows, "dim": dim, "k": k, "us_per_query_median": float(np.median(ts)) * 1e6,
+            "us_per_query_p99": float(np.percentile(ts, 99)) * 1e6, "queries_timed": len(ts),
+            "numpy_host_us_per_query_median": float(np.median(tc)) * 1e6,
+            "note": "FlatIndex.search(np.float32[1, dim], k): host buffers in and out, one kernel launch, results polled from pinned memory"}
+
+
 def c5_leg(dev, nq=200, nn=1_000_000, pool=80):
     """C5's fusion half: HybridSearcher.fuse's arithmetic with bm25 = the FULL N-note score vector per query (what
     bm25_scores() returns: one float64 per note, ~0.1 % non-zero, divided by its maximum) resident on the device and
@@ -591,7 +622,7 @@ def main():
         legs = {}
         for name, fn in (("shard_1250k", lambda: pipeline_leg(1_250_000, args.dim, args.batch, args.k, dev, 11)),
                          ("c2_1m", lambda: pipeline_leg(1_000_000, args.dim, args.batch, args.k, dev, 12)),
-                         ("c4", lambda: c4_leg(dev)), ("c5", lambda: c5_leg(dev))):
+                         ("c1_10k", lambda: c1_leg(dev)), ("c4", lambda: c4_leg(dev)), ("c5", lambda: c5_leg(dev))):
             try:
                 legs[name] = fn()
             except Exception as e:  # a failing extra leg must not cost the headline line
