@@ -659,6 +659,18 @@ __device__ __forceinline__ void fd_scan_chunk(const FdParams &p, FsShared &sh, F
     if (METHOD == 0) return vb[e];
     return nvalid == kFsChunk ? __ballot(f[e] == f[e]) : __ballot(e * kFsThreads + tid < nvalid && f[e] == f[e]);
   };
+  // lanes whose entry e is non-zero or NaN.  rrf ranks by the raw array value, so the test runs on the raw bits (integer
+  // operations instead of a float64 compare per entry); linear tests the fused value
+  auto nz_mask = [&](int e) -> unsigned long long {
+    if (METHOD == 1)
+      return DT0 == 0 ? __ballot((raw[e] & 0x7fffffffffffffffull) != 0ull) : __ballot(((unsigned)raw[e] & 0x7fffffffu) != 0u);
+    return __ballot(!(f[e] == 0.0));
+  };
+  // an all-zero row holds no NaN: its valid lanes are the ones inside the array
+  auto range_mask = [&](int e) -> unsigned long long {
+    if (METHOD == 0) return vb[e];
+    return nvalid == kFsChunk ? ~0ull : __ballot(e * kFsThreads + tid < nvalid);
+  };
   // lanes whose entry e passes both thresholds (for non-NaN doubles d2ord is strictly monotone with -0 == +0: exactly
   // these double comparisons)
   auto pass_mask = [&](int e) -> unsigned long long {
@@ -685,7 +697,7 @@ __device__ __forceinline__ void fd_scan_chunk(const FdParams &p, FsShared &sh, F
     nzid = pb_z1 - pb_z0;
     if (nzid > 0) sid0 = (int64_t)sh.sk_id[pb_z0];
 #pragma unroll
-    for (int e = 0; e < kFdPer; ++e) wtotal += (unsigned)__popcll(__ballot(!(f[e] == 0.0)));
+    for (int e = 0; e < kFdPer; ++e) wtotal += (unsigned)__popcll(nz_mask(e));
   }
   const bool defer = wtotal <= (unsigned)kFsPushMax;  // a sparse wave defers its searches to its own LDS segment
   const int wstart = tid & ~63;
@@ -709,9 +721,9 @@ __device__ __forceinline__ void fd_scan_chunk(const FdParams &p, FsShared &sh, F
   if (!skip0)
 #pragma unroll
   for (int e = 0; e < kFdPer; ++e) {
-    const unsigned long long nzm = __ballot(!(f[e] == 0.0));  // non-zero or NaN
+    const unsigned long long nzm = nz_mask(e);  // non-zero or NaN
     if (nzm == 0ull && !zero_passes) {
-      if (ranks) add_zeros(e, valid_mask(e));
+      if (ranks) add_zeros(e, range_mask(e));
       continue;
     }
     const unsigned long long ok = valid_mask(e);
@@ -752,7 +764,7 @@ __device__ __forceinline__ void fd_scan_chunk(const FdParams &p, FsShared &sh, F
       unsigned pend = 0;
 #pragma unroll
       for (int e = 0; e < kFdPer; ++e) {
-        const unsigned long long nb = valid_mask(e) & __ballot(!(f[e] == 0.0));
+        const unsigned long long nb = valid_mask(e) & nz_mask(e);
         pend |= (unsigned)((nb >> lane) & 1ull) << e;
       }
       while (__any(pend != 0)) {
