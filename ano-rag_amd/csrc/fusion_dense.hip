@@ -26,6 +26,7 @@
 // always candidates.  Ties: final desc, then the reference's order (rrf: ranks-dict insertion; linear: lower id,
 // where the reference iterates a set).
 #include <algorithm>
+#include <cmath>
 #include <mutex>
 #include <cstring>
 #include <vector>
@@ -114,6 +115,11 @@ struct FdParams {
   int64_t *o_offs;               // [nq][5]
   double *o_smax;                // [nq][4]
   FdSparse sp;
+  // linear, one array source: the barrier-free pass (k_fd_scan_free) flags the queries whose chunk lists overflowed;
+  // the regular scan then runs for those alone
+  unsigned *ovf;       // [nq + 1]: per query, and [nq] = any
+  int ovf_any;         // index of the "any" word
+  int only_flagged;    // regular scan: skip the items of queries that are not flagged
 };
 
 __device__ __forceinline__ bool fd_is_array(const FdParams &p, int s) { return p.src[s].arr != nullptr || s == p.sp.src; }
@@ -849,6 +855,7 @@ __global__ __launch_bounds__(kFsThreads, 4) void k_fd_scan(FdParams p, int64_t n
   const int64_t it0 = (int64_t)blockIdx.x * per_wg, it1 = it0 + per_wg < n_items ? it0 + per_wg : n_items;
   // the array source whose next chunk is prefetched (rrf has exactly one; linear: the first present)
   const int s0 = METHOD == 1 ? p.r1_src : (p.src[0].arr ? 0 : p.src[1].arr ? 1 : p.src[2].arr ? 2 : 3);
+  if (p.only_flagged && p.ovf[p.ovf_any] == 0u) return;  // (uniform, before any barrier) nothing overflowed
   FsState st{};
   st.cur_q = -1;
   st.zc = -1;
@@ -928,6 +935,7 @@ __global__ __launch_bounds__(kFsThreads, 4) void k_fd_scan(FdParams p, int64_t n
       T_nxt = load_T(q2);
       fd_load_raw<kFsThreads, DT0>(p.src[s0], p.q0 + q2, (int64_t)c2 * kFsChunk, tid, nxt);
     }
+    if (p.only_flagged && p.ovf[q] == 0u) continue;  // (uniform) this query's lists came out of the barrier-free pass
     if (q != st.cur_q) {
       __syncthreads();
       finish_query();
@@ -965,6 +973,106 @@ __global__ __launch_bounds__(kFsThreads, 4) void k_fd_scan(FdParams p, int64_t n
   }
   __syncthreads();
   finish_query();
+}
+
+// ---- linear, ONE array source: the barrier-free pass ---------------------------------------------------------------
+// On a BM25 row (~0.1 % non-zero) almost nothing the scan above does per chunk is needed: chunk 0's K'-th best is 0.0, so
+// a zero never passes, a chunk holds a handful of candidates, no list overflows and the running threshold never moves —
+// but every chunk still pays the staging protocol's barrier (eight waves arriving microseconds apart).  Here the waves
+// run free: a wave tests the raw bits of its eight entry rows, computes fused values only for rows with a non-zero entry,
+// and appends what beats chunk 0's threshold straight to the chunk's list in global memory (one atomic per row that has
+// a candidate).  No LDS, no barrier.  A list that would overflow (a dense vector, or no usable threshold) flags its QUERY;
+// k_fd_redo_prep clears the flagged queries' counts and the regular scan runs for them alone (it returns at once when
+// nothing is flagged).  Same fused-value arithmetic in the same order as fd_scan_chunk, so the keys of chunk 0 (regular
+// scan) and of the other chunks compare consistently.
+template <int DT0>
+__global__ __launch_bounds__(kFsThreads) void k_fd_scan_free(FdParams p, int64_t n_items) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int per_q = p.n_chunks - 1;
+  const int64_t per_wg = (n_items + gridDim.x - 1) / gridDim.x;
+  const int64_t it0 = (int64_t)blockIdx.x * per_wg, it1 = it0 + per_wg < n_items ? it0 + per_wg : n_items;
+  if (it0 >= it1) return;
+  const int s0 = p.src[0].arr ? 0 : p.src[1].arr ? 1 : p.src[2].arr ? 2 : 3;
+  const double w = p.w[s0], w3 = p.w[3];
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  unsigned long long nxt[kFdPer];
+  int q2 = (int)(it0 / per_q), c2 = 1 + (int)(it0 % per_q);
+  fd_load_raw<kFsThreads, DT0>(p.src[s0], p.q0 + q2, (int64_t)c2 * kFsChunk, tid, nxt);
+  int cur_q = -1;
+  double sm = 0.0, t0d = 0.0;
+  bool has_t0 = false, zero_passes = true;
+  for (int64_t item = it0; item < it1; ++item) {
+    const int q = q2, c = c2;
+    unsigned long long raw[kFdPer];
+#pragma unroll
+    for (int e = 0; e < kFdPer; ++e) raw[e] = nxt[e];
+    if (item + 1 < it1) {
+      if (++c2 == p.n_chunks) {
+        c2 = 1;
+        ++q2;
+      }
+      fd_load_raw<kFsThreads, DT0>(p.src[s0], p.q0 + q2, (int64_t)c2 * kFsChunk, tid, nxt);
+    }
+    if (q != cur_q) {
+      cur_q = q;
+      const unsigned long long o = s0 < 3 ? p.smax_ord[(int64_t)q * 4 + s0] : 0ull;
+      sm = o ? ord2d(o) : 0.0;
+      const unsigned long long tau0 = p.tau0[q];
+      has_t0 = tau0 != 0ull;
+      t0d = has_t0 ? ord2d(tau0) : 0.0;
+      zero_passes = !has_t0 || 0.0 > t0d;
+    }
+    const int64_t base = (int64_t)c * kFsChunk;
+    const int64_t room = p.src[s0].len - base;
+    const int nv = room >= kFsChunk ? kFsChunk : (room > 0 ? (int)room : 0);
+    unsigned *cnt = p.c_cnt + (int64_t)q * p.n_chunks + c;
+    const int64_t at = ((int64_t)q * p.n_chunks + c) * p.lcap;
+#pragma unroll
+    for (int e = 0; e < kFdPer; ++e) {
+      const bool nonzero = DT0 == 0 ? (raw[e] & 0x7fffffffffffffffull) != 0ull : ((unsigned)raw[e] & 0x7fffffffu) != 0u;
+      if (!__any(nonzero) && !zero_passes) continue;  // a row of zeros: fused values of exactly 0.0, below the threshold
+      const double x = fd_raw_value(DT0, raw[e]);
+      const bool ok = (nv == kFsChunk || e * kFsThreads + tid < nv) && x == x;
+      double f = 0.0;
+      if (s0 < 3) {
+        double r = sm < 0.0 ? -x : x;
+        if (__any(ok && x != 0.0)) r = x == 0.0 ? r : x / sm;
+        if (sm == 0.0) r = 0.0;
+        const double t = f + w * r;
+        f = ok ? t : f;
+        f = f + w3 * 0.0;
+      } else {
+        f = f + (ok ? w * x : w * 0.0);
+      }
+      const unsigned long long pm = __ballot(ok && (!has_t0 || f > t0d));
+      if (pm == 0ull) continue;
+      const unsigned n = (unsigned)__popcll(pm);
+      unsigned pos = 0;
+      if (lane == 0) {
+        pos = atomicAdd(cnt, n);
+        if (pos + n > (unsigned)p.lcap) {  // the regular scan takes this query over
+          p.ovf[q] = 1u;
+          p.ovf[p.ovf_any] = 1u;
+        }
+      }
+      pos = (unsigned)__builtin_amdgcn_readfirstlane((int)pos);
+      if ((pm >> lane) & 1ull) {
+        const unsigned mine = pos + (unsigned)__popcll(pm & lt_mask);
+        if (mine < (unsigned)p.lcap) {
+          p.c_hi[at + mine] = d2ord(f);
+          p.c_id[at + mine] = (unsigned)(base + e * kFsThreads + tid);
+        }
+      }
+    }
+  }
+}
+
+// the flagged queries start over: their chunk counts (chunk 0 stays: it came from the regular scan) back to zero
+__global__ __launch_bounds__(256) void k_fd_redo_prep(FdParams p) {
+  if (p.ovf[p.ovf_any] == 0u) return;
+  const int q = blockIdx.x;
+  if (p.ovf[q] == 0u) return;
+  for (int c = 1 + threadIdx.x; c < p.n_chunks; c += 256) p.c_cnt[(int64_t)q * p.n_chunks + c] = 0u;
 }
 
 // ---- build: K' best of the chunk lists, ordered; compose the short lists k_fuse<true> consumes ------------------
@@ -1474,7 +1582,7 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
   if (method != 0 && method != 1) return fail(ANR_EINVAL, "method must be 0 (linear) or 1 (rrf)");
   if (pool > kFdMaxSparse) return fail(ANR_EINVAL, "pool must be <= %d", kFdMaxSparse);
   if (nq == 0) return ANR_OK;
-  int n_arr = 0, r1 = -1, sp_src = -1;
+  int n_arr = 0, r1 = -1, sp_src = -1, arr_src = -1;
   int64_t U = 0;
   for (int s = 0; s < 4; ++s) {
     if (src[s].sparse_ids_dev) {
@@ -1493,6 +1601,7 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
       if (src[s].array_len <= 0 || src[s].array_len > 0xfffffff0ll) return fail(ANR_EINVAL, "source %d: bad array length", s);
       if (src[s].array_dtype != 0 && src[s].array_dtype != 1) return fail(ANR_EINVAL, "source %d: dtype must be 0 (f64) or 1 (f32)", s);
       ++n_arr;
+      arr_src = s;
       U = std::max<int64_t>(U, src[s].array_len);
       if (s < 3) r1 = s;
       if (method == 1 && s == 3) return fail(ANR_EINVAL, "rrf: the path source must be a list");
@@ -1562,7 +1671,8 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
   const size_t d_up = dc.take(n_ent * 16 + (size_t)nq * 5 * 8);
   // zeroed per sub-batch with one memset: [H | smax | T | tau0 | c_cnt]
   const size_t z_H = 0, z_smax = z_H + (((size_t)QB * (kFdMaxSparse + 1) * 4 + 7) & ~(size_t)7), z_T = z_smax + (size_t)QB * 32,
-               z_tau = z_T + (size_t)QB * 8, z_cnt = z_tau + (size_t)QB * 8, z_bytes = z_cnt + (size_t)QB * n_chunks * 4;
+               z_tau = z_T + (size_t)QB * 8, z_cnt = z_tau + (size_t)QB * 8, z_ovf = z_cnt + (size_t)QB * n_chunks * 4,
+               z_bytes = z_ovf + (size_t)(QB + 1) * 4;
   // (the 64-bit words behind the odd-sized histogram — 4100 bytes per query — must stay 8-byte aligned: k_fd_max and
   // the scan apply 64-bit atomics to them, and a 4-byte-aligned one raises a bus error)
   if ((z_smax | z_T | z_tau) & 7) return fail(ANR_EINTERNAL, "fuse_dense: misaligned 64-bit work area");
@@ -1652,6 +1762,8 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
     p.T = reinterpret_cast<unsigned long long *>(D + d_zero + z_T);
     p.tau0 = reinterpret_cast<unsigned long long *>(D + d_zero + z_tau);
     p.c_cnt = reinterpret_cast<unsigned *>(D + d_zero + z_cnt);
+    p.ovf = reinterpret_cast<unsigned *>(D + d_zero + z_ovf);
+    p.ovf_any = (int)nb;
     p.c_hi = reinterpret_cast<unsigned long long *>(D + d_chi);
     p.c_id = reinterpret_cast<unsigned *>(D + d_cid);
     p.lcap = lcap;
@@ -1690,7 +1802,18 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
         p.chunk0 = 1;
         p.prefix = 0;
         const int64_t items = nb * (int64_t)(n_chunks - 1);
+        // linear with one array source and finite weights: the barrier-free pass first, the regular scan for the queries
+        // it flags (none on a sparse vector)
+        const bool free_pass = method == 0 && n_arr == 1 && std::isfinite(weights[arr_src]) && std::isfinite(weights[3]);
+        if (free_pass) {
+          const dim3 g((unsigned)std::min<int64_t>(items, 4 * (int64_t)n_cu)), b(kFsThreads);
+          if (src[arr_src].array_dtype == 0) hipLaunchKernelGGL(k_fd_scan_free<0>, g, b, 0, st, p, items);
+          else hipLaunchKernelGGL(k_fd_scan_free<1>, g, b, 0, st, p, items);
+          hipLaunchKernelGGL(k_fd_redo_prep, dim3((unsigned)nb), dim3(256), 0, st, p);
+          p.only_flagged = 1;
+        }
         launch_scan(method, (unsigned)std::min<int64_t>(items, 2 * n_cu), st, p, items);
+        p.only_flagged = 0;
       }
     }
     if (timed) (void)hipEventRecord(ev[1], st);
