@@ -26,6 +26,7 @@
 // always candidates.  Ties: final desc, then the reference's order (rrf: ranks-dict insertion; linear: lower id,
 // where the reference iterates a set).
 #include <algorithm>
+#include <type_traits>
 #include <cmath>
 #include <mutex>
 #include <cstring>
@@ -568,6 +569,16 @@ struct FsShared : FdSharedT<kFsChunk> {
                        // segment fills up during chunk c; slot (c + 3) % 4 is cleared after the barrier of chunk c
 };
 
+// the barrier-free rrf pass (k_fd_scan<1, DT, true>) stages nothing: the same fields without the 48 KiB staging arrays,
+// so that four workgroups fit a CU instead of two
+struct FsSharedFree : FdSharedT<1> {
+  unsigned long long pk[kFsWaves * kFsPendW];
+  unsigned pi[kFsWaves * kFsPendW];
+  unsigned pw_n[kFsWaves];
+  unsigned n4[4];
+  unsigned drain4[4];
+};
+
 // workgroup barrier that waits for this wave's LDS traffic only (global loads of the next chunk stay in flight)
 __device__ __forceinline__ void fs_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -621,13 +632,17 @@ struct FsState {
 };
 
 // one chunk; `raw` = the prefetched values of array source s0, T = the running threshold read with them
-template <int METHOD, int DT0>
-__device__ __forceinline__ void fd_scan_chunk(const FdParams &p, FsShared &sh, FsState &st, const int q, const int c,
+// FREE (rrf only): no staging and no chunk barrier — candidates go straight to the chunk's list in global memory (a
+// list that would overflow flags the query for the regular scan, as in k_fd_scan_free), a wave searches its own deferred
+// entries when its segment fills up, the running threshold is not consulted; the rank bookkeeping is unchanged.
+template <int METHOD, int DT0, bool FREE, typename SH>
+__device__ __forceinline__ void fd_scan_chunk(const FdParams &p, SH &sh, FsState &st, const int q, const int c,
                                               const int s0, const unsigned long long (&raw)[kFdPer], const unsigned long long T) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int64_t base = (int64_t)c * kFsChunk;
   const int skn = st.skn;
-  const bool ranks = METHOD == 1 && skn > 0;
+  // (the regular scan re-doing a flagged query after the barrier-free pass: the rank histogram is already complete)
+  const bool ranks = METHOD == 1 && skn > 0 && !(p.only_flagged && !FREE);
   const unsigned long long kzero = 0x8000000000000000ull;  // d2ord(0.0)
   // pb of one (key, id) pair = short-list keys (sorted descending, ties by id) that beat it: binary search, branch-free
   // (every LDS read unconditional)
@@ -647,7 +662,7 @@ __device__ __forceinline__ void fd_scan_chunk(const FdParams &p, FsShared &sh, F
   };
   const unsigned long long Tu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(T >> 32)) << 32) |
                                 (unsigned)__builtin_amdgcn_readfirstlane((int)T);
-  const bool has_t0 = st.tau0 != 0ull, has_T = Tu != 0ull;
+  const bool has_t0 = st.tau0 != 0ull, has_T = !FREE && Tu != 0ull;
   const double t0d = has_t0 ? ord2d(st.tau0) : 0.0, Td = has_T ? ord2d(Tu) : 0.0;
   // do zero entries pass the thresholds?  (Almost never: chunk 0's K'-th best is >= 0 in a mostly-zero vector.)
   const bool zero_passes = (!has_t0 || 0.0 > t0d) && (!has_T || 0.0 >= Td);
@@ -819,13 +834,34 @@ __device__ __forceinline__ void fd_scan_chunk(const FdParams &p, FsShared &sh, F
     }
     const unsigned long long pm = pass_mask(e);
     if (pm) {
-      unsigned wbase = 0;
-      if (lane == 0) wbase = atomicAdd(&sh.n4[par], (unsigned)__popcll(pm));
-      wbase = (unsigned)__builtin_amdgcn_readfirstlane((int)wbase);
-      if ((pm >> lane) & 1ull) {
-        const unsigned pos = wbase + (unsigned)__popcll(pm & lt_mask);
-        sh.hi[pos] = d2ord(f[e]);
-        sh.idx[pos] = (unsigned)(base + e * kFsThreads + tid);
+      if constexpr (FREE) {
+        const unsigned n = (unsigned)__popcll(pm);
+        unsigned pos = 0;
+        if (lane == 0) {
+          pos = atomicAdd(p.c_cnt + (int64_t)q * p.n_chunks + c, n);
+          if (pos + n > (unsigned)p.lcap) {
+            p.ovf[q] = 1u;
+            p.ovf[p.ovf_any] = 1u;
+          }
+        }
+        pos = (unsigned)__builtin_amdgcn_readfirstlane((int)pos);
+        if ((pm >> lane) & 1ull) {
+          const unsigned mine = pos + (unsigned)__popcll(pm & lt_mask);
+          if (mine < (unsigned)p.lcap) {
+            const int64_t at = ((int64_t)q * p.n_chunks + c) * p.lcap + mine;
+            p.c_hi[at] = d2ord(f[e]);
+            p.c_id[at] = (unsigned)(base + e * kFsThreads + tid);
+          }
+        }
+      } else {
+        unsigned wbase = 0;
+        if (lane == 0) wbase = atomicAdd(&sh.n4[par], (unsigned)__popcll(pm));
+        wbase = (unsigned)__builtin_amdgcn_readfirstlane((int)wbase);
+        if ((pm >> lane) & 1ull) {
+          const unsigned pos = wbase + (unsigned)__popcll(pm & lt_mask);
+          sh.hi[pos] = d2ord(f[e]);
+          sh.idx[pos] = (unsigned)(base + e * kFsThreads + tid);
+        }
       }
     }
   }
@@ -835,8 +871,18 @@ __device__ __forceinline__ void fd_scan_chunk(const FdParams &p, FsShared &sh, F
       if (cnt1) atomicAdd(&sh.H[pb_z0 + 1], cnt1);
       if (defer && wtotal) {
         sh.pw_n[tid >> 6] = st.pw;
-        if (st.pw > kFsDrainAt) sh.drain4[(par + 1) & 3] = 1;  // acted on after the NEXT chunk's barrier
+        if (!FREE && st.pw > kFsDrainAt) sh.drain4[(par + 1) & 3] = 1;  // acted on after the NEXT chunk's barrier
       }
+    }
+    if (FREE && defer && st.pw > kFsDrainAt) {  // the wave searches its own segment (its LDS writes above are complete
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // for the wave once the counter has drained)
+      __builtin_amdgcn_wave_barrier();
+      const int w0 = (tid >> 6) * kFsPendW;
+      for (int i = lane; i < (int)st.pw; i += 64) atomicAdd(&sh.H[beaten_by(sh.pk[w0 + i], (int64_t)sh.pi[w0 + i])], 1u);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      st.pw = 0;
+      if (lane == 0) sh.pw_n[tid >> 6] = 0;
     }
     if (!defer) {  // a dense wave: one search per round while any lane still has one
       unsigned pend = 0;
@@ -857,6 +903,7 @@ __device__ __forceinline__ void fd_scan_chunk(const FdParams &p, FsShared &sh, F
       }
     }
   }
+  if constexpr (FREE) return;
   fs_barrier();  // ---- the chunk barrier ----
   const int n = (int)sh.n4[par];
   const bool drain = METHOD == 1 && sh.drain4[par] != 0;
@@ -917,17 +964,18 @@ __device__ __forceinline__ void fd_scan_chunk(const FdParams &p, FsShared &sh, F
   __syncthreads();
 }
 
-template <int METHOD, int DT0>  // DT0: dtype of the prefetched array source
+template <int METHOD, int DT0, bool FREE = false>  // DT0: dtype of the prefetched array source
 __global__ __launch_bounds__(kFsThreads, 4) void k_fd_scan(FdParams p, int64_t n_items) {
   extern __shared__ unsigned char fd_smem[];
-  FsShared &sh = *reinterpret_cast<FsShared *>(fd_smem);
+  using SH = typename std::conditional<FREE, FsSharedFree, FsShared>::type;
+  SH &sh = *reinterpret_cast<SH *>(fd_smem);
   const int tid = threadIdx.x;
   const int per_q = p.prefix ? 1 : p.n_chunks - 1;  // items of one query in this launch
   const int64_t per_wg = (n_items + gridDim.x - 1) / gridDim.x;
   const int64_t it0 = (int64_t)blockIdx.x * per_wg, it1 = it0 + per_wg < n_items ? it0 + per_wg : n_items;
   // the array source whose next chunk is prefetched (rrf has exactly one; linear: the first present)
   const int s0 = METHOD == 1 ? p.r1_src : (p.src[0].arr ? 0 : p.src[1].arr ? 1 : p.src[2].arr ? 2 : 3);
-  if (p.only_flagged && p.ovf[p.ovf_any] == 0u) return;  // (uniform, before any barrier) nothing overflowed
+  if (!FREE && p.only_flagged && p.ovf[p.ovf_any] == 0u) return;  // (uniform, before any barrier) nothing overflowed
   FsState st{};
   st.cur_q = -1;
   st.zc = -1;
@@ -984,7 +1032,7 @@ __global__ __launch_bounds__(kFsThreads, 4) void k_fd_scan(FdParams p, int64_t n
     // a few extra candidates at worst — an agent-scope atomic load went past the L2 and took ~4 us per chunk
     // (relaxed agent-scope atomic: re-read every chunk, but — unlike a volatile load — not waited for on the spot; it
     // is consumed one chunk later, with the prefetched values)
-    return p.prefix ? 0ull : __hip_atomic_load(p.T + fd_per_lane(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (p.prefix || FREE) ? 0ull : __hip_atomic_load(p.T + fd_per_lane(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   unsigned long long nxt[kFdPer];
   unsigned long long T_nxt = 0ull;
@@ -1007,7 +1055,7 @@ __global__ __launch_bounds__(kFsThreads, 4) void k_fd_scan(FdParams p, int64_t n
       T_nxt = load_T(q2);
       fd_load_raw<kFsThreads, DT0>(p.src[s0], p.q0 + q2, (int64_t)c2 * kFsChunk, tid, nxt);
     }
-    if (p.only_flagged && p.ovf[q] == 0u) continue;  // (uniform) this query's lists came out of the barrier-free pass
+    if (!FREE && p.only_flagged && p.ovf[q] == 0u) continue;  // (uniform) this query's lists came out of the barrier-free pass
     if (q != st.cur_q) {
       __syncthreads();
       finish_query();
@@ -1041,7 +1089,7 @@ __global__ __launch_bounds__(kFsThreads, 4) void k_fd_scan(FdParams p, int64_t n
         st.zc = -1;
       }
     }
-    fd_scan_chunk<METHOD, DT0>(p, sh, st, q, c, s0, raw, T);
+    fd_scan_chunk<METHOD, DT0, FREE>(p, sh, st, q, c, s0, raw, T);
   }
   __syncthreads();
   finish_query();
@@ -1881,6 +1929,13 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
           const dim3 g((unsigned)std::min<int64_t>(items, 4 * (int64_t)n_cu)), b(kFsThreads);
           if (src[arr_src].array_dtype == 0) hipLaunchKernelGGL(k_fd_scan_free<0>, g, b, 0, st, p, items);
           else hipLaunchKernelGGL(k_fd_scan_free<1>, g, b, 0, st, p, items);
+          hipLaunchKernelGGL(k_fd_redo_prep, dim3((unsigned)nb), dim3(256), 0, st, p);
+          p.only_flagged = 1;
+        }
+        if (method == 1) {  // rrf: the barrier-free pass keeps the rank bookkeeping and drops the staging protocol
+          const dim3 g((unsigned)std::min<int64_t>(items, 4 * (int64_t)n_cu)), b(kFsThreads);
+          if (src[r1].array_dtype == 0) hipLaunchKernelGGL((k_fd_scan<1, 0, true>), g, b, sizeof(FsSharedFree), st, p, items);
+          else hipLaunchKernelGGL((k_fd_scan<1, 1, true>), g, b, sizeof(FsSharedFree), st, p, items);
           hipLaunchKernelGGL(k_fd_redo_prep, dim3((unsigned)nb), dim3(256), 0, st, p);
           p.only_flagged = 1;
         }
