@@ -412,3 +412,35 @@ def test_rrf_long_lists_in_unrelated_orders_with_string_ids_and_heavy_ties():
         assert [r["final_similarity"] for r in got] == [r["final_similarity"] for r in exp]
         assert [r["scores"] for r in got] == [r["scores"] for r in exp]
     assert all(r["note_id"] != "only_in_path" for r in got)
+
+
+@pytest.mark.parametrize("slot", ["dense", "graph", "path"])
+def test_linear_with_the_one_array_in_any_slot_takes_the_barrier_free_pass(slot):
+    """linear with ONE array source (k_fd_scan_free; the path slot has its own arithmetic: w * x, no normalisation): a
+    sparse vector — nothing overflows — and a dense one — every query is flagged and re-done by the regular scan —
+    against the oracle over several chunks"""
+    from anorag_hip.fusion import DeviceArray, fuse_dense
+    rng = np.random.default_rng({"dense": 1, "graph": 2, "path": 3}[slot])
+    n, nq, pool = 30_000, 3, 60
+    w = {"dense": 0.8, "bm25": 0.6, "graph": 0.4, "path": 0.3}
+    other = "bm25"
+    for density in (0.002, 1.0):
+        a = np.zeros((nq, n))
+        for q in range(nq):
+            ids = rng.choice(n, size=max(1, int(n * density)), replace=False)
+            a[q, ids] = np.abs(rng.standard_normal(len(ids)))
+        lists = []
+        for q in range(nq):
+            ids = rng.choice(n, size=50, replace=False).astype(np.int64)
+            lists.append((ids, np.sort(rng.random(50))[::-1].copy()))
+        arr = DeviceArray.from_numpy(a)
+        got = fuse_dense("linear", w, 60.0, pool, nq, {slot: arr, other: lists})
+        arr.free()
+        full = np.arange(n, dtype=np.int64)
+        for q in range(nq):
+            src = {slot: (full, a[q]), other: lists[q]}
+            ids, fin = ofu.fuse_arrays(n, tuple(src.get(k) for k in ("dense", "bm25", "graph", "path")),
+                                       [w["dense"], w["bm25"], w["graph"], w["path"]], "linear", 60.0, pool)
+            cnt = int(got[3][q])
+            assert cnt == len(fin) and got[1][q, :cnt].tolist() == fin.tolist(), (slot, density, q)
+            assert got[0][q, :cnt].tolist() == ids.tolist(), (slot, density, q)
