@@ -628,6 +628,8 @@ struct FsState {
   int zp, zc; // rrf: short-list keys beating a zero entry at the first id of chunk zc
   int par;    // chunk counter mod 4
   bool fast0; // linear: one array source, finite weights (see skip0 in fd_scan_chunk)
+  bool flagged; // barrier-free rrf pass: this query's lists already overflowed (re-read at every chunk)
+  bool dense_q; // barrier-free rrf pass: chunk 0's threshold is not 0.0 — the whole query is left to the regular scan
   unsigned pw; // deferred entries in this wave's segment
 };
 
@@ -641,8 +643,9 @@ __device__ __forceinline__ void fd_scan_chunk(const FdParams &p, SH &sh, FsState
   const int tid = threadIdx.x, lane = tid & 63;
   const int64_t base = (int64_t)c * kFsChunk;
   const int skn = st.skn;
-  // (the regular scan re-doing a flagged query after the barrier-free pass: the rank histogram is already complete)
-  const bool ranks = METHOD == 1 && skn > 0 && !(p.only_flagged && !FREE);
+  // the regular scan re-doing a flagged query after the barrier-free pass: the rank histogram may be complete already
+  // (flag 1 = its lists overflowed DURING that pass, ranks done; flag 2 = left to the regular scan altogether)
+  const bool ranks = METHOD == 1 && skn > 0 && !(p.only_flagged && !FREE && p.ovf[q] == 1u);
   const unsigned long long kzero = 0x8000000000000000ull;  // d2ord(0.0)
   // pb of one (key, id) pair = short-list keys (sorted descending, ties by id) that beat it: binary search, branch-free
   // (every LDS read unconditional)
@@ -835,6 +838,7 @@ __device__ __forceinline__ void fd_scan_chunk(const FdParams &p, SH &sh, FsState
     const unsigned long long pm = pass_mask(e);
     if (pm) {
       if constexpr (FREE) {
+        if (st.flagged) continue;  // (uniform) the regular scan will stage this query's candidates
         const unsigned n = (unsigned)__popcll(pm);
         unsigned pos = 0;
         if (lane == 0) {
@@ -1037,11 +1041,17 @@ __global__ __launch_bounds__(kFsThreads, 4) void k_fd_scan(FdParams p, int64_t n
   unsigned long long nxt[kFdPer];
   unsigned long long T_nxt = 0ull;
   int q = 0, c = 0, q2 = 0, c2 = 0;
+  bool dense2 = false;  // the query of the next item is not this pass's (FREE: left to the regular scan; re-do pass: not
+                        // flagged) — nothing is loaded for it
   if (it0 < it1) {
     q2 = (int)(it0 / per_q);
     c2 = p.prefix ? 0 : 1 + (int)(it0 % per_q);
     T_nxt = load_T(q2);
-    fd_load_raw<kFsThreads, DT0>(p.src[s0], p.q0 + q2, (int64_t)c2 * kFsChunk, tid, nxt);
+    if (FREE) dense2 = p.tau0[q2] != kzero;
+    else if (p.only_flagged) dense2 = p.ovf[q2] == 0u;  // (the re-do pass: queries that are not flagged are not loaded)
+#pragma unroll
+    for (int e = 0; e < kFdPer; ++e) nxt[e] = 0ull;
+    if (!dense2) fd_load_raw<kFsThreads, DT0>(p.src[s0], p.q0 + q2, (int64_t)c2 * kFsChunk, tid, nxt);
   }
   for (int64_t item = it0; item < it1; ++item) {
     q = q2;
@@ -1051,9 +1061,12 @@ __global__ __launch_bounds__(kFsThreads, 4) void k_fd_scan(FdParams p, int64_t n
     for (int e = 0; e < kFdPer; ++e) raw[e] = nxt[e];
     const unsigned long long T = T_nxt;
     if (item + 1 < it1) {
+      const int q_before = q2;
       advance(q2, c2);
       T_nxt = load_T(q2);
-      fd_load_raw<kFsThreads, DT0>(p.src[s0], p.q0 + q2, (int64_t)c2 * kFsChunk, tid, nxt);
+      if (FREE && q2 != q_before) dense2 = p.tau0[q2] != kzero;
+      if (!FREE && p.only_flagged && q2 != q_before) dense2 = p.ovf[q2] == 0u;
+      if (!dense2) fd_load_raw<kFsThreads, DT0>(p.src[s0], p.q0 + q2, (int64_t)c2 * kFsChunk, tid, nxt);
     }
     if (!FREE && p.only_flagged && p.ovf[q] == 0u) continue;  // (uniform) this query's lists came out of the barrier-free pass
     if (q != st.cur_q) {
@@ -1077,6 +1090,13 @@ __global__ __launch_bounds__(kFsThreads, 4) void k_fd_scan(FdParams p, int64_t n
         for (int i = tid; i <= st.skn; i += kFsThreads) sh.H[i] = 0;
       }
       st.tau0 = p.prefix ? 0ull : p.tau0[q];
+      if (FREE) {  // (see k_fd_scan_free: only threshold-0.0 queries are taken by the barrier-free pass)
+        st.dense_q = st.tau0 != kzero;
+        if (st.dense_q && tid == 0) {
+          p.ovf[q] = 2u;
+          p.ovf[p.ovf_any] = 1u;
+        }
+      }
       __syncthreads();
       if (METHOD == 1) {  // where the zero-valued short-list keys end
         int lo = 0, hi = st.skn;
@@ -1088,6 +1108,10 @@ __global__ __launch_bounds__(kFsThreads, 4) void k_fd_scan(FdParams p, int64_t n
         st.z_hi = lo;
         st.zc = -1;
       }
+    }
+    if (FREE) {
+      if (st.dense_q) continue;  // (uniform) neither candidates nor ranks: the regular scan does both for this query
+      st.flagged = p.ovf[q] != 0u;
     }
     fd_scan_chunk<METHOD, DT0, FREE>(p, sh, st, q, c, s0, raw, T);
   }
@@ -1117,10 +1141,14 @@ __global__ __launch_bounds__(kFsThreads) void k_fd_scan_free(FdParams p, int64_t
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   unsigned long long nxt[kFdPer];
   int q2 = (int)(it0 / per_q), c2 = 1 + (int)(it0 % per_q);
-  fd_load_raw<kFsThreads, DT0>(p.src[s0], p.q0 + q2, (int64_t)c2 * kFsChunk, tid, nxt);
+  const unsigned long long kzero = 0x8000000000000000ull;
+  bool dense2 = p.tau0[q2] != kzero;  // the query of the NEXT item is left to the regular scan: nothing is loaded for it
+#pragma unroll
+  for (int e = 0; e < kFdPer; ++e) nxt[e] = 0ull;
+  if (!dense2) fd_load_raw<kFsThreads, DT0>(p.src[s0], p.q0 + q2, (int64_t)c2 * kFsChunk, tid, nxt);
   int cur_q = -1;
   double sm = 0.0, t0d = 0.0;
-  bool has_t0 = false, zero_passes = true;
+  bool has_t0 = false, zero_passes = true, dense_q = false;
   for (int64_t item = it0; item < it1; ++item) {
     const int q = q2, c = c2;
     unsigned long long raw[kFdPer];
@@ -1130,8 +1158,9 @@ __global__ __launch_bounds__(kFsThreads) void k_fd_scan_free(FdParams p, int64_t
       if (++c2 == p.n_chunks) {
         c2 = 1;
         ++q2;
+        dense2 = p.tau0[q2] != kzero;
       }
-      fd_load_raw<kFsThreads, DT0>(p.src[s0], p.q0 + q2, (int64_t)c2 * kFsChunk, tid, nxt);
+      if (!dense2) fd_load_raw<kFsThreads, DT0>(p.src[s0], p.q0 + q2, (int64_t)c2 * kFsChunk, tid, nxt);
     }
     if (q != cur_q) {
       cur_q = q;
@@ -1141,7 +1170,17 @@ __global__ __launch_bounds__(kFsThreads) void k_fd_scan_free(FdParams p, int64_t
       has_t0 = tau0 != 0ull;
       t0d = has_t0 ? ord2d(tau0) : 0.0;
       zero_passes = !has_t0 || 0.0 > t0d;
+      // Only a query whose chunk 0 holds fewer than K' positive values (threshold exactly 0.0) is taken here: on a denser
+      // vector the regular scan's RUNNING threshold is what keeps the candidate lists short (without it every chunk would
+      // contribute ~K' candidates).  Such a query is flagged (2) for the regular scan at once.
+      dense_q = tau0 != kzero;
+      if (dense_q && tid == 0) {
+        p.ovf[q] = 2u;
+        p.ovf[p.ovf_any] = 1u;
+      }
     }
+    if (dense_q) continue;
+    if (p.ovf[q] != 0u) continue;  // (uniform) already flagged — a dense vector: the regular scan will do this query
     const int64_t base = (int64_t)c * kFsChunk;
     const int64_t room = p.src[s0].len - base;
     const int nv = room >= kFsChunk ? kFsChunk : (room > 0 ? (int)room : 0);
