@@ -234,14 +234,22 @@ def pipeline_leg(rows, dim, batch, k, dev, seed, steps=60, warmup=10, serial=20)
 
     run(0, warmup)
     idx.reset_stats()
-    t0 = time.perf_counter()
-    run(warmup, nb)
-    dt = (time.perf_counter() - t0) / steps
+    # three segments, the median one reported: twice in nine runs of this leg a one-off ~65 ms stall (no collector, no
+    # fallback query, the kernel times unchanged) sat inside its 60 batches and quadrupled the mean
+    seg = max(1, steps // 3)
+    segs = []
+    for a in range(warmup, nb, seg):
+        b = min(a + seg, nb)
+        t0 = time.perf_counter()
+        run(a, b)
+        segs.append((time.perf_counter() - t0) / (b - a))
+    dt = float(np.median(segs))
     st = idx.last_stats()
     ms_k, bytes_k = serial_kernel_time(idx, Q, nb, serial, batch, k, D[0].data_ptr(), I[0].data_ptr(), S[0].cuda_stream)
     idx.close()
     gbps = bytes_k / 1e9 / (ms_k / 1e3) if ms_k > 0 else None
-    return {"rows": rows, "dim": dim, "batch": batch, "k": k, "ms_per_batch": dt * 1e3, "value": batch / dt,
+    return {"rows": rows, "dim": dim, "batch": batch, "k": k, "ms_per_batch": dt * 1e3,
+            "ms_per_batch_segments": [x * 1e3 for x in segs], "value": batch / dt,
             "unit": "queries/s", "batches": steps, "exact_fallback_queries": st["n_fallback"],
             "scan_ms_per_launch": ms_k, "scan_bytes_per_launch": bytes_k, "scan_GBps": gbps,
             "scan_frac_hbm": gbps / HBM_PEAK_GBPS if gbps else None,
