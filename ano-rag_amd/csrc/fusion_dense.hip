@@ -628,7 +628,7 @@ struct FsState {
   int zp, zc; // rrf: short-list keys beating a zero entry at the first id of chunk zc
   int par;    // chunk counter mod 4
   bool fast0; // linear: one array source, finite weights (see skip0 in fd_scan_chunk)
-  bool flagged; // barrier-free rrf pass: this query's lists already overflowed (re-read at every chunk)
+  bool flagged; // barrier-free rrf pass: this query's lists had already overflowed when this workgroup reached it
   bool dense_q; // barrier-free rrf pass: chunk 0's threshold is not 0.0 — the whole query is left to the regular scan
   unsigned pw; // deferred entries in this wave's segment
 };
@@ -1042,16 +1042,14 @@ __global__ __launch_bounds__(kFsThreads, 4) void k_fd_scan(FdParams p, int64_t n
   unsigned long long T_nxt = 0ull;
   int q = 0, c = 0, q2 = 0, c2 = 0;
   bool dense2 = false;  // the query of the next item is not this pass's (FREE: left to the regular scan; re-do pass: not
-                        // flagged) — nothing is loaded for it
+                        // flagged) — its loads all go to one chunk (cache hits; no branch around the prefetch)
   if (it0 < it1) {
     q2 = (int)(it0 / per_q);
     c2 = p.prefix ? 0 : 1 + (int)(it0 % per_q);
     T_nxt = load_T(q2);
     if (FREE) dense2 = p.tau0[q2] != kzero;
-    else if (p.only_flagged) dense2 = p.ovf[q2] == 0u;  // (the re-do pass: queries that are not flagged are not loaded)
-#pragma unroll
-    for (int e = 0; e < kFdPer; ++e) nxt[e] = 0ull;
-    if (!dense2) fd_load_raw<kFsThreads, DT0>(p.src[s0], p.q0 + q2, (int64_t)c2 * kFsChunk, tid, nxt);
+    else if (p.only_flagged) dense2 = p.ovf[q2] == 0u;  // (the re-do pass: queries that are not flagged are not streamed)
+    fd_load_raw<kFsThreads, DT0>(p.src[s0], p.q0 + q2, (int64_t)(dense2 ? 1 : c2) * kFsChunk, tid, nxt);
   }
   for (int64_t item = it0; item < it1; ++item) {
     q = q2;
@@ -1066,7 +1064,7 @@ __global__ __launch_bounds__(kFsThreads, 4) void k_fd_scan(FdParams p, int64_t n
       T_nxt = load_T(q2);
       if (FREE && q2 != q_before) dense2 = p.tau0[q2] != kzero;
       if (!FREE && p.only_flagged && q2 != q_before) dense2 = p.ovf[q2] == 0u;
-      if (!dense2) fd_load_raw<kFsThreads, DT0>(p.src[s0], p.q0 + q2, (int64_t)c2 * kFsChunk, tid, nxt);
+      fd_load_raw<kFsThreads, DT0>(p.src[s0], p.q0 + q2, (int64_t)(dense2 ? 1 : c2) * kFsChunk, tid, nxt);
     }
     if (!FREE && p.only_flagged && p.ovf[q] == 0u) continue;  // (uniform) this query's lists came out of the barrier-free pass
     if (q != st.cur_q) {
@@ -1091,6 +1089,7 @@ __global__ __launch_bounds__(kFsThreads, 4) void k_fd_scan(FdParams p, int64_t n
       }
       st.tau0 = p.prefix ? 0ull : p.tau0[q];
       if (FREE) {  // (see k_fd_scan_free: only threshold-0.0 queries are taken by the barrier-free pass)
+        st.flagged = p.ovf[q] != 0u;  // (read once per query: a load per chunk would be waited for on the spot)
         st.dense_q = st.tau0 != kzero;
         if (st.dense_q && tid == 0) {
           p.ovf[q] = 2u;
@@ -1111,7 +1110,6 @@ __global__ __launch_bounds__(kFsThreads, 4) void k_fd_scan(FdParams p, int64_t n
     }
     if (FREE) {
       if (st.dense_q) continue;  // (uniform) neither candidates nor ranks: the regular scan does both for this query
-      st.flagged = p.ovf[q] != 0u;
     }
     fd_scan_chunk<METHOD, DT0, FREE>(p, sh, st, q, c, s0, raw, T);
   }
@@ -1142,10 +1140,10 @@ __global__ __launch_bounds__(kFsThreads) void k_fd_scan_free(FdParams p, int64_t
   unsigned long long nxt[kFdPer];
   int q2 = (int)(it0 / per_q), c2 = 1 + (int)(it0 % per_q);
   const unsigned long long kzero = 0x8000000000000000ull;
-  bool dense2 = p.tau0[q2] != kzero;  // the query of the NEXT item is left to the regular scan: nothing is loaded for it
-#pragma unroll
-  for (int e = 0; e < kFdPer; ++e) nxt[e] = 0ull;
-  if (!dense2) fd_load_raw<kFsThreads, DT0>(p.src[s0], p.q0 + q2, (int64_t)c2 * kFsChunk, tid, nxt);
+  // the query of the NEXT item is left to the regular scan: its loads all go to ONE chunk (cache hits, no stream) — a
+  // branch around the prefetch would make hipcc wait for the loads at the join
+  bool dense2 = p.tau0[q2] != kzero;
+  fd_load_raw<kFsThreads, DT0>(p.src[s0], p.q0 + q2, (int64_t)(dense2 ? 1 : c2) * kFsChunk, tid, nxt);
   int cur_q = -1;
   double sm = 0.0, t0d = 0.0;
   bool has_t0 = false, zero_passes = true, dense_q = false;
@@ -1160,7 +1158,7 @@ __global__ __launch_bounds__(kFsThreads) void k_fd_scan_free(FdParams p, int64_t
         ++q2;
         dense2 = p.tau0[q2] != kzero;
       }
-      if (!dense2) fd_load_raw<kFsThreads, DT0>(p.src[s0], p.q0 + q2, (int64_t)c2 * kFsChunk, tid, nxt);
+      fd_load_raw<kFsThreads, DT0>(p.src[s0], p.q0 + q2, (int64_t)(dense2 ? 1 : c2) * kFsChunk, tid, nxt);
     }
     if (q != cur_q) {
       cur_q = q;
@@ -1180,7 +1178,6 @@ __global__ __launch_bounds__(kFsThreads) void k_fd_scan_free(FdParams p, int64_t
       }
     }
     if (dense_q) continue;
-    if (p.ovf[q] != 0u) continue;  // (uniform) already flagged — a dense vector: the regular scan will do this query
     const int64_t base = (int64_t)c * kFsChunk;
     const int64_t room = p.src[s0].len - base;
     const int nv = room >= kFsChunk ? kFsChunk : (room > 0 ? (int)room : 0);
