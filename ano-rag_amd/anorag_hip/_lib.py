@@ -28,6 +28,10 @@ OPT_STREAMS = 7
 OPT_ID_OFFSET = 8
 OPT_TINY = 9
 OPT_FUSED_POST = 10
+OPT_SHADOW = 11
+OPT_SCHEDULE = 12
+OPT_STREAM_WAIT = 13
+BATCH_LOG_FIELDS = 13
 
 
 class AnoragError(RuntimeError):
@@ -116,6 +120,7 @@ SIGNATURES = {
     ),
     "anr_index_set_option": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64]),
     "anr_index_last_stats": (C.c_int, [C.c_void_p, C.POINTER(SearchStats)]),
+    "anr_index_batch_log": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "anr_normalize_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32]),
     "anr_merge_topk_dev": (
         C.c_int,

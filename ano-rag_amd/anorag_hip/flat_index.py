@@ -183,6 +183,20 @@ class FlatIndex:
         _lib.check(self._lib.anr_index_last_stats(self._h, C.byref(st)), "anr_index_last_stats")
         return st.as_dict()
 
+    BATCH_LOG_NAMES = ("seq", "host_enqueue_ns", "host_enqueued_ns", "host_retired_ns", "dev_prep_end_ns",
+                       "dev_sample_end_ns", "dev_ladder_end_ns", "dev_scan_first_wg_ns", "dev_scan_last_wg_ns",
+                       "dev_scan_end_ns", "dev_select_end_ns", "dev_post_end_ns", "flags")
+
+    def batch_log(self, max_batches: int = 512, correlate: bool = True):
+        """time line of the most recent pipeline batches (anr_index_batch_log): (records [n, 13] int64, device clock
+        minus host clock in ns or None); retires the batches in flight first"""
+        out = np.zeros((max(1, int(max_batches)), _lib.BATCH_LOG_FIELDS), dtype=np.int64)
+        n = C.c_int32(0)
+        off = C.c_int64(0)
+        _lib.check(self._lib.anr_index_batch_log(self._h, out.ctypes.data, int(max_batches), C.byref(n),
+                                                 C.byref(off) if correlate else None), "anr_index_batch_log")
+        return out[: n.value], (int(off.value) if correlate else None)
+
     def close(self) -> None:
         if getattr(self, "_h", None):
             self._lib.anr_index_destroy(self._h)

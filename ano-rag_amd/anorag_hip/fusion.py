@@ -185,6 +185,13 @@ def fuse_dense(method: str, weights: Dict[str, float], rrf_k: float, pool: int, 
         if isinstance(v, SparseRows):
             if v.nq != nq:
                 raise ValueError(f"{name}: {v.nq} sparse rows, expected {nq}")
+            if v.counts is not None and (np.asarray(v.counts) < 0).any():
+                # count -1 = the producer's overflow mark (scores_sparse_device(allow_overflow=True)): such a query has to
+                # be fused from its N-vector (HybridSearcher.fuse_bm25 splits the batch); fusing it here would read it as
+                # "every BM25 score is 0.0".  Rows whose counts stayed on the device are checked there (ANR_EINVAL).
+                bad = np.flatnonzero(np.asarray(v.counts) < 0)
+                raise ValueError(f"{name}: sparse rows {bad[:8].tolist()} overflowed in the producer (count -1); "
+                                 "route those queries through the N-vector form")
             src[si].array_len = v.n
             src[si].sparse_ids_dev = v.ids_ptr
             src[si].sparse_scores_dev = v.scores_ptr

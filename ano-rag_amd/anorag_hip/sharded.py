@@ -452,7 +452,14 @@ class ShardedStream:
                 self.slot_free[slot] = None
             if isinstance(q, np.ndarray):
                 q = torch.from_numpy(np.ascontiguousarray(q, dtype=np.float32)).to(self.dev)
-                self._keep[slot] = q
+            else:
+                # a device tensor may still be being WRITTEN by work queued on the caller's stream: the slot's stream (the
+                # one the library is told the queries come from) waits for that stream first, and the caching allocator
+                # learns that the tensor is in use there (without this the scan could read q before its producer
+                # had run, and bench.py / the tests only passed because they synchronise after generating their queries)
+                self.streams[slot].wait_stream(torch.cuda.current_stream(self.dev))
+                q.record_stream(self.streams[slot])
+            self._keep[slot] = q  # alive until the slot comes round again (its batch has been retired by then)
             base = self.send.data_ptr() + slot * self.part
             s.index.search_device_async(q.data_ptr(), self.nq, self.k, base, base + self.id_off,
                                         self.streams[slot].cuda_stream)

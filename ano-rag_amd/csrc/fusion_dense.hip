@@ -78,6 +78,9 @@ struct FdSparse {
   unsigned *id;         // [nq][cap] this sub-batch's rows sorted by id (k_fs_sort), values beside them
   double *val;
   int *cnt;             // [nq]
+  unsigned *err;        // one word, zeroed per sub-batch: bit 0 a row count < 0 (the producer's overflow mark), bit 1 a count
+                        // above cap, bit 2 an id >= the array length, bit 3 an id listed twice — anr_fuse_dense returns
+                        // ANR_EINVAL instead of fusing such a row as if its missing scores were 0.0
 };
 
 struct FdParams {
@@ -578,6 +581,9 @@ struct FsSharedFree : FdSharedT<1> {
   unsigned n4[4];
   unsigned drain4[4];
 };
+// (the barrier-free instantiations are launched without ensure_dynamic_lds: they must stay below the 64 KiB a kernel gets
+// without asking — ADVICE r3)
+static_assert(sizeof(FsSharedFree) <= 64 * 1024, "k_fd_scan<.., FREE>: FsSharedFree outgrew the default dynamic LDS limit");
 
 // workgroup barrier that waits for this wave's LDS traffic only (global loads of the next chunk stay in flight)
 __device__ __forceinline__ void fs_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -1529,6 +1535,7 @@ __global__ __launch_bounds__(kFsSortThreads) void k_fs_sort(FdParams p, int P2ma
   const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cap = p.sp.cap;
   int nnz = p.sp.in_cnt[p.q0 + q];
+  if (tid == 0 && (nnz < 0 || nnz > cap)) atomicOr(p.sp.err, nnz < 0 ? 1u : 2u);
   nnz = nnz < 0 ? 0 : (nnz > cap ? cap : nnz);
   int P2 = 2;
   while (P2 < nnz) P2 <<= 1;
@@ -1541,9 +1548,13 @@ __global__ __launch_bounds__(kFsSortThreads) void k_fs_sort(FdParams p, int P2ma
   __syncthreads();
   double best = 0.0;
   bool any = false;
+  const unsigned alen = (unsigned)(p.src[p.sp.src].len > 0xffffffffll ? 0xffffffffll : p.src[p.sp.src].len);
   for (int i = tid; i < nnz; i += kFsSortThreads) {
     const unsigned long long k = key[i];
     const double v = gv[(unsigned)k];
+    const unsigned id = (unsigned)(k >> 32);
+    if (id >= alen) atomicOr(p.sp.err, 4u);
+    if (i > 0 && (unsigned)(key[i - 1] >> 32) == id) atomicOr(p.sp.err, 8u);
     p.sp.id[(int64_t)q * cap + i] = (unsigned)(k >> 32);
     p.sp.val[(int64_t)q * cap + i] = v;
     if (v == v) {
@@ -1828,7 +1839,7 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
   // zeroed per sub-batch with one memset: [H | smax | T | tau0 | c_cnt]
   const size_t z_H = 0, z_smax = z_H + (((size_t)QB * (kFdMaxSparse + 1) * 4 + 7) & ~(size_t)7), z_T = z_smax + (size_t)QB * 32,
                z_tau = z_T + (size_t)QB * 8, z_cnt = z_tau + (size_t)QB * 8, z_ovf = z_cnt + (size_t)QB * n_chunks * 4,
-               z_bytes = z_ovf + (size_t)(QB + 1) * 4;
+               z_bytes = z_ovf + (size_t)(QB + 2) * 4;  // (+ the sparse-row error word)
   // (the 64-bit words behind the odd-sized histogram — 4100 bytes per query — must stay 8-byte aligned: k_fd_max and
   // the scan apply 64-bit atomics to them, and a 4-byte-aligned one raises a bus error)
   if ((z_smax | z_T | z_tau) & 7) return fail(ANR_EINTERNAL, "fuse_dense: misaligned 64-bit work area");
@@ -1841,7 +1852,7 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
                d_oo = dc.take((size_t)QB * 5 * 8), d_om = dc.take((size_t)QB * 4 * 8);
   const size_t d_spi = dc.take((size_t)QB * sp_cap * 4), d_spv = dc.take((size_t)QB * sp_cap * 8), d_spc = dc.take((size_t)QB * 4);
   // results of a sub-batch, downloaded with one copy: [ids | final | per-source | count]
-  const size_t out_bytes = (size_t)QB * ((size_t)pool * 48 + 4);
+  const size_t out_bytes = (size_t)QB * ((size_t)pool * 48 + 4) + 8;  // (+ the sparse-row error word)
   const size_t d_out = dc.take(out_bytes);
   const size_t h_up = hc.take(n_ent * 16 + (size_t)nq * 5 * 8), h_out = hc.take(out_bytes);
   FuseArena &ar = g_fd_arena[device];
@@ -1900,6 +1911,7 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
       p.sp.id = reinterpret_cast<unsigned *>(D + d_spi);
       p.sp.val = reinterpret_cast<double *>(D + d_spv);
       p.sp.cnt = reinterpret_cast<int *>(D + d_spc);
+      p.sp.err = reinterpret_cast<unsigned *>(D + d_zero + z_ovf) + QB + 1;
     }
     p.rrf_k = rrf_k;
     p.U = U;
@@ -1983,7 +1995,7 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
     hipLaunchKernelGGL(k_fd_build, dim3((unsigned)nb), dim3(kFdThreads), sizeof(FdShared), st, p);
     // the sub-batch's results, packed: [ids nb*pool | final nb*pool | per-source nb*pool*4 | count nb]
     const size_t o_ids = 0, o_fin = (size_t)nb * pool * 8, o_src = o_fin + (size_t)nb * pool * 8,
-                 o_cnt = o_src + (size_t)nb * pool * 32, o_bytes = o_cnt + (size_t)nb * 4;
+                 o_cnt = o_src + (size_t)nb * pool * 32, o_err = o_cnt + (size_t)nb * 4, o_bytes = o_err + 4;
     FuseParams fp{};
     fp.method = method;
     fp.ids = p.o_ids;
@@ -2000,11 +2012,24 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
     fp.rank_ovr = p.o_rank;
     hipLaunchKernelGGL(k_fuse<true>, dim3((unsigned)nb), dim3(1024), sizeof(FuseShared), st, fp);
     e = hipGetLastError();
+    // the sparse rows' error word rides in the same download
+    if (e == hipSuccess && sparse) e = hipMemcpyAsync(D + d_out + o_err, p.sp.err, 4, hipMemcpyDeviceToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(Hs + h_out, D + d_out, o_bytes, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) {
       rc = fail(ANR_EHIP, "fuse_dense failed: %s", hipGetErrorString(e));
       break;
+    }
+    if (sparse) {
+      unsigned err = 0;
+      std::memcpy(&err, Hs + h_out + o_err, 4);
+      if (err) {
+        rc = fail(ANR_EINVAL, "fuse_dense: malformed sparse rows in queries %lld..%lld:%s%s%s%s", (long long)q0, (long long)(q0 + nb - 1),
+                  (err & 1u) ? " a row count < 0 (the producer's overflow mark: that query needs the N-vector form)" : "",
+                  (err & 2u) ? " a row count above the row capacity" : "", (err & 4u) ? " an id >= array_len" : "",
+                  (err & 8u) ? " an id listed twice" : "");
+        break;
+      }
     }
     std::memcpy(out_ids + q0 * pool, Hs + h_out + o_ids, (size_t)nb * pool * 8);
     std::memcpy(out_final + q0 * pool, Hs + h_out + o_fin, (size_t)nb * pool * 8);

@@ -12,6 +12,7 @@
 // (measured at a 1.25 M-row shard: 0.417 -> 0.376 ms per batch).  Queries whose certificate fails are
 // answered by the second pass / the dense exact path when the batch is retired.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <mutex>
@@ -25,6 +26,11 @@ using namespace anr;
 
 
 namespace {
+constexpr int kBatchLogFields = ANR_BATCH_LOG_FIELDS;
+constexpr int kBatchLogCap = 512;
+inline int64_t host_ns() {
+  return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 constexpr int kWorkspaces = 3;
 constexpr int64_t kZeroCopyResults = 64 * 1024;       // nq * k up to which results are written straight to host memory
 
@@ -49,9 +55,14 @@ struct Workspace {
   unsigned *sel_row = nullptr;
   int *sel_m = nullptr;
   float *exact = nullptr;
-  unsigned *cnt_host = nullptr;    // pinned [4][64] batch status, written by k_finalize
+  unsigned *cnt_host = nullptr;    // pinned [6][64] batch status, written by k_post / k_finalize (rows 4-5: the batch's time stamps)
   unsigned *cnt_dev = nullptr;     // the same memory as the device addresses it
+  unsigned long long *stamps = nullptr;  // [kStamps] device time stamps of the batch's kernels (index_kernels.hpp)
+  int64_t t_enq0 = 0, t_enq1 = 0;  // host clock (ns) when the batch's enqueue began / returned
+  int64_t seq = 0;
+  bool shadow = false;             // the batch's side kernels were the shadow-sized ones
   hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+  hipEvent_t ev_pre = nullptr, ev_scan = nullptr;  // role streams: ladder ready (pre -> main), scan done (main -> post)
   // the batch in flight
   bool in_flight = false;   // set once the batch's completion event has been recorded, cleared when it is final
   bool folded = false;      // its statistics have been added to the handle's
@@ -106,6 +117,13 @@ struct anr_index {
 
   // single-launch path for tiny corpora (tiny_kernels.hpp)
   int fused_post = 1;                             // ANR_OPT_FUSED_POST
+  int shadow = 0;                                 // ANR_OPT_SHADOW
+  int schedule = 0;                               // ANR_OPT_SCHEDULE
+  int stream_wait = 0;                            // ANR_OPT_STREAM_WAIT
+  int64_t batch_seq = 0;
+  std::vector<int64_t> batch_log;                 // ring of kBatchLogFields-word records, one per retired batch
+  int64_t batch_log_n = 0;                        // records ever written
+  int clock_khz = 100000;                         // rate of the device's constant clock (wall_clock64)
   int tiny = 1;                                   // ANR_OPT_TINY
   unsigned char *tiny_pin = nullptr, *tiny_pin_dev = nullptr;  // pinned: queries | D | I | completion words
   unsigned char *sr_buf = nullptr;                // anr_index_score_rows scratch
@@ -201,9 +219,13 @@ int alloc_workspaces(anr_index *h) {
     ANR_TRY(dev_alloc(&w.sel_row, kQB * kMaxSel, true));
     ANR_TRY(dev_alloc(&w.sel_m, kQB, true));
     ANR_TRY(dev_alloc(&w.exact, kQB * kMaxSel, true));
-    ANR_HIP(hipHostMalloc(reinterpret_cast<void **>(&w.cnt_host), 4 * kQB * sizeof(unsigned), hipHostMallocDefault));
+    ANR_TRY(dev_alloc(&w.stamps, kStamps, true));
+    ANR_HIP(hipHostMalloc(reinterpret_cast<void **>(&w.cnt_host), 6 * kQB * sizeof(unsigned), hipHostMallocDefault));
+    memset(w.cnt_host, 0, 6 * kQB * sizeof(unsigned));
     ANR_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&w.cnt_dev), w.cnt_host, 0));
     ANR_HIP(hipEventCreateWithFlags(&w.ev_in, hipEventDisableTiming));
+    ANR_HIP(hipEventCreateWithFlags(&w.ev_pre, hipEventDisableTiming | hipEventDisableSystemFence));
+    ANR_HIP(hipEventCreateWithFlags(&w.ev_scan, hipEventDisableTiming | hipEventDisableSystemFence));
     // the batch status lands in pinned memory with its own system-scope fence: no cache write-back needed here
     ANR_HIP(hipEventCreateWithFlags(&w.ev_done, hipEventDisableTiming | hipEventDisableSystemFence));
     ANR_HIP(hipEventCreateWithFlags(&w.ev_t0, hipEventDisableSystemFence));  // timing only
@@ -247,6 +269,35 @@ int launch_select(int nblocks, const SelParams &sp, hipStream_t st) {
   const int nt = 1024;
   (void)n_hint;
   hipLaunchKernelGGL(k_select, dim3(nblocks), dim3(nt), sizeof(SelShared), st, sp);
+  ANR_HIP(hipGetLastError());
+  return ANR_OK;
+}
+
+// shadow-sized side kernels (index_kernels.hpp: k_sample, k_select_shadow, k_rescore_shadow): 256 threads, <= 56 registers,
+// <= 29 KiB of LDS
+int launch_select_shadow(int nblocks, const SelParams &sp, hipStream_t st) {
+  if (sp.G > kShadowLists || sp.M > kShadowSel) return fail(ANR_EINTERNAL, "shadow select: %d lists / %d entries", sp.G, sp.M);
+  hipLaunchKernelGGL(k_select_shadow, dim3(nblocks), dim3(256), sizeof(SelSharedShadow), st, sp);
+  ANR_HIP(hipGetLastError());
+  return ANR_OK;
+}
+
+// k-blocks per LDS slice of the shadow sample: the largest divisor of kb that is a multiple of `ch` and <= 28 (KiB)
+int sample_slice(int kb, int ch) {
+  for (int s = 28 / ch * ch; s >= ch; s -= ch)
+    if (kb % s == 0) return s;
+  return 0;
+}
+
+int launch_sample_shadow(SampleParams p, hipStream_t st, int n_cu) {
+  const int64_t per_half = std::max<int64_t>(1, std::min<int64_t>(n_cu / 2, ceil_div(p.n_tiles, 4)));
+  // (kb % 8 == 0, so slices of a multiple of four blocks always exist)
+  const int ch = p.rowbias ? 2 : 4;
+  p.kbs = sample_slice(p.kb, ch);
+  if (p.kbs <= 0) return fail(ANR_EINTERNAL, "shadow sample: no LDS slice for kb = %d", p.kb);
+  const size_t lds = (size_t)p.kbs * 1024;
+  if (p.rowbias) hipLaunchKernelGGL((k_sample<2, true>), dim3((unsigned)(2 * per_half)), dim3(256), lds, st, p);
+  else hipLaunchKernelGGL((k_sample<4, false>), dim3((unsigned)(2 * per_half)), dim3(256), lds, st, p);
   ANR_HIP(hipGetLastError());
   return ANR_OK;
 }
@@ -498,6 +549,20 @@ int retire(anr_index *h, Workspace &w) {
   }
   if (!w.folded) {
     w.folded = true;
+    if (!w.exact_all && w.sparse) {
+      // one record of the batch log (anr_index_batch_log): host times and the device stamps the last kernel left in the
+      // status block, converted to nanoseconds of the device's constant clock
+      if (h->batch_log.empty()) h->batch_log.assign((size_t)kBatchLogCap * kBatchLogFields, 0);
+      int64_t *rec = h->batch_log.data() + (size_t)(h->batch_log_n % kBatchLogCap) * kBatchLogFields;
+      const unsigned long long *stp = reinterpret_cast<const unsigned long long *>(w.cnt_host + 4 * kQB);
+      rec[0] = w.seq;
+      rec[1] = w.t_enq0;
+      rec[2] = w.t_enq1;
+      rec[3] = host_ns();
+      for (int i = 0; i < kStamps; ++i) rec[4 + i] = (int64_t)((double)stp[i] * 1e6 / (double)h->clock_khz);
+      rec[4 + kStamps] = (w.shadow ? 1 : 0) | ((int64_t)w.nq << 8);
+      h->batch_log_n += 1;
+    }
     if (!w.exact_all) {
       if (w.timed) {
         float ms = 0.f;
@@ -541,7 +606,15 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
   const int ws_index = h->next_ws;
   Workspace &w = h->ws[ws_index];
   h->next_ws = (h->next_ws + 1) % kWorkspaces;
+  const int64_t t_enq0 = host_ns();
   ANR_TRY(retire(h, w));  // back-pressure: the workspace's previous batch must be complete
+  // another batch still in flight = a pipelined caller: this batch's side kernels take their shadow-sized forms, which
+  // run BESIDE the resident workgroups of the scan in front of them instead of after it (ANR_OPT_SHADOW)
+  bool others_in_flight = false;
+  for (int i = 0; i < kWorkspaces; ++i) others_in_flight |= (i != ws_index && h->ws[i].in_flight);
+  w.t_enq0 = t_enq0;
+  w.seq = h->batch_seq++;
+  w.shadow = false;
   w.folded = false;
   w.nq = nq;
   w.k = k;
@@ -554,7 +627,17 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
   w.sample_rows = 0;
   w.exact_all = h->force_exact != 0 || h->f16_unusable;
 
-  hipStream_t bs = h->bstream[ws_index % h->n_streams];
+  // Streams.  ANR_OPT_SCHEDULE 1 (default): ROLE streams — every batch's query preparation, threshold sample and ladder go
+  // to the PRE stream, every main scan to the MAIN stream, every select / re-score / finalize to the POST stream, tied by
+  // two events per batch.  The scans then run strictly one after the other in submission order, and the side kernels of the
+  // neighbouring batches — shadow-sized, see k_sample — run beside them on their own hardware queues: a side kernel that
+  // sat in the same queue as a scan waiting for CUs (or behind another batch's completion marker) used to wait with it, which
+  // put ~45 us of side kernels between two 300-us scans at the 8-GPU shard size.  0: one stream per in-flight batch
+  // (ANR_OPT_STREAMS of them), the scheme of rounds 1-3.
+  const bool roles = h->schedule == 1 && h->n_streams == kWorkspaces;
+  hipStream_t bs = roles ? h->bstream[0] : h->bstream[ws_index % h->n_streams];  // pre
+  hipStream_t ms = roles ? h->bstream[1] : bs;                                    // main scan
+  hipStream_t ps = roles ? h->bstream[2] : bs;                                    // post
   // the queries are ready once everything already enqueued on the caller's stream has run
   // (an idle caller stream has nothing to wait for: skip the cross-queue dependency, which costs the
   // command processor several microseconds per batch)
@@ -577,12 +660,13 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
   qp.q32 = w.q32;
   qp.q16 = w.q16;
   qp.qstat = w.qstat;
+  qp.stamps = w.stamps;
   hipLaunchKernelGGL(k_prepq, dim3(kQB), dim3(256), 0, bs, qp);
 
   if (w.exact_all) {
     ANR_HIP(hipEventRecord(w.ev_done, bs));
     w.in_flight = true;  // only now: a failure above leaves no half-enqueued batch to retire
-    ANR_HIP(hipStreamWaitEvent(user, w.ev_done, 0));
+    if (h->stream_wait) ANR_HIP(hipStreamWaitEvent(user, w.ev_done, 0));
     return ANR_OK;
   }
 
@@ -602,7 +686,10 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
   w.sparse = sparse;
   // k_post runs ONE workgroup per query: a batch of a few queries leaves its select and re-score to a handful of CUs
   // (batch 1, k = 100, 20 k x 768: 92 us fused vs 84 us as three grid-wide launches); from 5 queries up it wins
-  const bool fused_post = h->fused_post == 1 ? nq > 4 : h->fused_post != 0;
+  const bool shadow = sparse && M <= kShadowSel && h->n_cu <= kShadowLists &&
+                      (h->shadow == 2 || (h->shadow == 1 && others_in_flight));
+  w.shadow = shadow;
+  const bool fused_post = !shadow && (h->fused_post == 1 ? nq > 4 : h->fused_post != 0);
   const int side_grid = h->n_cu;
   // (Leaving 8-32 CUs out of the main scan's persistent grid so that the next batch's side kernels run beside it was
   // tried at the 1.25 M-row shard size: wall 0.347 -> 0.345-0.350 ms, and -2 % at 10 M rows.  The scan's 12-wave
@@ -621,6 +708,7 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
   sp.out_rank = w.sel_rank;
   sp.out_row = w.sel_row;
   sp.out_m = w.sel_m;
+  sp.stamps = w.stamps;
 
   if (!sparse) {
     // small corpus: dense scores of every row, select the candidates from them
@@ -630,16 +718,24 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
     sc.n_tiles = n_tiles;
     sc.dense = w.dense;
     sc.dense_ld = w.dense_ld;
-    if (w.timed) ANR_HIP(hipEventRecord(w.ev_t0, bs));
-    ANR_TRY(launch_scan<true>(h, sc, bs, scan_grid_max));
-    if (w.timed) ANR_HIP(hipEventRecord(w.ev_t1, bs));
+    if (roles) {
+      ANR_HIP(hipEventRecord(w.ev_pre, bs));
+      ANR_HIP(hipStreamWaitEvent(ms, w.ev_pre, 0));
+    }
+    if (w.timed) ANR_HIP(hipEventRecord(w.ev_t0, ms));
+    ANR_TRY(launch_scan<true>(h, sc, ms, scan_grid_max));
+    if (w.timed) ANR_HIP(hipEventRecord(w.ev_t1, ms));
+    if (roles) {
+      ANR_HIP(hipEventRecord(w.ev_scan, ms));
+      ANR_HIP(hipStreamWaitEvent(ps, w.ev_scan, 0));
+    }
     w.scan_bytes = n_tiles * kTileRows * (int64_t)h->dimp * 2;
     sp.dense = w.dense;
     sp.dense_ld = w.dense_ld;
     sp.n = h->ntotal;
     sp.row0 = 0;
     sp.row_tile_stride = 1;
-    if (!fused_post) ANR_TRY(launch_select(nq, sp, bs));
+    if (!fused_post) ANR_TRY(launch_select(nq, sp, ps));
   } else {
     ANR_TRY(ensure_dense(w, sample_tiles * kTileRows));
     ANR_TRY(ensure_cand(h, w));
@@ -651,7 +747,23 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
     sc.dense = w.dense;
     sc.dense_ld = w.dense_ld;
     sc.groupmax = 1;  // one value per 32-row tile: the K'-th largest tile maximum is a valid threshold
-    ANR_TRY(launch_scan<true>(h, sc, bs, side_grid));
+    if (shadow) {
+      SampleParams sm{};
+      sm.x16 = sc.x16;
+      sm.q16 = sc.q16;
+      sm.kb = sc.kb;
+      sm.tile_stride = sc.tile_stride;
+      sm.n_tiles = sc.n_tiles;
+      sm.rowbias = sc.rowbias;
+      sm.dense = sc.dense;
+      sm.dense_ld = sc.dense_ld;
+      sm.stamps = w.stamps;
+      ANR_TRY(launch_sample_shadow(sm, bs, h->n_cu));
+    } else {
+      // (fewer, fuller workgroups for a pipelined caller's sample — 8 or 12 waves instead of 4, each filling 96 KiB of LDS
+      // with the query operand once — measured the same per-batch time at 1.25 M rows: 0.3142 / 0.3147 / 0.3162 ms)
+      ANR_TRY(launch_scan<true>(h, sc, bs, side_grid));
+    }
     sc.groupmax = 0;
     // start level of the scan: the highest one whose sample rank still predicts >= 4 K' corpus rows above it
     int lvl0 = 0;
@@ -671,7 +783,8 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
     ss.lvl_init = w.lvlmax;
     ss.lvl_init_value = lvl0;
     ss.live_q = nq;  // slots beyond the batch stay inert in the scan
-    ANR_TRY(launch_select(kQB, ss, bs));
+    if (shadow) ANR_TRY(launch_select_shadow(kQB, ss, bs));
+    else ANR_TRY(launch_select(kQB, ss, bs));
     // scan
     sc.tile0 = 0;
     sc.tile_stride = 1;
@@ -684,11 +797,20 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
     sc.cand = w.cand;
     sc.capb = (unsigned)h->cand_cap;
     sc.kprime = (unsigned)M;
+    sc.stamps = w.stamps;
     int scan_grid = 0;
-    if (w.timed) ANR_HIP(hipEventRecord(w.ev_t0, bs));
-    ANR_TRY(launch_scan<false>(h, sc, bs, scan_grid_max, &scan_grid));
+    if (roles) {
+      ANR_HIP(hipEventRecord(w.ev_pre, bs));
+      ANR_HIP(hipStreamWaitEvent(ms, w.ev_pre, 0));
+    }
+    if (w.timed) ANR_HIP(hipEventRecord(w.ev_t0, ms));
+    ANR_TRY(launch_scan<false>(h, sc, ms, scan_grid_max, &scan_grid));
     w.scan_grid = scan_grid;
-    if (w.timed) ANR_HIP(hipEventRecord(w.ev_t1, bs));
+    if (w.timed) ANR_HIP(hipEventRecord(w.ev_t1, ms));
+    if (roles) {
+      ANR_HIP(hipEventRecord(w.ev_scan, ms));
+      ANR_HIP(hipStreamWaitEvent(ps, w.ev_scan, 0));
+    }
     w.scan_bytes = n_tiles * kTileRows * (int64_t)h->dimp * 2;
     // post
     sp.cand = w.cand;
@@ -697,7 +819,8 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
     sp.capb = (unsigned)h->cand_cap;
     sp.overflow = w.ncand + kQB;
     sp.ncand = w.ncand;
-    if (!fused_post) ANR_TRY(launch_select(nq, sp, bs));
+    if (shadow) ANR_TRY(launch_select_shadow(nq, sp, ps));
+    else if (!fused_post) ANR_TRY(launch_select(nq, sp, ps));
   }
 
   if (fused_post) {
@@ -724,10 +847,12 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
     pp.id_offset = h->id_offset;
     pp.status_host = w.cnt_dev;
     pp.host_out = host_out ? 1 : 0;
-    ANR_TRY(launch_post(nq, sp, pp, bs));
-    ANR_HIP(hipEventRecord(w.ev_done, bs));
+    pp.stamps = sparse ? w.stamps : nullptr;
+    ANR_TRY(launch_post(nq, sp, pp, ps));
+    ANR_HIP(hipEventRecord(w.ev_done, ps));
     w.in_flight = true;
-    ANR_HIP(hipStreamWaitEvent(user, w.ev_done, 0));
+    if (h->stream_wait) ANR_HIP(hipStreamWaitEvent(user, w.ev_done, 0));
+    w.t_enq1 = host_ns();
     return ANR_OK;
   }
 
@@ -741,7 +866,20 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
   rp.sel_m = w.sel_m;
   rp.exact = w.exact;
   rp.M = M;
-  hipLaunchKernelGGL(k_rescore, dim3((unsigned)ceil_div((int64_t)nq * M, 4)), dim3(256), 0, bs, rp);
+  if (shadow) {
+    // one four-wave workgroup per CU (at least one wave per query), RB rows in flight per wave
+    const unsigned grid = (unsigned)std::max(h->n_cu, (nq + 3) / 4);
+    const bool v4 = (h->dim & 3) == 0;
+    if (h->metric == ANR_METRIC_L2) {
+      if (v4) hipLaunchKernelGGL((k_rescore_shadow<4, true, true>), dim3(grid), dim3(256), 0, ps, rp, nq);
+      else hipLaunchKernelGGL((k_rescore_shadow<3, true, false>), dim3(grid), dim3(256), 0, ps, rp, nq);
+    } else {
+      if (v4) hipLaunchKernelGGL((k_rescore_shadow<4, false, true>), dim3(grid), dim3(256), 0, ps, rp, nq);
+      else hipLaunchKernelGGL((k_rescore_shadow<3, false, false>), dim3(grid), dim3(256), 0, ps, rp, nq);
+    }
+  } else {
+    hipLaunchKernelGGL(k_rescore, dim3((unsigned)ceil_div((int64_t)nq * M, 4)), dim3(256), 0, ps, rp);
+  }
 
   FinalParams fp{};
   fp.exact = w.exact;
@@ -766,11 +904,13 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
   fp.ncand = sparse ? w.ncand : nullptr;
   fp.status_host = w.cnt_dev;
   fp.host_out = host_out ? 1 : 0;
-  hipLaunchKernelGGL(k_finalize, dim3(nq), dim3(256), 0, bs, fp);
+  fp.stamps = sparse ? w.stamps : nullptr;
+  hipLaunchKernelGGL(k_finalize, dim3(nq), dim3(256), 0, ps, fp);
   ANR_HIP(hipGetLastError());
-  ANR_HIP(hipEventRecord(w.ev_done, bs));
+  ANR_HIP(hipEventRecord(w.ev_done, ps));
   w.in_flight = true;
-  ANR_HIP(hipStreamWaitEvent(user, w.ev_done, 0));
+  if (h->stream_wait) ANR_HIP(hipStreamWaitEvent(user, w.ev_done, 0));
+  w.t_enq1 = host_ns();
   return ANR_OK;
 }
 
@@ -1109,14 +1249,14 @@ void free_workspaces(anr_index *h) {
   for (auto &w : h->ws) {
     dev_free(w.q32); dev_free(w.q16); dev_free(w.qstat); dev_free(w.qstage); dev_free(w.dense);
     dev_free(w.ladder); dev_free(w.cntb); dev_free(w.ncand); dev_free(w.cand); dev_free(w.qslots); dev_free(w.lvlmax);
-    dev_free(w.sel_rank); dev_free(w.sel_row); dev_free(w.sel_m); dev_free(w.exact);
+    dev_free(w.sel_rank); dev_free(w.sel_row); dev_free(w.sel_m); dev_free(w.exact); dev_free(w.stamps);
     if (w.cnt_host) (void)hipHostFree(w.cnt_host);
     if (w.qpin) (void)hipHostFree(w.qpin);
     w.cnt_host = w.cnt_dev = nullptr;
     w.qpin = nullptr;
     w.cand_alloc = 0;
     w.dense_ld = 0;
-    for (hipEvent_t *e : {&w.ev_in, &w.ev_done, &w.ev_t0, &w.ev_t1}) {
+    for (hipEvent_t *e : {&w.ev_in, &w.ev_done, &w.ev_t0, &w.ev_t1, &w.ev_pre, &w.ev_scan}) {
       if (*e) (void)hipEventDestroy(*e);
       *e = nullptr;
     }
@@ -1154,6 +1294,10 @@ int anr_index_create(int32_t dim, int32_t metric, int32_t normalize, int32_t dev
   h->normalize = normalize ? 1 : 0;
   h->device = device;
   h->n_cu = device_cu_count(device);
+  {
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) h->clock_khz = khz;
+  }
   hipStream_t *streams[1 + kWorkspaces] = {&h->stream, &h->bstream[0], &h->bstream[1], &h->bstream[2]};
   for (auto s : streams) {
     hipError_t e = hipStreamCreateWithFlags(s, hipStreamNonBlocking);
@@ -1478,6 +1622,51 @@ int anr_index_self_join(anr_index *h, float threshold, int64_t cap, int64_t *I_h
   return ANR_OK;
 }
 
+int anr_index_batch_log(anr_index *h, int64_t *out, int32_t max_batches, int32_t *n_out, int64_t *dev_minus_host_ns) {
+  if (!h || !n_out || (max_batches > 0 && !out)) return fail(ANR_EINVAL, "null argument");
+  DeviceGuard g(h->device);
+  std::lock_guard<std::mutex> lk(h->mu);
+  ANR_TRY(drain(h));
+  const int64_t have = std::min<int64_t>(h->batch_log_n, kBatchLogCap);
+  const int64_t n = std::min<int64_t>(have, std::max(0, max_batches));
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t r = h->batch_log_n - n + i;
+    memcpy(out + i * kBatchLogFields, h->batch_log.data() + (size_t)(r % kBatchLogCap) * kBatchLogFields,
+           kBatchLogFields * sizeof(int64_t));
+  }
+  *n_out = (int32_t)n;
+  if (dev_minus_host_ns) {
+    // correlate the two clocks: a one-thread kernel writes the device clock into pinned memory, the host notes when it
+    // sees it; the tightest of a few round trips (the stamp is taken 1-3 us before the host can observe it)
+    ANR_TRY(ensure_workspaces(h));
+    volatile unsigned long long *pin = reinterpret_cast<volatile unsigned long long *>(h->ws[0].cnt_host + 4 * kQB);
+    unsigned long long *pin_dev = reinterpret_cast<unsigned long long *>(h->ws[0].cnt_dev + 4 * kQB);
+    int64_t best_rt = -1, best_off = 0;
+    for (int rep = 0; rep < 6; ++rep) {
+      const unsigned long long saved = pin[0];
+      pin[0] = 0;
+      const int64_t t0 = host_ns();
+      hipLaunchKernelGGL(k_clock, dim3(1), dim3(1), 0, h->stream, pin_dev);
+      ANR_HIP(hipGetLastError());
+      int64_t t1 = t0;
+      while (pin[0] == 0) {
+        t1 = host_ns();
+        if (t1 - t0 > 2000000000ll) return fail(ANR_EHIP, "clock calibration kernel did not report");
+      }
+      t1 = host_ns();
+      const int64_t dev_ns = (int64_t)((double)pin[0] * 1e6 / (double)h->clock_khz);
+      ANR_HIP(hipStreamSynchronize(h->stream));
+      pin[0] = saved;
+      if (rep > 0 && (best_rt < 0 || t1 - t0 < best_rt)) {
+        best_rt = t1 - t0;
+        best_off = dev_ns - t1;
+      }
+    }
+    *dev_minus_host_ns = best_off;
+  }
+  return ANR_OK;
+}
+
 int anr_index_set_option(anr_index *h, int32_t opt, int64_t value) {
   if (!h) return fail(ANR_EINVAL, "null handle");
   DeviceGuard g(h->device);
@@ -1505,6 +1694,9 @@ int anr_index_set_option(anr_index *h, int32_t opt, int64_t value) {
       break;
     case ANR_OPT_TINY: h->tiny = value < 0 ? 0 : (value > 2 ? 2 : (int)value); break;
     case ANR_OPT_FUSED_POST: h->fused_post = value < 0 ? 0 : (value > 2 ? 2 : (int)value); break;
+    case ANR_OPT_SHADOW: h->shadow = value < 0 ? 0 : (value > 2 ? 2 : (int)value); break;
+    case ANR_OPT_SCHEDULE: h->schedule = value != 0; break;
+    case ANR_OPT_STREAM_WAIT: h->stream_wait = value != 0; break;
     case ANR_OPT_STREAMS:
       if (value < 1 || value > kWorkspaces) return fail(ANR_EINVAL, "streams must be in 1..%d", kWorkspaces);
       h->n_streams = (int)value;

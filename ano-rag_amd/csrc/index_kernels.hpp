@@ -37,6 +37,23 @@ __device__ __forceinline__ unsigned long long make_key(float rank, unsigned row)
   return ((unsigned long long)f2ord(rank) << 32) | (unsigned long long)(0xffffffffu - row);
 }
 
+// Device time stamps of a batch (anr_index_batch_log): u64 words in device memory, one set per workspace, in ticks of the
+// constant 100-MHz clock.  "End" stamps are atomic maxima (the clock is monotone, so a new batch's stamps overwrite the
+// previous batch's without a reset); the scan's start is a minimum over its workgroups and is reset by the kernel before.
+enum { kStampPrepEnd = 0, kStampSampleEnd = 1, kStampLadderEnd = 2, kStampScanStart = 3, kStampScanPlaced = 4, kStampScanEnd = 5,
+       kStampSelEnd = 6, kStampPostEnd = 7, kStamps = 8 };
+__device__ __forceinline__ void stamp_max(unsigned long long *st, int slot) {
+  if (st) atomicMax(st + slot, (unsigned long long)wall_clock64());
+}
+__device__ __forceinline__ void stamp_min(unsigned long long *st, int slot) {
+  if (st) atomicMin(st + slot, (unsigned long long)wall_clock64());
+}
+
+// clock correlation for anr_index_batch_log: the device clock, written where the host is watching
+__global__ void k_clock(unsigned long long *out_pinned) {
+  __hip_atomic_store(out_pinned, (unsigned long long)wall_clock64(), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ------------------------------------------------------------------------------------------------
 // add: normalise (optional), store x32, convert to the blocked f16 image, track norm / error maxima
 // ------------------------------------------------------------------------------------------------
@@ -152,6 +169,7 @@ struct PrepQParams {
   float *q32;        // [64][dimp]
   _Float16 *q16;     // [2][kb][64][8]
   float *qstat;      // [64][4]: ||q||, ||q16||, ||q16 - q||, ||q||^2
+  unsigned long long *stamps;  // optional
 };
 
 __global__ __launch_bounds__(256) void k_prepq(PrepQParams p) {
@@ -210,6 +228,7 @@ __global__ __launch_bounds__(256) void k_prepq(PrepQParams p) {
     p.qstat[q * 4 + 1] = (float)sqrt(b) * 1.0001f;
     p.qstat[q * 4 + 2] = (float)sqrt(c) * 1.0001f;
     p.qstat[q * 4 + 3] = (float)a;
+    stamp_max(p.stamps, kStampPrepEnd);
   }
 }
 
@@ -249,6 +268,7 @@ struct ScanParams {
   uint2 *cand;           // [gridDim.x][64][capb] (rank-score bits, row)
   unsigned capb;
   unsigned kprime;
+  unsigned long long *stamps;  // optional (main scan only)
 };
 
 // STREAM: every byte is read once per batch and the corpus is far larger than the 256-MiB Infinity Cache,
@@ -360,6 +380,10 @@ __global__ __launch_bounds__(NT) ANR_SCAN_ATTR void k_scan(ScanParams p) {
   int *lds_lvl = reinterpret_cast<int *>(lds_cnt + kQB);
   unsigned *lds_pend = reinterpret_cast<unsigned *>(lds_lvl + kQB);
   if (!DENSE) {
+    if (tid == 0 && p.stamps) {
+      stamp_min(p.stamps, kStampScanStart);
+      stamp_max(p.stamps, kStampScanPlaced);
+    }
     for (int i = tid; i < kQB * kLadder; i += nthreads) {
       lad[i] = p.ladder[i];
       lds_pend[i] = 0;
@@ -470,7 +494,90 @@ __global__ __launch_bounds__(NT) ANR_SCAN_ATTR void k_scan(ScanParams p) {
     __syncthreads();
     if (tid < kQB) p.cntb[(int64_t)tid * gridDim.x + blockIdx.x] = lds_cnt[tid];
     if (tid < kQB && p.lvlmax && lds_lvl[tid] > p.lvl0) atomicMax(p.lvlmax + tid, lds_lvl[tid]);
+    if (tid == 0) stamp_max(p.stamps, kStampScanEnd);
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// sample (shadow form of k_scan<DENSE> + groupmax): the threshold sample of batch i + 1 computed BESIDE the resident
+// workgroups of batch i's scan instead of after them.  A scan workgroup leaves a CU 56 vector registers per SIMD, five wave
+// slots per SIMD and 59.5 KiB of LDS in up to two pieces: this kernel's workgroup is 4 waves (one per SIMD) of <= 56
+// registers and <= 28 KiB of LDS.  Workgroup b serves query half b & 1 (32 queries); in a round each of its waves
+// multiplies ONE sampled 32-row tile with those 32 queries, the k range cut into slices of kbs blocks whose B operand
+// (kbs KiB) is staged in LDS one after the other — kb MFMAs per tile in the same k order as the scan, so the accumulators,
+// hence the tile maxima and the ladder, are bit-identical to k_scan<true>'s — and writes the tile's best score per query.
+// ------------------------------------------------------------------------------------------------
+struct SampleParams {
+  const uint4 *x16;
+  const uint4 *q16;
+  int kb, kbs;                   // k-blocks in all and per LDS slice (kb % kbs == 0, kbs % CH == 0, kbs KiB <= 28 KiB)
+  int64_t tile_stride, n_tiles;  // sampled tile i = corpus tile i * tile_stride (all full tiles)
+  const float *rowbias;
+  float *dense;                  // [64][dense_ld]: dense[q][i] = best score of sampled tile i
+  int64_t dense_ld;
+  unsigned long long *stamps;    // optional
+};
+
+// (a plain __device__ function: the builtin written directly inside a __global__ template breaks the host-side instantiation)
+__device__ __forceinline__ void sample_glds16(const uint4 *g, uint4 *l) { __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0); }
+
+template <int CH, bool BIAS>
+__global__ __launch_bounds__(256) void k_sample(SampleParams p) {
+  extern __shared__ uint4 lds[];  // [kbs][64] B operand slice of this workgroup's query half
+  // (wave index as a scalar: tile addresses are scalar base + lane offset, which is what keeps the kernel within 56 registers)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qh = blockIdx.x & 1;
+  const uint4 *qsrc = p.q16 + (int64_t)qh * p.kb * 64;
+  const uint4 *ldsq = lds + lane;
+  const int q0 = lane & 31, half = lane >> 5;
+  const int64_t w0 = (int64_t)(blockIdx.x >> 1) * 4 + wave, wt = (int64_t)(gridDim.x >> 1) * 4;
+  const int64_t rounds = (p.n_tiles - (int64_t)(blockIdx.x >> 1) * 4 + wt - 1) / wt;  // of the workgroup's FIRST wave: all waves keep its barriers
+  for (int64_t r = 0; r < rounds; ++r) {
+    const int64_t i = w0 + r * wt;
+    const bool live = i < p.n_tiles;
+    const int64_t tile = (live ? i : w0) * p.tile_stride;  // a wave without a tile in the last round re-reads its first one
+    const uint4 *xa = p.x16 + tile * p.kb * 64 + lane;
+    floatx16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+    // CH operand registers: each is re-filled with the block CH k-steps ahead as soon as its MFMA has issued
+    uint4 a[CH];
+    scan_load<CH, false>(a, xa, 0);
+    // ONE loop over the k-steps (a nest of slice and step loops doubled the accumulator registers); at a slice boundary
+    // the workgroup swaps the LDS slice
+    for (int kc = 0, c = p.kbs; kc < p.kb; kc += CH, c += CH) {
+      if (c == p.kbs) {
+        c = 0;
+        __syncthreads();  // the previous slice (or round) has been consumed
+        // global -> LDS copies that bypass the registers (a wave's 64 x 16 B land lane-linear at the uniform LDS address)
+        for (int blk = wave; blk < p.kbs; blk += 4) sample_glds16(qsrc + ((int64_t)kc + blk) * 64 + lane, lds + blk * 64);
+        __syncthreads();
+      }
+      const int kn = kc + CH < p.kb ? kc + CH : p.kb - CH;  // past the end: re-request the last blocks (an L2 hit)
+      const uint4 *nx = xa + (int64_t)kn * 64;
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const uint4 b = ldsq[(c + j) * 64];
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a[j]), __builtin_bit_cast(half8, b), acc, 0, 0, 0);
+        a[j] = nx[j * 64];
+      }
+    }
+    if (BIAS) {  // L2 metric: rank = q.x - 0.5 ||x||^2
+      const float *rb = p.rowbias + tile * kTileRows + 4 * half;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 bb = *reinterpret_cast<const float4 *>(rb + 8 * g);
+        acc[4 * g + 0] += bb.x; acc[4 * g + 1] += bb.y; acc[4 * g + 2] += bb.z; acc[4 * g + 3] += bb.w;
+        asm volatile("" ::: "memory");  // one group at a time (register budget)
+      }
+    }
+    float m = acc[0];
+#pragma unroll
+    for (int e = 1; e < 16; ++e) m = fmaxf(m, acc[e]);
+    m = fmaxf(m, __shfl_xor(m, 32));
+    if (live && half == 0) p.dense[(int64_t)(q0 + 32 * qh) * p.dense_ld + i] = m;
+  }
+  if (tid == 0) stamp_max(p.stamps, kStampSampleEnd);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -504,24 +611,39 @@ struct SelParams {
   const int *qslots;     // optional: block b handles query slot qslots[b]
   int *lvl_init;         // optional (ladder mode): lvl_init[q] = lvl_init_value, the scan's start level
   int lvl_init_value;
+  unsigned long long *stamps;  // optional: ladder mode stamps kStampLadderEnd (and resets the scan's start), else kStampSelEnd
   int live_q;            // ladder mode, > 0: query slots >= live_q carry no query — their ladder is +inf, so the scan
                          // never emits for them (a zero query would otherwise pass its own all-zero thresholds on
                          // every row of every tile)
 };
 
-struct SelShared {
-  unsigned long long keys[kSelLds];
-  unsigned long long sel[kMaxSel];
-  unsigned long long srt[kMaxSel];
+// KEYS = keys a workgroup can stage in LDS, NSEL = entries it can return, NLISTS = candidate lists it can read.  Two sizes:
+// the wide kernels (1024 threads, 150 KiB: a CU to themselves) and the "shadow" kernels (256 threads, <= 56 vector
+// registers, 26 KiB) that are placed on a CU BESIDE a resident scan workgroup — which leaves 56 registers per SIMD and
+// 59.5 KiB of LDS, the latter possibly in TWO pieces (the scan workgroup sits wherever the side workgroups resident at
+// ITS placement left room), so that only a request of <= 29 KiB is certain to fit: with 53 KiB the select waited for the
+// scan to end in half of the batches (r4 notes in DESIGN.md §4).
+template <int KEYS, int NSEL, int NLISTS>
+struct SelSharedT {
+  static constexpr int kKeys = KEYS, kSel = NSEL, kLists = NLISTS;
+  unsigned long long keys[KEYS];
+  unsigned long long sel[NSEL];
+  unsigned long long srt[NSEL];
   unsigned long long red[16][2];
-  unsigned offs[kSelMaxLists + 1];
+  unsigned offs[NLISTS + 1];
   unsigned hist[256];
   unsigned cnt;
   int d;
   unsigned above, h, ovf;
 };
+typedef SelSharedT<kSelLds, kMaxSel, kSelMaxLists> SelShared;
+constexpr int kShadowKeys = 2048, kShadowSel = 512, kShadowLists = 256;
+typedef SelSharedT<kShadowKeys, kShadowSel, kShadowLists> SelSharedShadow;
+constexpr int kShadowLds = 29 * 1024;  // what a shadow kernel may ask for
+static_assert(sizeof(SelSharedShadow) <= kShadowLds, "the shadow select must fit into either piece of the LDS a scan workgroup leaves");
 
-__device__ __forceinline__ unsigned long long sel_key(const SelParams &p, const SelShared &sh, int q, int64_t i,
+template <class SH>
+__device__ __forceinline__ unsigned long long sel_key(const SelParams &p, const SH &sh, int q, int64_t i,
                                                       bool staged, int koff = 0) {
   if (staged) return sh.keys[koff + i];
   if (p.dense) {
@@ -543,7 +665,8 @@ __device__ __forceinline__ unsigned long long sel_key(const SelParams &p, const 
 
 // The selection itself: leaves the M best keys, ordered best first, in sh.srt[0, M) and returns M (the same value in
 // every thread; 0 when the query has no entry).  All threads of the workgroup call it.
-__device__ __forceinline__ int sel_run(const SelParams &p, SelShared &sh, const int q) {
+template <class SH>
+__device__ __forceinline__ int sel_run(const SelParams &p, SH &sh, const int q) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int NT = blockDim.x, NW = NT >> 6;
   int64_t n;
@@ -586,7 +709,7 @@ __device__ __forceinline__ int sel_run(const SelParams &p, SelShared &sh, const 
   }
   int M = (int)((int64_t)p.M < n ? (int64_t)p.M : n);
   if (M == 0) return 0;
-  const bool staged = n <= kSelLds;
+  const bool staged = n <= SH::kKeys;
   if (tid == 0) sh.cnt = 0;
   __syncthreads();
   // stage the keys in LDS (when they fit) and find the common leading bytes of all keys on the way -> those
@@ -640,7 +763,7 @@ __device__ __forceinline__ int sel_run(const SelParams &p, SelShared &sh, const 
     kmin = sh.red[w][0] < kmin ? sh.red[w][0] : kmin;
     kmax = sh.red[w][1] > kmax ? sh.red[w][1] : kmax;
   }
-  if (staged && n > 256 && n <= kSelLds / 2) {
+  if (staged && n > 256 && n <= SH::kKeys / 2) {
     // shrink the ranking problem: 256 linear score bins between the smallest and largest staged score, keep the
     // keys from the top bins that together hold >= M keys (typically M plus a few dozen)
     const float smin = ord2f((unsigned)(kmin >> 32)), smax = ord2f((unsigned)(kmax >> 32));
@@ -681,14 +804,14 @@ __device__ __forceinline__ int sel_run(const SelParams &p, SelShared &sh, const 
       const float sc = ord2f((unsigned)(k >> 32));
       int bin = (int)((sc - smin) * scale);
       bin = bin < 0 ? 0 : (bin > 255 ? 255 : bin);
-      if (bin >= cut) sh.keys[kSelLds / 2 + atomicAdd(&sh.cnt, 1u)] = k;
+      if (bin >= cut) sh.keys[SH::kKeys / 2 + atomicAdd(&sh.cnt, 1u)] = k;
     }
     __syncthreads();
     n = sh.cnt;
-    koff = kSelLds / 2;
+    koff = SH::kKeys / 2;
     __syncthreads();
   }
-  if (staged && n <= kMaxSel) {
+  if (staged && n <= SH::kSel) {
     // small input: rank every key directly (distinct keys), n*n/NT compares per thread
     for (int i = tid; i < (int)n; i += NT) {
       const unsigned long long kk = sh.keys[koff + i];
@@ -751,7 +874,7 @@ __device__ __forceinline__ int sel_run(const SelParams &p, SelShared &sh, const 
     const unsigned long long k = sel_key(p, sh, q, i, staged, koff);
     if (bits == 0 || (k >> (64 - bits)) >= prefix) {
       const unsigned pos = atomicAdd(&sh.cnt, 1u);
-      if (pos < (unsigned)kMaxSel) sh.sel[pos] = k;
+      if (pos < (unsigned)SH::kSel) sh.sel[pos] = k;
     }
   }
   __syncthreads();
@@ -769,7 +892,8 @@ __device__ __forceinline__ int sel_run(const SelParams &p, SelShared &sh, const 
 }
 
 // write a selection out: (rank value, row) pairs, their count, and (ladder mode) the threshold ladder
-__device__ __forceinline__ void sel_write(const SelParams &p, const SelShared &sh, const int q, const int M) {
+template <class SH>
+__device__ __forceinline__ void sel_write(const SelParams &p, const SH &sh, const int q, const int M) {
   const int tid = threadIdx.x, NT = blockDim.x;
   if (tid == 0) p.out_m[q] = M;
   for (int i = tid; i < M; i += NT) {
@@ -791,9 +915,8 @@ __device__ __forceinline__ void sel_write(const SelParams &p, const SelShared &s
   }
 }
 
-__global__ __launch_bounds__(1024) void k_select(SelParams p) {
-  extern __shared__ unsigned char sel_smem[];
-  SelShared &sh = *reinterpret_cast<SelShared *>(sel_smem);
+template <class SH>
+__device__ __forceinline__ void select_body(const SelParams &p, SH &sh) {
   const int tid = threadIdx.x;
   const int q = p.qslots ? p.qslots[blockIdx.x] : blockIdx.x;
   if (p.ladder && p.live_q > 0 && q >= p.live_q) {
@@ -804,6 +927,23 @@ __global__ __launch_bounds__(1024) void k_select(SelParams p) {
   }
   const int M = sel_run(p, sh, q);
   sel_write(p, sh, q, M);
+  if (tid == 0 && p.stamps) {
+    if (p.ladder && blockIdx.x == 0) p.stamps[kStampScanStart] = ~0ull;  // the scan that follows takes the minimum
+    stamp_max(p.stamps, p.ladder ? kStampLadderEnd : kStampSelEnd);
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_select(SelParams p) {
+  extern __shared__ unsigned char sel_smem[];
+  select_body(p, *reinterpret_cast<SelShared *>(sel_smem));
+}
+
+// the same selection sized to run in the shadow of a resident scan (DESIGN.md §4 "shadow kernels"): 4 waves, <= 56
+// registers, 26 KiB; M <= 512 entries out of <= 256 lists (the host checks); more than 2048 entries are ranked from global
+// memory (the radix passes re-read them)
+__global__ __launch_bounds__(256) void k_select_shadow(SelParams p) {
+  extern __shared__ unsigned char sel_smem[];
+  select_body(p, *reinterpret_cast<SelSharedShadow *>(sel_smem));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -831,7 +971,16 @@ struct PostParams {
   int64_t id_offset;
   unsigned *status_host;
   int host_out;
+  unsigned long long *stamps;  // optional; copied to status_host[4 * 64 ...] by query 0's workgroup
 };
+
+// the batch's stamps travel to the host in the status block (rows 4 and 5: kStamps u64 words)
+__device__ __forceinline__ void stamps_to_host(unsigned long long *stamps, unsigned *status_host) {
+  if (!stamps || !status_host) return;
+  stamp_max(stamps, kStampPostEnd);
+  unsigned long long *dst = reinterpret_cast<unsigned long long *>(status_host + 4 * kQB);
+  for (int i = 0; i < kStamps; ++i) dst[i] = __hip_atomic_load(stamps + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 __global__ __launch_bounds__(1024) void k_post(SelParams p, PostParams pp) {
   extern __shared__ unsigned char sel_smem[];
@@ -954,6 +1103,7 @@ __global__ __launch_bounds__(1024) void k_post(SelParams p, PostParams pp) {
       pp.status_host[kQB + q] = ovf ? 1u : 0u;
       pp.status_host[2 * kQB + q] = (unsigned)flag;
       pp.status_host[3 * kQB + q] = __float_as_uint(theta);
+      if (q == 0) stamps_to_host(pp.stamps, pp.status_host);
       __threadfence_system();
     }
   }
@@ -1016,6 +1166,77 @@ __global__ __launch_bounds__(256) void k_rescore(RescoreParams p) {
   }
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
   if (lane == 0) p.exact[q * kMaxSel + j] = (float)acc;
+}
+
+// rescore, shadow form: the same values (one wave per (query, candidate), a row's products added in the same order), but as
+// ONE workgroup of 4 waves per CU: the waves are dealt to the queries (W / nq waves each) and a wave walks its share of the
+// query's candidates with RB rows in flight — 3072 four-wave workgroups placed one at a time beside a resident scan took
+// 12 placement rounds (~120 us in the shadow of a 1.25 M-row scan)
+template <int RB, bool L2, bool VEC4>
+__global__ __launch_bounds__(256) void k_rescore_shadow(RescoreParams p, int nq) {
+  const int lane = threadIdx.x & 63;
+  // the wave index as a scalar: query, candidate slots and row addresses then live in scalar registers
+  const int w = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), W = gridDim.x * 4;
+  const int per_q = W / nq;  // the host launches at least nq waves
+  const int q = w % nq, slot = w / nq;
+  if (slot >= per_q) return;
+  const int m = p.sel_m[q];
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const float *qv = p.q32 + (int64_t)q * p.dimp;
+  for (int j0 = slot; j0 < m; j0 += per_q * RB) {
+    unsigned row[RB];
+    double acc[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const int j = j0 + r * per_q < m ? j0 + r * per_q : j0;
+      row[r] = p.sel_row[q * kMaxSel + j];
+      acc[r] = 0.0;
+    }
+    if (VEC4) {  // dim % 4 == 0
+      const int n4 = p.dim >> 2;
+#pragma unroll 1
+      for (int k = lane; k < n4; k += 64) {
+        const f32x4 b = reinterpret_cast<const f32x4 *>(qv)[k];
+        f32x4 a[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+          a[r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p.x32 + (int64_t)row[r] * p.dim) + k);
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+          if (!L2) {
+            acc[r] += (double)a[r].x * (double)b.x;
+            acc[r] += (double)a[r].y * (double)b.y;
+            acc[r] += (double)a[r].z * (double)b.z;
+            acc[r] += (double)a[r].w * (double)b.w;
+          } else {
+            const double d0 = (double)b.x - (double)a[r].x, d1 = (double)b.y - (double)a[r].y;
+            const double d2 = (double)b.z - (double)a[r].z, d3 = (double)b.w - (double)a[r].w;
+            acc[r] += d0 * d0;
+            acc[r] += d1 * d1;
+            acc[r] += d2 * d2;
+            acc[r] += d3 * d3;
+          }
+          asm volatile("" ::: "memory");  // one row's float64 temporaries at a time: the kernel must stay within 56 registers
+        }
+      }
+    } else {
+#pragma unroll 1
+      for (int k = lane; k < p.dim; k += 64) {
+        const double b = (double)qv[k];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+          const double a = (double)p.x32[(int64_t)row[r] * p.dim + k];
+          if (!L2) acc[r] += a * b;
+          else acc[r] += (b - a) * (b - a);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      for (int off = 32; off > 0; off >>= 1) acc[r] += __shfl_xor(acc[r], off);
+      if (lane == 0 && j0 + r * per_q < m) p.exact[q * kMaxSel + j0 + r * per_q] = (float)acc[r];
+    }
+  }
 }
 
 // score_rows: exact value of given (query, row) pairs — the gather(note_embeddings, ids) . q the reference
@@ -1149,8 +1370,9 @@ struct FinalParams {
   float *theta;              // [64] scan-score threshold of the second pass: rank(k-th exact) - eps
   int64_t id_offset;
   const unsigned *ncand;     // may be null: [64] candidates seen (statistics)
-  unsigned *status_host;     // pinned host memory [4][64]: candidates | overflow | flag | theta bits
+  unsigned *status_host;     // pinned host memory [6][64]: candidates | overflow | flag | theta bits | time stamps (2 rows)
   int host_out;              // D / I are pinned host memory: fence the writes at system scope
+  unsigned long long *stamps;  // optional
 };
 
 __global__ __launch_bounds__(256) void k_finalize(FinalParams p) {
@@ -1215,6 +1437,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinalParams p) {
       p.status_host[kQB + q] = p.overflow ? p.overflow[q] : 0u;
       p.status_host[2 * kQB + q] = (unsigned)flag;
       p.status_host[3 * kQB + q] = __float_as_uint(theta);
+      if (q == 0) stamps_to_host(p.stamps, p.status_host);
       __threadfence_system();
     }
   }

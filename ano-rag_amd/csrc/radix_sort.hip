@@ -19,7 +19,8 @@ namespace anr {
 constexpr int kRsThreads = 256, kRsRounds = 16, kRsTile = kRsThreads * kRsRounds;
 
 __device__ __forceinline__ unsigned rs_f2ord(float v) {
-  const unsigned u = __float_as_uint(v);
+  unsigned u = __float_as_uint(v);
+  if ((u << 1) == 0u) u = 0u;  // -0.0 and +0.0 compare equal: one key, so that their ids decide
   return (u >> 31) ? ~u : (u | 0x80000000u);
 }
 __device__ __forceinline__ float rs_ord2f(unsigned o) { return __uint_as_float((o >> 31) ? (o & 0x7fffffffu) : ~o); }

@@ -77,12 +77,14 @@ int anr_index_search_devq(anr_index *h, const float *q_dev, int64_t nq, int32_t 
 int anr_index_search_dev(anr_index *h, const float *q_dev, int64_t nq, int32_t k, float *D_dev,
                          int64_t *I_dev, void *stream);
 
-/* Asynchronous form: enqueues the search and returns; results are complete for work enqueued on `stream`
- * after the call (the stream is made to wait on them).  Up to three batches are in flight (rotating
- * workspaces), so successive calls queue back to back on the device with no host synchronisation in between.
- * D_dev / I_dev of calls still in flight must be distinct buffers.  anr_index_sync()
- * waits for everything enqueued, runs the exact path for the queries whose certificate failed (patching
- * D_dev / I_dev) and folds the statistics: results are FINAL only after it returns. */
+/* Asynchronous form: enqueues the search and returns.  Up to three batches are in flight (rotating workspaces), so
+ * successive calls queue back to back on the device with no host synchronisation in between; `stream` is the stream the
+ * queries were produced on (the batch waits for it when it is busy).  D_dev / I_dev of calls still in flight must be
+ * distinct buffers.  Results may be READ only after anr_index_wait() / anr_index_sync() have retired the batch: retiring
+ * waits for it, runs the exact path for the queries whose certificate failed (patching D_dev / I_dev) and folds the
+ * statistics.  (Until round 4 every call also made `stream` wait for the batch — ANR_OPT_STREAM_WAIT 1 restores that; the
+ * marker ordered nothing that the retire does not, and in the device's four shared hardware queues it sat in front of the
+ * NEXT batches' kernels: 0.348 -> 0.314 ms per batch at the 8-GPU shard size without it.) */
 int anr_index_search_dev_async(anr_index *h, const float *q_dev, int64_t nq, int32_t k, float *D_dev,
                                int64_t *I_dev, void *stream);
 int anr_index_sync(anr_index *h);
@@ -137,6 +139,20 @@ int anr_index_self_join(anr_index *h, float threshold, int64_t cap, int64_t *I_h
                                      launches (identical results) */
 int anr_index_set_option(anr_index *h, int32_t opt, int64_t value);
 
+#define ANR_OPT_SHADOW 11         /* 0 (default): off; 1: a batch enqueued while another is still in flight (a pipelined caller) uses the
+                                     "shadow" forms of its side kernels — threshold sample, ladder select, candidate select,
+                                     re-score, finalize as workgroups of 4 waves, <= 56 registers, <= 58 KiB LDS, which are placed
+                                     BESIDE the resident workgroups of the previous batch's scan instead of waiting for them
+                                     (identical results); 2: every batch.  Measured slower than the wide kernels (a wave beside the
+                                     scan waits ~8 us per memory round trip behind the scan's own requests): kept as an option */
+
+#define ANR_OPT_SCHEDULE 12       /* 0 (default): one stream per in-flight batch (ANR_OPT_STREAMS of them); 1: role streams — all query
+                                     preparations / threshold samples on one stream, all main scans on a second (strictly one after
+                                     the other, in submission order), all select / re-score / finalize kernels on a third, two events
+                                     per batch (measured 5 % slower at the 8-GPU shard size) */
+#define ANR_OPT_STREAM_WAIT 13    /* 0 (default): results are read after anr_index_wait / anr_index_sync; 1: anr_index_search_dev_async
+                                     also makes the caller's stream wait for the batch (the behaviour up to round 3) */
+
 typedef struct anr_search_stats {
   int64_t n_queries;        /* queries of the last search call                                        */
   int64_t n_fallback;       /* of those, whose certificate failed (answered from the lists / by a second scan) */
@@ -154,6 +170,20 @@ typedef struct anr_search_stats {
  * anr_index_reset_stats() */
 int anr_index_last_stats(anr_index *h, anr_search_stats *out);
 int anr_index_reset_stats(anr_index *h);
+
+/* Time line of the most recent batches of the scan pipeline (diagnostics; the reference has no counterpart — it is what
+ * bench.py prints to explain a slow batch).  Retires every batch in flight, then copies up to max_batches records, oldest
+ * first, ANR_BATCH_LOG_FIELDS int64 words each:
+ *   [0] batch sequence number   [1] host clock (ns, monotonic) when its enqueue began   [2] when the enqueue returned
+ *   [3] host clock when it was retired
+ *   device clock (ns) at: [4] end of the query preparation  [5] end of the threshold sample  [6] end of the ladder select
+ *   [7] first / [8] last workgroup of the main scan started  [9] end of the main scan  [10] end of the candidate select
+ *   [11] end of the batch's last kernel
+ *   [12] bit 0: shadow-sized side kernels; bits 8..: queries in the batch
+ * (fused post kernel: [10] is 0).  *dev_minus_host_ns (may be NULL) receives an estimate of device clock - host clock,
+ * good to a few microseconds, so that the two sets of times can be laid on one axis. */
+#define ANR_BATCH_LOG_FIELDS 13
+int anr_index_batch_log(anr_index *h, int64_t *out, int32_t max_batches, int32_t *n_out, int64_t *dev_minus_host_ns);
 
 /* In-place row normalisation on host memory through the device (vector_index.py:276-280): rows with
  * zero norm are left unchanged. */

@@ -269,8 +269,38 @@ def test_sparse_producer_and_consumer_refuse_what_they_cannot_hold():
     assert rows is None
     rows = dev.scores_sparse_device(toks, cap=4, allow_overflow=True)
     assert rows.counts.tolist() == [-1]
+    # ... and an overflow-marked row handed STRAIGHT to the fusion is refused, not fused as "every BM25 score
+    # is 0.0": by the Python check when the counts are on the host, by the device's error word when they are not
+    w0 = {"dense": 1.0, "bm25": 0.5, "graph": 0.5, "path": 0.1}
+    dl = [(np.array([1, 2, 3], dtype=np.int64), np.array([0.9, 0.8, 0.7]))]
+    with pytest.raises(ValueError):
+        fuse_dense("linear", w0, 60.0, 5, 1, {"dense": dl, "bm25": rows})
+    from retrieval.hybrid_search import HybridSearcher
+    hs0 = HybridSearcher({"retrieval": {"candidate_pool": 5, "hybrid": {"enabled": True, "fusion_method": "linear", "weights": w0}}})
+    with pytest.raises((ValueError, _lib.AnoragError)):
+        hs0.fuse_arrays(1, dense=dl, bm25=rows)
+    wrapped = SparseRows.wrap(rows.ids_ptr, rows.scores_ptr, rows.count_ptr, 1, rows.n, rows.cap, rows.device)  # counts unknown here
+    for method in ("linear", "rrf"):
+        with pytest.raises(_lib.AnoragError, match="count < 0"):
+            fuse_dense(method, w0, 60.0, 5, 1, {"dense": dl, "bm25": wrapped})
     rows.free()
     dev.close()
+    # ids outside the array, ids listed twice, a count beyond the capacity
+    for bad, what in (((np.array([5, 100]), np.array([1.0, 2.0])), "array_len"), ((np.array([7, 3, 7]), np.array([1.0, 2.0, 3.0])), "twice")):
+        r = SparseRows.from_numpy([bad], 50)
+        with pytest.raises(_lib.AnoragError, match=what):
+            fuse_dense("linear", w0, 60.0, 5, 1, {"dense": dl, "bm25": r})
+        r.free()
+    r = SparseRows.from_numpy([(np.array([1, 2]), np.array([1.0, 2.0]))], 50, cap=4)
+    cnt = np.array([9], dtype=np.int32)
+    _lib.check(_lib.load().anr_device_copy(0, r.count_ptr, cnt.ctypes.data, 4, 0), "anr_device_copy")
+    r.counts = None
+    with pytest.raises(_lib.AnoragError, match="capacity"):
+        fuse_dense("rrf", w0, 60.0, 5, 1, {"dense": dl, "bm25": r})
+    r.free()
+    ok = SparseRows.from_numpy([(np.array([7, 3]), np.array([1.0, 2.0]))], 50)   # a well-formed row still fuses
+    assert fuse_dense("linear", w0, 60.0, 5, 1, {"dense": dl, "bm25": ok})[3][0] == 5
+    ok.free()
     w = {"dense": 1.0, "bm25": 0.5, "graph": 0.5, "path": 0.1}
     big = SparseRows(1, 100_000, 8193)             # beyond the fusion's 8192 entries per row
     with pytest.raises(_lib.AnoragError):

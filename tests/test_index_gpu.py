@@ -578,3 +578,47 @@ def test_fused_post_kernel_equals_the_three_launch_pipeline():
         for key in ("n_fallback", "n_candidates", "n_from_lists", "n_dense_exact"):
             assert res[0][2][key] == res[1][2][key], (key, res[0][2], res[1][2])
     assert res[0][2]["n_fallback"] > 0     # the clustered case exercised the failed-certificate hand-off
+
+
+def test_shadow_side_kernels_and_role_streams_equal_the_wide_pipeline():
+    """The shadow-sized side kernels (k_sample, k_select_shadow, k_rescore_shadow + k_finalize: what a pipelined caller's
+    batches use so that they run BESIDE the previous batch's resident scan) and the role-stream schedule against the wide
+    kernels on one stream per batch: identical bits and identical statistics — IP at 768-d, a dimension that is not a
+    multiple of four, L2 (row bias in the sample), a partial batch, and tight clusters whose certificates fail."""
+    from anorag_hip import FlatIndex, METRIC_IP, METRIC_L2
+    from anorag_hip._lib import OPT_SHADOW, OPT_SCHEDULE, OPT_TINY, OPT_FUSED_POST
+    rng = np.random.default_rng(5)
+    cent = rng.standard_normal((300, 256)).astype(np.float32)
+    cl = (cent[rng.integers(0, 300, 260_000)] + 0.02 * rng.standard_normal((260_000, 256))).astype(np.float32)
+    clq = (cent[rng.integers(0, 300, 64)] + 0.02 * rng.standard_normal((64, 256))).astype(np.float32)
+    cases = [(_data(300_000, 768, 128), METRIC_IP, True, 100), (_data(280_000, 102, 70), METRIC_IP, True, 10),
+             (_data(270_000, 384, 64), METRIC_L2, False, 50), (_data(260_000, 130, 5), METRIC_L2, False, 20),
+             ((cl, clq), METRIC_IP, True, 50)]
+    for (x, q), metric, norm, k in cases:
+        res = []
+        for shadow, schedule, fused in ((0, 0, 0), (2, 1, 0), (2, 0, 1), (0, 1, 2)):
+            idx = FlatIndex(x.shape[1], metric, normalize=norm)
+            idx.set_option(OPT_TINY, 0)
+            idx.set_option(OPT_SHADOW, shadow)
+            idx.set_option(OPT_SCHEDULE, schedule)
+            idx.set_option(OPT_FUSED_POST, fused)
+            idx.add(x)
+            D, I = idx.search(q, k)
+            st = idx.last_stats()
+            assert st["sample_rows"] > 0, "the case must take the threshold-gated scan"
+            rec, _ = idx.batch_log(8, correlate=False)
+            assert rec.shape[0] >= 1 and bool(rec[-1, 12] & 1) == (shadow == 2)
+            res.append((D, I, st))
+            idx.close()
+        for other in res[1:]:
+            assert np.array_equal(res[0][1], other[1]) and np.array_equal(res[0][0], other[0])
+            for key in ("n_fallback", "n_candidates", "n_from_lists", "n_dense_exact", "overfetch"):
+                assert res[0][2][key] == other[2][key], (key, res[0][2], other[2])
+    assert res[0][2]["n_fallback"] > 0     # the clustered case exercised the failed-certificate hand-off
+    # and the results are the oracle's
+    x, q = _data(300_000, 768, 16)
+    idx = FlatIndex(768, METRIC_IP, normalize=True)
+    idx.set_option(OPT_SHADOW, 2)
+    idx.add(x)
+    _check(idx, x, q, 100, "ip", True)
+    idx.close()

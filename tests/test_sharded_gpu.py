@@ -271,6 +271,29 @@ def test_sharded_searcher_device_path_under_an_nccl_group_of_one():
                 s64 = orc.exact_scores(qn, xn, "ip")
                 assert orc.near_tie_equal(got[b][1] - off, Ir, s64, k, 1e-6), (B, k, b)
                 assert np.max(np.abs(got[b][0] - Dr)) <= SCORE_TOL
+        # queries PRODUCED by un-synchronised work on the caller's stream: a long matrix product sits in front of
+        # the copy that fills q, submit() is called right away — the search must wait for the producer, not read the zeros
+        stream = srch.stream(64, 10, lag=2, group=2)
+        qs = np.random.default_rng(77).standard_normal((6, 64, d), dtype=np.float32)
+        src = torch.from_numpy(qs).cuda()
+        big = torch.randn((6144, 6144), device="cuda")
+        torch.cuda.synchronize()
+        got = {}
+        for b in range(6):
+            qd = torch.zeros((64, d), device="cuda")
+            for _ in range(3):
+                big = (big @ big) * 1e-4      # milliseconds of work in front of ...
+            qd.copy_(src[b])                   # ... the kernel that writes the queries
+            for tag, Dt, It in stream.submit(qd, tag=b):
+                got[tag] = (Dt.cpu().numpy(), It.cpu().numpy())
+            del qd                            # the allocator may hand the block out again: record_stream keeps it safe
+        idx.sync()
+        for tag, Dt, It in stream.flush():
+            got[tag] = (Dt.cpu().numpy(), It.cpu().numpy())
+        for b in range(6):
+            qn = orc.preprocess_vectors(qs[b])
+            Dr, Ir = orc.flat_search(qn, xn, 10, "ip")
+            assert orc.near_tie_equal(got[b][1] - off, Ir, orc.exact_scores(qn, xn, "ip"), 10, 1e-6), b
         idx.close()
     finally:
         dist.destroy_process_group()
