@@ -342,6 +342,13 @@ class HybridSearcher:
             if 2 * len(heavy) > nq:  # mostly frequent-word queries: one pass down the N-vector path for all of them
                 heavy, results = list(range(nq)), [None] * nq
             else:
+                if heavy:
+                    # the overflow-marked rows are answered below from their N-vectors; here they are fused as EMPTY rows
+                    # (the fusion refuses a count of -1 — it would otherwise read "every BM25 score is 0.0" silently)
+                    rows.counts = np.maximum(rows.counts, 0).astype(np.int32)
+                    _lib.check(_lib.load().anr_device_copy(rows.device, C.c_void_p(rows.count_ptr),
+                                                           rows.counts.ctypes.data_as(C.c_void_p), rows.counts.nbytes, 0),
+                               "anr_device_copy")
                 results = self.fuse_arrays(nq, dense=dense, bm25=rows, graph=graph, path=path, note_ids=note_ids)
         finally:
             rows.free()

@@ -300,13 +300,19 @@ class EmbeddingManager:
 
     # -- similarity helpers (embedding_manager.py:586-660) through the device index ---------------------
     def compute_similarity(self, embeddings1: np.ndarray, embeddings2: np.ndarray, metric: str = "cosine") -> np.ndarray:
+        """reference embedding_manager.py:586-629 (pinned by tests/golden/similarity_cases.json, a reference-run fixture): cosine
+        x / (||x|| + 1e-8) with 1-D inputs promoted to one row; euclidean 1 / (1 + cdist) — float64 whatever the inputs, and
+        cdist REFUSES 1-D inputs (the reference then returns its empty-array sentinel); dot = np.dot(a, b.T), whose result
+        loses the axis of a 1-D operand; an unknown metric or mismatched widths -> the sentinel"""
         if embeddings1.size == 0 or embeddings2.size == 0:
             return np.array([])
         try:
-            a = embeddings1.reshape(1, -1) if embeddings1.ndim == 1 else embeddings1
-            b = embeddings2.reshape(1, -1) if embeddings2.ndim == 1 else embeddings2
             if metric not in ("cosine", "dot", "euclidean"):
                 raise ValueError(f"unsupported similarity metric: {metric}")
+            if metric == "euclidean" and (embeddings1.ndim != 2 or embeddings2.ndim != 2):
+                raise ValueError("XA and XB must be 2-dimensional arrays")  # scipy.spatial.distance.cdist's own check
+            a = embeddings1.reshape(1, -1) if embeddings1.ndim == 1 else embeddings1
+            b = embeddings2.reshape(1, -1) if embeddings2.ndim == 1 else embeddings2
             import ctypes as C
             from anorag_hip import _lib
             # one tiled kernel (anr_similarity_matrix): the cosine normalisation x / (||x|| + 1e-8), the products
@@ -322,42 +328,31 @@ class EmbeddingManager:
                                                          sim.ctypes.data_as(C.c_void_p)), "anr_similarity_matrix")
             if metric == "euclidean":
                 return sim  # scipy's cdist returns float64 whatever the inputs are (:613-616)
-            return sim.astype(np.result_type(embeddings1.dtype, embeddings2.dtype), copy=False)
+            sim = sim.astype(np.result_type(embeddings1.dtype, embeddings2.dtype), copy=False)
+            if metric == "dot":  # np.dot(a, b.T): a 1-D operand's axis is not in the result
+                if embeddings1.ndim == 1 and embeddings2.ndim == 1:
+                    return sim.reshape(())[()]
+                if embeddings1.ndim == 1 or embeddings2.ndim == 1:
+                    return sim.reshape(-1)
+            return sim
         except Exception as e:
             logger.error(f"Similarity computation failed: {e}")
             return np.array([])
 
     def find_most_similar(self, query_embedding: np.ndarray, candidate_embeddings: np.ndarray, top_k: int = 10,
                           metric: str = "cosine") -> List[Dict[str, Any]]:
+        """reference embedding_manager.py:631-660: the similarities of the one query (the device kernel above), then the
+        reference's OWN ordering call — np.argsort(similarities)[::-1][:top_k] — so that equal similarities come out in the
+        order numpy gives the reference (the exact-scan index orders ties by ascending id, numpy's reversed ascending sort
+        the other way round)"""
         if query_embedding.size == 0 or candidate_embeddings.size == 0:
             return []
-        try:
-            from anorag_hip import METRIC_IP, METRIC_L2, FlatIndex
-            q = query_embedding.reshape(1, -1)
-            c = candidate_embeddings.reshape(1, -1) if candidate_embeddings.ndim == 1 else candidate_embeddings
-            if metric not in ("cosine", "dot", "euclidean"):
-                raise ValueError(f"unsupported similarity metric: {metric}")
-            if metric == "cosine":
-                q = q / (np.linalg.norm(q, axis=1, keepdims=True) + 1e-8)
-                c = c / (np.linalg.norm(c, axis=1, keepdims=True) + 1e-8)
-            idx = FlatIndex(c.shape[1], METRIC_L2 if metric == "euclidean" else METRIC_IP, normalize=False,
-                            device=self.hip_device)
-            try:
-                idx.add(c)
-                k = min(int(top_k), c.shape[0])
-                D, I = idx.search(q, k)
-            finally:
-                idx.close()
-            out = []
-            for s, i in zip(D[0], I[0]):
-                if i < 0:
-                    continue
-                s = float(s)
-                out.append({"index": int(i), "similarity": 1.0 / (1.0 + s ** 0.5) if metric == "euclidean" else s})
-            return out
-        except Exception as e:
-            logger.error(f"find_most_similar failed: {e}")
+        similarities = self.compute_similarity(query_embedding.reshape(1, -1), candidate_embeddings, metric=metric)
+        if similarities.size == 0:
             return []
+        similarities = similarities.flatten()
+        top = np.argsort(similarities)[::-1][:top_k]
+        return [{"index": int(i), "similarity": float(similarities[i])} for i in top]
 
     # -- metadata --------------------------------------------------------------------------------------
     def get_model_info(self) -> Dict[str, Any]:

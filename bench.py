@@ -24,8 +24,10 @@ ms_per_step).  `cpu_baseline` is the oracle (numpy sgemm + argpartition restatem
 faiss-flat path) timed on this box's host cores on a bounded row sample and scaled linearly to the full corpus.
 The interpreter's cyclic garbage collector is switched off once the corpus is built (as `timeit` does).
 `legs` (N = 1 only, untimed extras, never `value`): the other BASELINE.json configurations measured in the same
-driver-run process — the 1.25 M-row shard and the 1 M-row C2 pipeline, C1 (one query at a time), the C4 encoder forward (MFMA roofline),
-the C5 N-array fusion (HBM roofline).
+driver-run process, before any CPU leg — the 1.25 M-row shard and the 1 M-row C2 pipeline (every segment of their timed
+loops, with the library's batch log naming the largest host and device gap of each), the shard size on SURVEY.md 8d's
+clustered corpus and on a tight mixture whose certificates fail, C1 (one query at a time), the C4 encoder forward (MFMA
+roofline), the C5 N-array fusion (HBM roofline).
 """
 from __future__ import annotations
 
@@ -56,7 +58,7 @@ def parse():
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--k", type=int, default=100)
-    ap.add_argument("--cpu-rows", type=int, default=200_000, help="rows of the CPU-baseline sample")
+    ap.add_argument("--cpu-rows", type=int, default=1_000_000, help="rows of the CPU-baseline sample (SURVEY.md 8d: 1 M)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--recall-queries", type=int, default=-1,
                     help="queries of the last batch checked against the oracle (-1 = the whole batch, 0 = skip)")
@@ -73,27 +75,33 @@ def parse():
     return ap.parse_args()
 
 
-def gen_shard(rows, dim, shard, device, chunk=262_144):
+def gen_shard(rows, dim, shard, device, chunk=262_144, centroids=0, sigma=0.0):
     """unit-norm-able Gaussian rows, generated on the device chunk by chunk (torch Philox, seed 1234000 + shard:
-    a 30 GB host array from numpy's default_rng([1234, s]) would take minutes; same distribution, other stream)."""
+    a 30 GB host array from numpy's default_rng([1234, s]) would take minutes; same distribution, other stream).
+    centroids > 0: the clustered variant of SURVEY.md 8d — every row is one of `centroids` Gaussian centres + sigma x noise."""
     g = torch.Generator(device=device)
     g.manual_seed(1234 * 1000 + shard)
+    cent = torch.randn((centroids, dim), generator=g, device=device, dtype=torch.float32) if centroids else None
     done = 0
     while done < rows:
         m = min(chunk, rows - done)
-        yield torch.randn((m, dim), generator=g, device=device, dtype=torch.float32)
+        x = torch.randn((m, dim), generator=g, device=device, dtype=torch.float32)
+        if cent is not None:
+            x = cent[torch.randint(0, centroids, (m,), generator=g, device=device)] + sigma * x
+        yield x
         done += m
 
 
 def cpu_baseline(args, world):
-    """oracle timed on host cores: bounded sample, scaled linearly in rows."""
+    """oracle timed on host cores: bounded sample (1 M rows), scaled linearly in rows; batch 64 (the
+    metric's batch) and batch 1 (the reference's own per-query regime)."""
     from oracle import flat_index as orc
     try:
         from threadpoolctl import threadpool_info
         thr = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
     except Exception:
         thr = os.cpu_count() or 1
-    n = args.cpu_rows
+    n = min(args.cpu_rows, args.rows)
     # the SAME synthetic stream as the GPU run: the first rows of shard 0 (torch Philox, seed 1234000) and the first
     # query batch (seed 4321), generated on the device and copied to the host
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
@@ -104,27 +112,32 @@ def cpu_baseline(args, world):
         if got >= n:
             break
     x = orc.preprocess_vectors(np.concatenate(xs, axis=0))
+    del xs
     gq = torch.Generator(device=dev)
     gq.manual_seed(4321)
     q = orc.preprocess_vectors(torch.randn((args.batch, args.dim), generator=gq, device=dev, dtype=torch.float32).cpu().numpy())
 
-    def one():
-        s = q @ x.T
+    def one(qq):
+        s = qq @ x.T
         part = np.argpartition(-s, args.k - 1, axis=1)[:, :args.k]
         ps = np.take_along_axis(s, part, axis=1)
         order = np.argsort(-ps, axis=1, kind="stable")
         return np.take_along_axis(part, order, axis=1)
 
-    one()
-    t0 = time.perf_counter()
-    it = 0
-    while True:
-        one()
-        it += 1
-        dt = time.perf_counter() - t0
-        if dt > 10.0 or it >= 50:
-            break
-    t_batch = dt / it
+    def timed(qq, budget_s, max_it):
+        one(qq)
+        t0 = time.perf_counter()
+        it = 0
+        while True:
+            one(qq)
+            it += 1
+            dt = time.perf_counter() - t0
+            if dt > budget_s or it >= max_it:
+                break
+        return dt / it, it
+
+    t_batch, it = timed(q, 10.0, 50)
+    t_one, it1 = timed(q[:1], 5.0, 200)
     qps_sample = args.batch / t_batch
     qps_full = qps_sample * n / args.rows
     return {
@@ -132,10 +145,11 @@ def cpu_baseline(args, world):
         "unit": "queries/s",
         "cores": int(thr),
         "kind": "port",
-        "sample": (f"numpy fp32 sgemm + argpartition top-{args.k}, batch {args.batch}, the first {n} x {args.dim} rows of the bench "
-                   f"corpus (same device-generated stream) and its first query batch: "
-                   f"{qps_sample:.1f} q/s measured over {it} batches, scaled x{n / args.rows:.4g} to {args.rows} rows; "
-                   f"os.cpu_count()={os.cpu_count()}"),
+        "batch1_value": (1.0 / t_one) * n / args.rows,
+        "sample": (f"numpy fp32 sgemm + argpartition top-{args.k}, the first {n} x {args.dim} rows of the bench corpus (same "
+                   f"device-generated stream) and its first query batch: batch {args.batch} {qps_sample:.1f} q/s over {it} batches, "
+                   f"batch 1 {1.0 / t_one:.1f} q/s over {it1} calls (`batch1_value`), both scaled x{n / args.rows:.4g} to "
+                   f"{args.rows} rows; BLAS threads {int(thr)}, os.cpu_count()={os.cpu_count()}"),
     }
 
 
@@ -184,7 +198,8 @@ def pmc_traffic(rows_per_gpu, dim, notes):
     if p["dim"] != dim:
         notes.append("PMC profile taken at another dim")
         return None
-    notes.append(os.path.basename(files[-1]))
+    notes.append(f"STORED measurement, not read in this run: {os.path.basename(files[-1])} (rocprofv3 --pmc passes on the same "
+                 f"kernel source, sha256 checked), scaled by rows")
     return p["traffic_bytes_per_launch"] * rows_per_gpu / p["rows"]
 
 
@@ -195,32 +210,46 @@ def serial_kernel_time(idx, Q, first, count, batch, k, d_ptr, i_ptr, stream):
     """k_scan's own duration: `count` batches issued ONE AT A TIME (sync after each), so the HIP events the library
     records around the launch (OPT_TIMING) bracket the kernel alone — with several batches in flight they also span
     the wait for the previous batch's scan to free the CUs.  Returns (ms per launch, bytes per launch)."""
+    from anorag_hip._lib import OPT_TIMING
     idx.sync()
-    idx.reset_stats()
+    idx.set_option(OPT_TIMING, 1)  # (only here: the two timing events per batch are markers in the batch's queue — the
+    idx.reset_stats()              # pipelined loops run without them)
     for j in range(count):
         idx.search_device_async(Q[first + j].data_ptr(), batch, k, d_ptr, i_ptr, stream)
         idx.sync()
     st = idx.last_stats()
+    idx.set_option(OPT_TIMING, 0)
     idx.reset_stats()
     return st["scan_ms"] / max(1, count), st["scan_bytes"] / max(1, count)
 
 
-def pipeline_leg(rows, dim, batch, k, dev, seed, steps=60, warmup=10, serial=20):
-    """the search pipeline at another corpus size (the 8-GPU shard, C2): 3-deep asynchronous batches for the per-batch
-    time, then serialised batches for the scan kernel's own time"""
+def pipeline_leg(rows, dim, batch, k, dev, seed, steps=60, warmup=10, serial=20, centroids=0, sigma=0.0, overfetch=0):
+    """the search pipeline at another corpus size (the 8-GPU shard, C2) or distribution (clustered): 3-deep asynchronous
+    batches for the per-batch time, then serialised batches for the scan kernel's own time.  EVERY segment of the timed
+    loop is reported (a one-off ~78 ms stall sat in the first segment of this leg in the round-3 driver record, hidden
+    by a median), and the library's batch log (anr_index_batch_log: host enqueue times + device clock stamps of every
+    batch) says where a slow batch lost its time: the largest host gap between two enqueues and the largest
+    scan-start-to-scan-start period on the device, per segment."""
     from anorag_hip import FlatIndex, METRIC_IP
-    from anorag_hip._lib import OPT_TIMING
+    from anorag_hip._lib import OPT_OVERFETCH
     idx = FlatIndex(dim, METRIC_IP, normalize=True, device=dev.index)
     idx.reserve(rows)
-    for xb in gen_shard(rows, dim, seed, dev):
+    for xb in gen_shard(rows, dim, seed, dev, centroids=centroids, sigma=sigma):
         torch.cuda.synchronize()
         idx.add_device(xb.data_ptr(), xb.shape[0])
     del xb
-    idx.set_option(OPT_TIMING, 1)
+    if overfetch:
+        idx.set_option(OPT_OVERFETCH, overfetch)
     g = torch.Generator(device=dev)
     g.manual_seed(4321 + seed)
     nb = warmup + steps
     Q = torch.randn((nb + serial, batch, dim), generator=g, device=dev, dtype=torch.float32)
+    if centroids:  # queries from the same mixture (the centres are the first draw of the corpus generator)
+        gc_ = torch.Generator(device=dev)
+        gc_.manual_seed(1234 * 1000 + seed)
+        cent = torch.randn((centroids, dim), generator=gc_, device=dev, dtype=torch.float32)
+        Q = cent[torch.randint(0, centroids, (nb + serial, batch), generator=g, device=dev)] + sigma * Q
+        del cent
     NS = 3
     S = [torch.cuda.Stream(device=dev) for _ in range(NS)]
     D = [torch.empty((batch, k), device=dev, dtype=torch.float32) for _ in range(NS)]
@@ -234,23 +263,35 @@ def pipeline_leg(rows, dim, batch, k, dev, seed, steps=60, warmup=10, serial=20)
 
     run(0, warmup)
     idx.reset_stats()
-    # three segments, the median one reported: twice in nine runs of this leg a one-off ~65 ms stall (no collector, no
-    # fallback query, the kernel times unchanged) sat inside its 60 batches and quadrupled the mean
     seg = max(1, steps // 3)
-    segs = []
+    segs, diag = [], []
+    t_all = 0.0
     for a in range(warmup, nb, seg):
         b = min(a + seg, nb)
         t0 = time.perf_counter()
         run(a, b)
-        segs.append((time.perf_counter() - t0) / (b - a))
-    dt = float(np.median(segs))
+        dt = time.perf_counter() - t0
+        t_all += dt
+        segs.append(dt / (b - a))
+        rec, _ = idx.batch_log(b - a, correlate=False)
+        if rec.shape[0] >= 2:
+            host = np.diff(np.sort(rec[:, 1])) / 1e3                      # enqueue -> next enqueue, us
+            first = np.sort(rec[:, 7])                                    # first workgroup of each main scan, device clock
+            per = np.diff(first) / 1e3
+            diag.append({"max_host_enqueue_gap_us": float(host.max()), "max_device_scan_to_scan_us": float(per.max()),
+                         "median_device_scan_to_scan_us": float(np.median(per))})
     st = idx.last_stats()
     ms_k, bytes_k = serial_kernel_time(idx, Q, nb, serial, batch, k, D[0].data_ptr(), I[0].data_ptr(), S[0].cuda_stream)
     idx.close()
+    dt = t_all / steps
     gbps = bytes_k / 1e9 / (ms_k / 1e3) if ms_k > 0 else None
     return {"rows": rows, "dim": dim, "batch": batch, "k": k, "ms_per_batch": dt * 1e3,
-            "ms_per_batch_segments": [x * 1e3 for x in segs], "value": batch / dt,
+            "ms_per_batch_note": "mean over all timed batches (every segment below counts)",
+            "ms_per_batch_segments": [x * 1e3 for x in segs], "ms_per_batch_median_segment": float(np.median(segs)) * 1e3,
+            "ms_per_batch_worst_segment": float(np.max(segs)) * 1e3, "segment_diagnostics": diag, "value": batch / dt,
             "unit": "queries/s", "batches": steps, "exact_fallback_queries": st["n_fallback"],
+            "n_from_lists": st["n_from_lists"], "n_dense_exact": st["n_dense_exact"], "overfetch": st["overfetch"],
+            "candidates_per_query": st["n_candidates"] / max(1, steps * batch),
             "scan_ms_per_launch": ms_k, "scan_bytes_per_launch": bytes_k, "scan_GBps": gbps,
             "scan_frac_hbm": gbps / HBM_PEAK_GBPS if gbps else None,
             "batch_GBps": bytes_k / 1e9 / dt, "batch_frac_hbm": bytes_k / 1e9 / dt / HBM_PEAK_GBPS}
@@ -505,7 +546,6 @@ def main():
         idx.add_device(xb.data_ptr(), xb.shape[0])
     del xb
     torch.cuda.empty_cache()
-    idx.set_option(OPT_TIMING, 1)
     # Python's cyclic collector stays off from here on, as `timeit` runs its statements: a generation-2 pass over the heap
     # torch and numpy leave behind takes 40-70 ms — one landed inside a 60-batch leg and turned 0.35 ms per batch into 1.57
     # (reference counting still frees everything the loops allocate)
@@ -585,8 +625,19 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     st_all = idx.last_stats()
-    scan_ms, scan_bytes = st_all["scan_ms"], st_all["scan_bytes"]
+    scan_bytes = st_all["scan_bytes"]
     n_fallback, n_cand = st_all["n_fallback"], st_all["n_candidates"]
+    # what the device did inside the timed region, from the library's batch log (device clock stamps left by the kernels
+    # themselves; no timing events sit in the batches' queues): the main scans' own spans and the scan-to-scan period
+    rec, _ = idx.batch_log(min(args.steps, 512), correlate=False)
+    pipe = None
+    if rec.shape[0] >= 2:
+        first = np.sort(rec[:, 7])
+        span = (rec[:, 9] - rec[:, 7]) / 1e6
+        pipe = {"scan_span_ms_median": float(np.median(span)), "scan_to_scan_ms_median": float(np.median(np.diff(first))) / 1e6,
+                "scan_to_scan_ms_max": float(np.max(np.diff(first))) / 1e6, "batches_logged": int(rec.shape[0]),
+                "note": "first workgroup start -> last workgroup end of each main scan (spans of neighbouring scans overlap: "
+                        "the next scan's workgroups take over CU by CU), and start-to-start periods, device clock"}
     if dist_on:
         t = torch.tensor([dt], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -601,6 +652,31 @@ def main():
     facade = None
     if rank == 0 and world == 1 and not args.no_facade:
         facade = facade_leg(idx, args, Q[nb - 1].cpu().numpy())
+
+    # the other BASELINE.json configurations, in the same driver-run process and BEFORE any CPU leg: in the round-3 driver
+    # record the first pipeline leg after the oracle's 10 M-row BLAS passes (the recall check) carried a ~78 ms stall in its
+    # first segment — the same host-side after-effect the facade leg had shown (128 BLAS threads left spinning) — and the
+    # legs had been left behind the recall pass.  Order now: timed region, kernel-only launches, facade, legs, recall, CPU.
+    legs = None
+    if rank == 0 and world == 1 and not args.no_legs:
+        legs = {}
+        shard_rows = 1_250_000
+        for name, fn in (("shard_1250k", lambda: pipeline_leg(shard_rows, args.dim, args.batch, args.k, dev, 11)),
+                         ("c2_1m", lambda: pipeline_leg(1_000_000, args.dim, args.batch, args.k, dev, 12)),
+                         # SURVEY.md 8d's clustered variant (1024 centroids, sigma 0.3) at the shard size, and a TIGHT mixture
+                         # (sigma 0.02: hundreds of rows within the f16 error bound of the k-th score) whose certificates
+                         # fail, so that the recovery passes' cost is in the record
+                         ("shard_1250k_clustered", lambda: pipeline_leg(shard_rows, args.dim, args.batch, args.k, dev, 13,
+                                                                        centroids=1024, sigma=0.3)),
+                         ("shard_1250k_tight_clusters", lambda: pipeline_leg(shard_rows, args.dim, args.batch, args.k, dev, 14,
+                                                                             steps=30, warmup=6, serial=6, centroids=1024, sigma=0.02)),
+                         ("c1_10k", lambda: c1_leg(dev)), ("c4", lambda: c4_leg(dev)), ("c5", lambda: c5_leg(dev))):
+            try:
+                legs[name] = fn()
+            except Exception as e:  # a failing extra leg must not cost the headline line
+                legs[name] = {"error": f"{type(e).__name__}: {e}"}
+                print(f"bench.py: leg {name} failed: {e}", file=sys.stderr)
+            torch.cuda.empty_cache()
 
     # recall@k of the last batch's first few queries vs the oracle: every rank ranks its own rows on the CPU
     # (float64), rank 0 merges the partial lists and compares with the ids the GPU path returned
@@ -623,21 +699,6 @@ def main():
         if rank == 0:
             recall = recall_from_partials(parts, I_gpu, args.k)
 
-    legs = None
-    if rank == 0 and world == 1 and not args.no_legs:
-        # the other BASELINE.json configurations, in the same driver-run process (before the CPU legs: host threads left
-        # spinning by BLAS stretch launch loops several-fold)
-        legs = {}
-        for name, fn in (("shard_1250k", lambda: pipeline_leg(1_250_000, args.dim, args.batch, args.k, dev, 11)),
-                         ("c2_1m", lambda: pipeline_leg(1_000_000, args.dim, args.batch, args.k, dev, 12)),
-                         ("c1_10k", lambda: c1_leg(dev)), ("c4", lambda: c4_leg(dev)), ("c5", lambda: c5_leg(dev))):
-            try:
-                legs[name] = fn()
-            except Exception as e:  # a failing extra leg must not cost the headline line
-                legs[name] = {"error": f"{type(e).__name__}: {e}"}
-                print(f"bench.py: leg {name} failed: {e}", file=sys.stderr)
-            torch.cuda.empty_cache()
-
     if rank == 0:
         tnotes = []
         traffic = pmc_traffic(per, args.dim, tnotes)
@@ -645,10 +706,11 @@ def main():
         ms_step = dt / args.steps * 1e3
         if ker_ms:
             achieved = (ker_bytes / 1e9) / (ker_ms / 1e3)
-        else:
-            achieved = (scan_bytes / 1e9) / (scan_ms / 1e3) if scan_ms > 0 else None
-        ms_launch = ker_ms if ker_ms else scan_ms / max(1, args.steps)
-        consistent = bool(ms_launch <= ms_step * 1.005)
+            ms_launch = ker_ms
+        else:  # --serial-launches 0: the scans' spans in the pipeline (an upper bound of the kernel time)
+            ms_launch = pipe["scan_span_ms_median"] if pipe else None
+            achieved = (scan_bytes / max(1, args.steps) / 1e9) / (ms_launch / 1e3) if ms_launch else None
+        consistent = bool(ms_launch is not None and ms_launch <= ms_step * 1.005)
         if not consistent:
             print(f"bench.py: kernel time per launch {ms_launch:.4f} ms exceeds the step time {ms_step:.4f} ms", file=sys.stderr)
         out = {
@@ -692,8 +754,8 @@ def main():
                 "ms_per_launch": ms_launch,
                 "launches_timed": n_serial if ker_ms else args.steps,
                 "timing": ("HIP events around the launch on its stream, serialised batches after the timed region"
-                           if ker_ms else "HIP events around the launch, batches overlapping (includes waits for CUs)"),
-                "ms_per_launch_overlapped": scan_ms / max(1, args.steps),
+                           if ker_ms else "device clock stamps of the scans inside the timed region (spans include placement)"),
+                "in_timed_region": pipe,
                 "launch_le_step": consistent,
                 "frac_end_to_end": (scan_bytes / max(1, args.steps) / 1e9) / (ms_step / 1e3) / HBM_PEAK_GBPS,
             },

@@ -93,6 +93,54 @@ def install_stand_ins():
 
     fa.IndexFlatIP = lambda d: _Flat(d, True)
     fa.IndexFlatL2 = lambda d: _Flat(d, False)
+
+    class _IVF(_Flat):
+        """IndexIVFFlat / IndexIVFPQ stand-in: an EXACT flat search that carries nlist / nprobe and wants training — it pins
+        the reference's Python around an IVF index (training, add_with_ids, the nprobe sweep), nothing about IVF recall"""
+        def __init__(self, quantizer, d, nlist, *rest):
+            metric = rest[-1]
+            super().__init__(d, metric == fa.METRIC_INNER_PRODUCT)
+            self.nlist, self.nprobe, self.is_trained, self.ids = nlist, 1, False, None
+            self.nprobe_seen = []
+
+        def train(self, v):
+            self.is_trained = True
+
+        def add_with_ids(self, v, ids):
+            self.add(v)
+            self.ids = np.asarray(ids, np.int64) if self.ids is None else np.concatenate([self.ids, np.asarray(ids, np.int64)])
+
+        def search(self, q, k):
+            self.nprobe_seen.append(int(self.nprobe))
+            D, I = super().search(q, k)
+            if self.ids is not None:
+                I = np.where(I >= 0, self.ids[np.clip(I, 0, None)], -1)
+                fa.last_search = (D.copy(), I.copy())
+            return D, I
+
+    fa.IndexIVFFlat = _IVF
+    fa.IndexIVFPQ = _IVF
+
+    def write_index(index, path):     # what faiss.write_index / read_index mean to the reference: the object comes back
+        import pickle
+        with open(path, "wb") as f:
+            pickle.dump({"cls": type(index).__name__, "d": index.d, "ip": index.ip, "x": index.x,
+                         "nlist": getattr(index, "nlist", None), "nprobe": getattr(index, "nprobe", None),
+                         "ids": getattr(index, "ids", None)}, f)
+
+    def read_index(path):
+        import pickle
+        with open(path, "rb") as f:
+            st = pickle.load(f)
+        if st["cls"] == "_IVF":
+            ix = _IVF(None, st["d"], st["nlist"], fa.METRIC_INNER_PRODUCT if st["ip"] else fa.METRIC_L2)
+            ix.nprobe, ix.ids, ix.is_trained = st["nprobe"], st["ids"], True
+        else:
+            ix = _Flat(st["d"], st["ip"])
+        ix.x, ix.ntotal = st["x"], st["x"].shape[0]
+        return ix
+
+    fa.write_index, fa.read_index = write_index, read_index
     sys.modules["faiss"] = fa
 
     # ---- sentence_transformers stand-in -----------------------------------------------------------------------------
@@ -146,6 +194,30 @@ def install_stand_ins():
         @staticmethod
         def ensure_dir(p):
             os.makedirs(p, exist_ok=True)
+
+        # (the reference's utils/file_utils.py cannot be imported here — it pulls in jsonlines and python-docx; what its
+        # write_json / read_json do for these callers: numpy scalars become Python numbers, then plain json)
+        @staticmethod
+        def write_json(data, path):
+            def conv(o):
+                if isinstance(o, np.integer):
+                    return int(o)
+                if isinstance(o, np.floating):
+                    return float(o)
+                if isinstance(o, np.ndarray):
+                    return o.tolist()
+                if isinstance(o, dict):
+                    return {(int(k) if isinstance(k, np.integer) else k): conv(v) for k, v in o.items()}
+                if isinstance(o, (list, tuple)):
+                    return [conv(v) for v in o]
+                return o
+            with open(path, "w", encoding="utf-8") as f:
+                json.dump(conv(data), f, ensure_ascii=False, indent=2)
+
+        @staticmethod
+        def read_json(path):
+            with open(path, "r", encoding="utf-8") as f:
+                return json.load(f)
 
     class BatchProcessor:
         def __init__(self, *a, **k):
@@ -479,6 +551,258 @@ def embedding_manager_cases(em_mod, stm):
     return out
 
 
+
+def arr_out(a):
+    a = np.asarray(a)
+    return {"shape": list(a.shape), "dtype": str(a.dtype), "values": a.astype(np.float64).reshape(-1).tolist()}
+
+
+def similarity_cases(em_mod):
+    """EmbeddingManager.compute_similarity / find_most_similar (embedding_manager.py:586-660): the +1e-8 denominators, 1-D
+    inputs, 1 / (1 + cdist), argsort[::-1] tie order, the empty / failure sentinels"""
+    rng = np.random.default_rng(20261104)
+    em = object.__new__(em_mod.EmbeddingManager)
+    out = {"compute_similarity": [], "find_most_similar": []}
+    a = rng.standard_normal((4, 6)).astype(np.float32)
+    b = rng.standard_normal((5, 6)).astype(np.float32)
+    bz = b.copy()
+    bz[2] = 0.0
+    tie = np.vstack([b[0], b[1], b[0], b[3], b[1], b[0]]).astype(np.float32)   # repeated rows: equal similarities
+    inputs = [("f32_2d", a, b), ("f64_2d", a.astype(np.float64), b.astype(np.float64)), ("zero_row", a, bz),
+              ("one_dim_first", a[0], b), ("one_dim_both", a[1], b[2]), ("one_dim_second", a, b[1]),
+              ("empty_first", np.zeros((0, 6), np.float32), b), ("empty_second", a, np.zeros((0, 6), np.float32)),
+              ("mismatched_dims", a, rng.standard_normal((3, 5)).astype(np.float32)), ("single_rows", a[:1], b[:1]),
+              ("tiny_norms", a * 1e-12, b), ("mixed_dtypes", a, b.astype(np.float64))]
+    for name, x, y in inputs:
+        for metric in ("cosine", "euclidean", "dot", "manhattan"):
+            r = em.compute_similarity(np.array(x), np.array(y), metric=metric)
+            out["compute_similarity"].append({"name": name, "metric": metric, "a": arr_out(x), "b": arr_out(y), "expected": arr_out(r)})
+    for name, q, c, k in [("plain", a[0], b, 3), ("top_k_beyond", a[1], b, 10), ("ties", b[0], tie, 6), ("ties_top2", b[1], tie, 2),
+                          ("empty_query", np.zeros((0,), np.float32), b, 3), ("empty_candidates", a[0], np.zeros((0, 6), np.float32), 3),
+                          ("mismatched", a[0], rng.standard_normal((3, 5)).astype(np.float32), 2), ("f64", a[2].astype(np.float64), b.astype(np.float64), 4),
+                          ("zero_candidates", a[0], np.zeros((3, 6), np.float32), 3), ("top_k_zero", a[0], b, 0)]:
+        for metric in ("cosine", "euclidean", "dot"):
+            r = em.find_most_similar(np.array(q), np.array(c), top_k=k, metric=metric)
+            out["find_most_similar"].append({"name": name, "metric": metric, "query": arr_out(q), "candidates": arr_out(c), "top_k": k,
+                                             "expected": r})
+    return out
+
+
+def index_persistence_cases(vi_mod, fa):
+    """VectorIndex.save_index / load_index (vector_index.py:284-364: file names, the sidecar's schema, the returned path,
+    what a load restores), get_index_stats, optimize_search_params / _calculate_recall (:428-491)"""
+    import tempfile
+    rng = np.random.default_rng(20261105)
+    out = {"save_load": [], "optimize": [], "calculate_recall": []}
+
+    def new_index(metric, dim, itype, index_dir, nlist=None):
+        CONFIG_OVERRIDES.clear()
+        CONFIG_OVERRIDES.update({"vector_store.index_type": itype, "vector_store.similarity_metric": metric,
+                                 "vector_store.dimension": dim, "storage.vector_index_path": index_dir})
+        if nlist is not None:
+            CONFIG_OVERRIDES["vector_store.nlist"] = nlist
+        v = vi_mod.VectorIndex(dim)
+        v.index_dir = index_dir
+        return v
+
+    def attrs(v):
+        return {k: getattr(v, k) for k in ("index_type", "embedding_dim", "similarity_metric", "total_vectors", "is_trained", "nlist", "nprobe")}
+
+    for name, metric, itype, dim, n, fname in [("flat_cosine_default_name", "cosine", "Flat", 6, 12, None),
+                                               ("flat_l2_custom_name", "l2", "Flat", 5, 9, "my_index.faiss"),
+                                               ("ivfflat_cosine", "cosine", "IVFFlat", 6, 40, None),
+                                               ("name_without_faiss_suffix", "cosine", "Flat", 4, 7, "plain.bin")]:
+        d0 = tempfile.mkdtemp(prefix="anr_golden_ix_")
+        v = new_index(metric, dim, itype, d0, nlist=4)
+        assert v.create_index()
+        x = rng.standard_normal((n, dim)).astype(np.float32)
+        ids = np.arange(100, 100 + n, dtype=np.int64)
+        assert v.add_vectors(x, ids)
+        q = rng.standard_normal((3, dim)).astype(np.float32)
+        before = v.search(q, top_k=4)
+        saved_attrs = attrs(v)
+        path = v.save_index(fname) if fname else v.save_index()
+        files = sorted(os.listdir(d0))
+        meta_name = os.path.basename(path).replace(".faiss", "_metadata.json")
+        meta = json.load(open(os.path.join(d0, meta_name))) if os.path.exists(os.path.join(d0, meta_name)) else None
+        v2 = new_index("l2" if metric == "cosine" else "cosine", 3, "Flat", d0)   # other settings: the sidecar must win
+        loaded = v2.load_index(os.path.basename(path))
+        after = v2.search(q, top_k=4)
+        out["save_load"].append({"name": name, "metric": metric, "index_type": itype, "dim": dim, "vectors": jf(x), "ids": ids.tolist(),
+                                 "queries": jf(q), "filename_arg": fname, "returned_basename": os.path.basename(path),
+                                 "returned_dir_is_index_dir": os.path.dirname(path) == d0, "files": files,
+                                 "metadata_file": meta_name, "metadata": meta, "attrs_at_save": saved_attrs, "load_returned": loaded,
+                                 "attrs_after_load": attrs(v2), "search_before": before, "search_after_load": after,
+                                 "stats_after_load": v2.get_index_stats(), "load_missing": v2.load_index("nope.faiss")})
+    d0 = tempfile.mkdtemp(prefix="anr_golden_ix_")
+    v = new_index("cosine", 4, "Flat", d0)
+    out["save_without_index"] = {"returned": v.save_index(), "stats": v.get_index_stats()}
+    # a file WITHOUT a sidecar: the attributes keep the loader's own values, total_vectors stays what it was
+    v = new_index("cosine", 4, "Flat", d0)
+    assert v.create_index() and v.add_vectors(rng.standard_normal((5, 4)).astype(np.float32))
+    p = v.save_index("bare.faiss")
+    os.remove(p.replace(".faiss", "_metadata.json"))
+    v3 = new_index("cosine", 4, "Flat", d0)
+    out["load_without_sidecar"] = {"load_returned": v3.load_index("bare.faiss"), "attrs_after_load": attrs(v3)}
+
+    # optimize_search_params: only IVF types; the sweep over nprobe <= nlist; best / early stop; the nprobe left behind
+    for name, itype, nlist, n, gt_kind, target in [("flat_is_refused", "Flat", 4, 30, "exact", 0.9),
+                                                   ("ivf_exact_truth_stops_at_first", "IVFFlat", 64, 200, "exact", 0.9),
+                                                   ("ivf_half_wrong_truth_sweeps", "IVFFlat", 64, 200, "half", 0.9),
+                                                   ("ivf_small_nlist_breaks", "IVFFlat", 8, 60, "half", 0.9),
+                                                   ("ivfpq_low_target", "IVFPQ", 64, 200, "half", 0.4),
+                                                   ("ivf_single_query", "IVFFlat", 64, 200, "exact1", 0.9)]:
+        d0 = tempfile.mkdtemp(prefix="anr_golden_ix_")
+        v = new_index("cosine", 8, itype, d0, nlist=nlist)
+        assert v.create_index()
+        x = rng.standard_normal((n, 8)).astype(np.float32)
+        assert v.add_vectors(x)
+        nq = 1 if gt_kind == "exact1" else 5
+        q = rng.standard_normal((nq, 8)).astype(np.float32)
+        xn = x / np.linalg.norm(x, axis=1, keepdims=True)
+        qn = q / np.linalg.norm(q, axis=1, keepdims=True)
+        truth = np.argsort(-(qn @ xn.T), axis=1, kind="stable")[:, :6]
+        if gt_kind == "half":
+            truth = truth.copy()
+            truth[:, 3:] = n + 1000 + np.arange(3)        # rows that do not exist: recall can reach 0.5 at most
+        nprobe_before = v.nprobe
+        try:   # (one query: search returns a FLAT list and _calculate_recall then indexes a str — the reference raises)
+            res = v.optimize_search_params(q, truth, target_recall=target)
+            raised = None
+        except Exception as e:
+            res, raised = None, type(e).__name__
+        out["optimize"].append({"name": name, "index_type": itype, "nlist": nlist, "vectors": jf(x), "queries": jf(q),
+                                "ground_truth": truth.tolist(), "target_recall": target, "nprobe_before": nprobe_before,
+                                "expected": res, "raises": raised, "nprobe_after": v.nprobe, "nlist_after": v.nlist,
+                                "index_nprobe_after": getattr(v.index, "nprobe", None)})
+    v = new_index("cosine", 4, "Flat", tempfile.mkdtemp(prefix="anr_golden_ix_"))
+    hits = lambda *rows: [[{"index": i} for i in r] for r in rows]
+    for name, res, gt in [("plain", hits([1, 2, 3], [4, 5, 6]), [[1, 2, 9], [7, 8, 9]]),
+                          ("empty_results", [], [[1]]), ("empty_truth", hits([1]), []),
+                          ("more_results_than_truth", hits([1, 2], [3, 4], [5, 6]), [[1, 2], [9, 9]]),
+                          ("more_truth_than_results", hits([1, 2]), [[1, 5], [3], [4]]),
+                          ("empty_truth_row", hits([1, 2], [3]), [[], [3]]),
+                          ("duplicates_in_truth", hits([1, 2, 3]), [[1, 1, 2, 7]])]:
+        out["calculate_recall"].append({"name": name, "search_results": res, "ground_truth": gt,
+                                        "expected": v._calculate_recall(res, np.array(gt, dtype=object) if gt and len({len(g) for g in gt}) > 1 else np.array(gt))})
+    return out
+
+
+def retriever_persistence_cases(rt_mod, em_mod, stm):
+    """VectorRetriever._save_index_data / _can_load_existing_index (retriever.py:680-749: the file set, npz keys, the
+    id_mappings.json schema, when an existing index is taken), optimize_retrieval / _calculate_f1_score / get_retrieval_stats
+    (:751-860)"""
+    import tempfile
+    rng = np.random.default_rng(20261106)
+    d = 8
+    em = object.__new__(em_mod.EmbeddingManager)
+    em.model = stm.SentenceTransformer()
+    em.model.dim = d
+    em.model_name, em.batch_size, em.device, em.max_length = "BAAI/bge-m3", 32, "cpu", 512
+    em.normalize_embeddings, em.embedding_dim, em.consistency_checker = True, d, None
+    em_mod.EmbeddingManager._instance = em
+    em_mod.EmbeddingManager._model_loaded = True
+    out = {}
+
+    def fresh(data_dir, index_dir, itype="Flat"):
+        CONFIG_OVERRIDES.clear()
+        CONFIG_OVERRIDES.update({"vector_store.index_type": itype, "vector_store.similarity_metric": "cosine",
+                                 "storage.vector_store_path": data_dir, "storage.vector_index_path": index_dir})
+        r = rt_mod.VectorRetriever()
+        r.data_dir = data_dir
+        r.vector_index.index_dir = index_dir
+        return r
+
+    notes = FakeNotes.make(rng, 14)
+    for i, n in enumerate(notes):
+        if not isinstance(n["content"], str):
+            n["content"] = f"plain content {i} paris river"
+    data_dir = tempfile.mkdtemp(prefix="anr_golden_rd_")
+    r = fresh(data_dir, data_dir)            # the reference loads `index_files[0]` from data_dir through vector_index.load_index:
+    em.model.calls = []                      # it only finds the file when both directories are the same one
+    ok = r.build_index([dict(n) for n in notes], force_rebuild=True, save_index=True)
+    files = sorted(os.listdir(data_dir))
+    npz = np.load(os.path.join(data_dir, "note_embeddings.npz"))
+    out["save"] = {"notes": notes, "build_returned": ok, "files": files, "npz_keys": sorted(npz.files),
+                   "npz_embeddings_shape": list(npz["embeddings"].shape), "npz_embeddings_dtype": str(npz["embeddings"].dtype),
+                   "atomic_notes_json": json.load(open(os.path.join(data_dir, "atomic_notes.json"))),
+                   "id_mappings_json": json.load(open(os.path.join(data_dir, "id_mappings.json"))),
+                   "vectors": {k: [float(t) for t in v] for k, v in em.model.seen.items()}}
+    can = []
+    for name, cand in [("same_notes", [dict(n) for n in notes]), ("other_count", [dict(n) for n in notes[:-1]]),
+                       ("other_first_id", [dict(notes[1])] + [dict(n) for n in notes[1:]]),
+                       ("same_count_same_first_other_rest", [dict(notes[0])] + [dict(n, note_id="zzz") for n in notes[1:]])]:
+        r2 = fresh(data_dir, data_dir)
+        got = r2._can_load_existing_index(cand)
+        can.append({"name": name, "candidate_ids": [n.get("note_id") for n in cand], "returned": got,
+                    "n_notes_after": len(r2.atomic_notes), "total_vectors_after": int(r2.vector_index.total_vectors),
+                    "embeddings_shape_after": list(r2.note_embeddings.shape) if r2.note_embeddings is not None else None,
+                    "note_id_to_index_after": dict(r2.note_id_to_index)})
+    empty_dir = tempfile.mkdtemp(prefix="anr_golden_rd_")
+    r3 = fresh(empty_dir, empty_dir)
+    can.append({"name": "empty_directory", "candidate_ids": [n["note_id"] for n in notes], "returned": r3._can_load_existing_index(notes)})
+    only_index = tempfile.mkdtemp(prefix="anr_golden_rd_")
+    open(os.path.join(only_index, "x.faiss"), "wb").write(b"junk")
+    r4 = fresh(only_index, only_index)
+    can.append({"name": "index_file_without_notes_file", "candidate_ids": [n["note_id"] for n in notes],
+                "returned": r4._can_load_existing_index(notes)})
+    out["can_load"] = can
+    # build_index without force_rebuild takes the existing index: no encoder call
+    r5 = fresh(data_dir, data_dir)
+    em.model.calls = []
+    ok = r5.build_index([dict(n) for n in notes], force_rebuild=False, save_index=False)
+    out["build_reuses_existing"] = {"returned": ok, "encoder_calls": len(em.model.calls), "n_notes": len(r5.atomic_notes)}
+
+    # get_retrieval_stats: with embeddings present the reference calls a method its EmbeddingManager does not have
+    def stats_of(rr):
+        try:
+            return {"returned": rr.get_retrieval_stats()}
+        except Exception as e:
+            return {"raises": type(e).__name__}
+    r6 = fresh(tempfile.mkdtemp(prefix="anr_golden_rd_"), tempfile.mkdtemp(prefix="anr_golden_ri_"))
+    out["stats_empty"] = stats_of(r6)
+    out["stats_built"] = stats_of(r)
+
+    # _calculate_f1_score
+    hits = lambda *rows: [[{"note_id": i} for i in rr] for rr in rows]
+    f1 = []
+    for name, res, gt in [("plain", hits(["a", "b", "c"], ["d"]), [["a", "x"], ["d"]]), ("no_results", [], [["a"]]),
+                          ("no_truth", hits(["a"]), []), ("empty_truth_rows_skipped", hits(["a"], ["b"]), [[], ["b"]]),
+                          ("nothing_retrieved", hits([], ["b"]), [["a"], ["b", "c"]]), ("disjoint", hits(["a"]), [["z"]]),
+                          ("all_truth_rows_empty", hits(["a"]), [[]]), ("missing_note_id_key", [[{"x": 1}, {"note_id": "a"}]], [["a"]]),
+                          ("more_results_than_truth", hits(["a"], ["b"], ["c"]), [["a"]])]:
+        f1.append({"name": name, "search_results": res, "ground_truth": gt, "expected": r._calculate_f1_score(res, gt)})
+    out["f1"] = f1
+
+    # optimize_retrieval on the built retriever (Flat: index_optimization == {}), and on an IVFFlat one
+    prefix = "Represent this sentence for searching relevant passages: "
+    opt = []
+    for itype in ("Flat", "IVFFlat"):
+        dd = tempfile.mkdtemp(prefix="anr_golden_rd_")
+        rr = fresh(dd, dd, itype)
+        em.model.calls = []
+        assert rr.build_index([dict(n) for n in notes], force_rebuild=True, save_index=False)
+        emb = rr.note_embeddings
+        queries = ["first probe", "second probe", "third probe"]
+        near = [2, 5, 9]
+        table = {}
+        for qt, j in zip(queries, near):
+            v = emb[j] + 0.25 * rng.standard_normal(d).astype(np.float32)
+            table[prefix + qt] = (v / np.linalg.norm(v)).astype(np.float32)
+        em.model.table = table
+        gt = [[notes[2]["note_id"], notes[3]["note_id"]], [notes[5]["note_id"]], [notes[9]["note_id"], "unknown_id"]]
+        thr_before = rr.similarity_threshold
+        res = rr.optimize_retrieval(queries, gt, target_recall=0.8)
+        opt.append({"index_type": itype, "queries": queries, "ground_truth": gt, "target_recall": 0.8,
+                    "query_vectors": {k: [float(t) for t in v] for k, v in table.items()},
+                    "note_vectors": {k: [float(t) for t in v] for k, v in em.model.seen.items()},
+                    "threshold_before": thr_before, "expected": res, "threshold_after": rr.similarity_threshold})
+        em.model.table = {}
+    out["optimize_retrieval"] = opt
+    out["optimize_retrieval_no_data"] = {"no_queries": r.optimize_retrieval([], [["a"]]), "no_truth": r.optimize_retrieval(["q"], [])}
+    return out
+
+
 def main():
     fa, stm = install_stand_ins()
     pkg = types.ModuleType("vector_store")
@@ -502,6 +826,19 @@ def main():
     with open(os.path.join(HERE, "embedding_manager_facade_cases.json"), "w") as f:
         json.dump({"source": "reference vector_store/embedding_manager.py text assembly / preprocessing / prefix / sentinels",
                    "note": note, **embedding_manager_cases(em_mod, stm)}, f)
+    with open(os.path.join(HERE, "similarity_cases.json"), "w") as f:
+        json.dump({"source": "reference vector_store/embedding_manager.py compute_similarity / find_most_similar (scipy's cdist is "
+                             "the real one)", "note": note, **similarity_cases(em_mod)}, f)
+    with open(os.path.join(HERE, "index_persistence_cases.json"), "w") as f:
+        json.dump({"source": "reference vector_store/vector_index.py save_index / load_index / get_index_stats / "
+                             "optimize_search_params / _calculate_recall", "note": note + "; the IVF stand-in is an exact search "
+                             "that carries nlist / nprobe, faiss.write_index / read_index bring the stand-in object back",
+                   **index_persistence_cases(vi_mod, fa)}, f, default=lambda o: o.item() if hasattr(o, "item") else str(o))
+    with open(os.path.join(HERE, "retriever_persistence_cases.json"), "w") as f:
+        json.dump({"source": "reference vector_store/retriever.py _save_index_data / _can_load_existing_index / optimize_retrieval "
+                             "/ _calculate_f1_score / get_retrieval_stats", "note": note,
+                   **retriever_persistence_cases(rt_mod, em_mod, stm)}, f, default=lambda o: o.item() if hasattr(o, "item") else str(o))
+    print("wrote similarity_cases.json, index_persistence_cases.json, retriever_persistence_cases.json")
     print("wrote vector_index_facade_cases.json, retriever_facade_cases.json, retriever_lifecycle_cases.json, embedding_manager_facade_cases.json")
 
 

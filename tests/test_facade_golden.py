@@ -9,6 +9,11 @@ text assembly — not the libraries themselves):
   rows c2 / c6 / c7 / c10 vector_store/retriever.py:118-184, :514-659, :924-1034 (build / add / remove / update / similar notes,
                           the TF-IDF fallback and the namespace filter; incl. the reference's total_vectors that keeps
                           growing across rebuilds)
+  rows a8 / a9            vector_store/embedding_manager.py:586-660 (compute_similarity / find_most_similar; device kernel: gpu)
+  rows b8 / b9            vector_store/vector_index.py:284-364 (save / load: file names, sidecar schema, restored attributes),
+                          :366-393 (stats), :428-491 (optimize_search_params, _calculate_recall)
+  rows c8 / c9            vector_store/retriever.py:680-749 (_save_index_data / _can_load_existing_index: file set, npz keys,
+                          id_mappings.json), :751-860 (get_retrieval_stats, optimize_retrieval, _calculate_f1_score)
 
 CPU tests drive the classes with a numpy index in the place of the device index (host logic only, no compute through
 the C ABI); the `gpu` tests run the same cases through the real FlatIndex."""
@@ -84,6 +89,24 @@ class _NumpyFlat:
 
     def close(self):
         pass
+
+    # what VectorIndex.save_index / load_index / remove_vectors use of the device index
+    raw = False
+
+    def reserve(self, n):
+        pass
+
+    def set_option(self, opt, value):
+        from anorag_hip._lib import OPT_ADD_RAW
+        if opt == OPT_ADD_RAW:
+            self.raw = bool(value)
+            if self.raw:
+                self._saved, self.normalize = self.normalize, False
+            else:
+                self.normalize = getattr(self, "_saved", self.normalize)
+
+    def reconstruct_n(self, s, n):
+        return self.x[s:s + n].copy()
 
 
 class _ReplayIndex:
@@ -418,3 +441,216 @@ def test_vector_index_search_matches_the_reference_on_the_device():
             pass
         _same(got, c["expected"], 1e-4, c["name"])
         vi.cleanup()
+
+
+# ---- round 4: persistence, tuning helpers, similarity (reference-run fixtures) ---------------------------------------------
+def _arr(spec):
+    return np.array(spec["values"], dtype=np.float64).reshape(spec["shape"]).astype(np.dtype(spec["dtype"]))
+
+
+def _patch_numpy_index(monkeypatch):
+    from anorag_hip import METRIC_IP
+    from vector_store.vector_index import VectorIndex
+    monkeypatch.setattr(VectorIndex, "_new_index", lambda self, d, metric, normalize: _NumpyFlat(d, metric == METRIC_IP, normalize))
+
+
+def _new_vi(dim, metric, itype, index_dir, nlist=None):
+    from vector_store.vector_index import VectorIndex
+    vi = VectorIndex(dim)
+    vi.index_type, vi.similarity_metric, vi.index_dir = itype, metric, index_dir
+    if nlist is not None:
+        vi.nlist = nlist
+    return vi
+
+
+_ATTRS = ("index_type", "embedding_dim", "similarity_metric", "total_vectors", "is_trained", "nlist", "nprobe")
+
+
+def _run_index_persistence(tmp_path, tol):
+    g = _load("index_persistence_cases.json")
+    for n_case, c in enumerate(g["save_load"]):
+        d0 = str(tmp_path / f"ix{n_case}")
+        os.makedirs(d0)
+        vi = _new_vi(c["dim"], c["metric"], c["index_type"], d0, nlist=4)
+        assert vi.create_index()
+        assert vi.add_vectors(np.array(c["vectors"], np.float32), np.array(c["ids"], np.int64))
+        q = np.array(c["queries"], np.float32)
+        _same(vi.search(q, top_k=4), c["search_before"], tol, c["name"] + ".before")
+        assert {k: getattr(vi, k) for k in _ATTRS} == c["attrs_at_save"], c["name"]
+        path = vi.save_index(c["filename_arg"]) if c["filename_arg"] else vi.save_index()
+        assert os.path.basename(path) == c["returned_basename"] and (os.path.dirname(path) == d0) == c["returned_dir_is_index_dir"]
+        assert sorted(os.listdir(d0)) == c["files"], c["name"]               # the same file set under the same names
+        if c["metadata"] is not None:
+            with open(os.path.join(d0, c["metadata_file"])) as f:
+                assert json.load(f) == c["metadata"], c["name"]               # the sidecar's schema and values
+        other = "l2" if c["metric"] == "cosine" else "cosine"
+        v2 = _new_vi(3, other, "Flat", d0)                                     # other settings: the sidecar must win
+        assert v2.load_index(os.path.basename(path)) == c["load_returned"], c["name"]
+        assert {k: getattr(v2, k) for k in _ATTRS} == c["attrs_after_load"], c["name"]
+        _same(v2.search(q, top_k=4), c["search_after_load"], tol, c["name"] + ".after")
+        got, exp = v2.get_index_stats(), c["stats_after_load"]
+        assert list(got) == list(exp) and {k: v for k, v in got.items() if k != "use_gpu"} == {k: v for k, v in exp.items() if k != "use_gpu"}
+        assert v2.load_index("nope.faiss") == c["load_missing"]
+        vi.cleanup()
+        v2.cleanup()
+    d0 = str(tmp_path / "ixs")
+    os.makedirs(d0)
+    vi = _new_vi(4, "cosine", "Flat", d0)
+    assert vi.save_index() == g["save_without_index"]["returned"] and vi.get_index_stats() == g["save_without_index"]["stats"]
+    assert vi.create_index() and vi.add_vectors(np.random.default_rng(1).standard_normal((5, 4)).astype(np.float32))
+    p = vi.save_index("bare.faiss")
+    os.remove(p.replace(".faiss", "_metadata.json"))
+    v3 = _new_vi(4, "cosine", "Flat", d0)
+    assert v3.load_index("bare.faiss") == g["load_without_sidecar"]["load_returned"]
+    assert {k: getattr(v3, k) for k in _ATTRS} == g["load_without_sidecar"]["attrs_after_load"]
+    vi.cleanup()
+    v3.cleanup()
+    for n_case, c in enumerate(g["optimize"]):
+        d0 = str(tmp_path / f"opt{n_case}")
+        os.makedirs(d0)
+        vi = _new_vi(8, "cosine", c["index_type"], d0, nlist=c["nlist"])
+        assert vi.create_index() and vi.add_vectors(np.array(c["vectors"], np.float32))
+        assert vi.nprobe == c["nprobe_before"]
+        q, gt = np.array(c["queries"], np.float32), np.array(c["ground_truth"])
+        if c["raises"]:
+            with pytest.raises(Exception) as ei:
+                vi.optimize_search_params(q, gt, target_recall=c["target_recall"])
+            assert type(ei.value).__name__ == c["raises"], c["name"]
+        else:
+            _same(vi.optimize_search_params(q, gt, target_recall=c["target_recall"]), c["expected"], 1e-12, c["name"])
+        assert vi.nprobe == c["nprobe_after"] and vi.nlist == c["nlist_after"], c["name"]
+        vi.cleanup()
+    vi = _new_vi(4, "cosine", "Flat", str(tmp_path))
+    for c in g["calculate_recall"]:
+        gt = c["ground_truth"]
+        gt = np.array(gt, dtype=object) if gt and len({len(x) for x in gt}) > 1 else np.array(gt)
+        assert vi._calculate_recall(c["search_results"], gt) == c["expected"], c["name"]
+
+
+def test_index_persistence_and_tuning_match_the_reference_host_logic(monkeypatch, tmp_path):
+    _patch_numpy_index(monkeypatch)
+    _run_index_persistence(tmp_path, 1e-6)
+
+
+@pytest.mark.gpu
+def test_index_persistence_and_tuning_match_the_reference_on_the_device(tmp_path):
+    _run_index_persistence(tmp_path, 1e-4)
+
+
+def _run_retriever_persistence(tmp_path, tol):
+    from vector_store import embedding_manager as emm
+    from vector_store.retriever import VectorRetriever
+    g = _load("retriever_persistence_cases.json")
+    notes = g["save"]["notes"]
+    d = 8
+
+    class Strict(dict):
+        def get(self, key, default=None):
+            return self[key]
+
+    em = _manager(d, table=Strict({k: np.array(v, np.float32) for k, v in g["save"]["vectors"].items()}))
+
+    def fresh(data_dir, itype="Flat"):
+        old = (emm.EmbeddingManager._instance, emm.EmbeddingManager._model_loaded)
+        emm.EmbeddingManager._instance, emm.EmbeddingManager._model_loaded = em, True
+        try:
+            r = VectorRetriever()
+        finally:
+            emm.EmbeddingManager._instance, emm.EmbeddingManager._model_loaded = old
+        os.makedirs(data_dir, exist_ok=True)
+        r.data_dir = data_dir
+        r.vector_index.index_dir = data_dir
+        r.vector_index.index_type, r.vector_index.similarity_metric = itype, "cosine"
+        return r
+
+    data_dir = str(tmp_path / "rd")
+    r = fresh(data_dir)
+    assert r.build_index([dict(n) for n in notes], force_rebuild=True, save_index=True) == g["save"]["build_returned"]
+    assert sorted(os.listdir(data_dir)) == g["save"]["files"]                              # the reference's file set
+    npz = np.load(os.path.join(data_dir, "note_embeddings.npz"))
+    assert sorted(npz.files) == g["save"]["npz_keys"] and list(npz["embeddings"].shape) == g["save"]["npz_embeddings_shape"]
+    assert str(npz["embeddings"].dtype) == g["save"]["npz_embeddings_dtype"]
+    with open(os.path.join(data_dir, "atomic_notes.json")) as f:
+        assert json.load(f) == g["save"]["atomic_notes_json"]
+    with open(os.path.join(data_dir, "id_mappings.json")) as f:
+        assert json.load(f) == g["save"]["id_mappings_json"]                                 # both maps, int keys as strings
+    by_id = {n["note_id"]: n for n in notes}
+    for c in g["can_load"]:
+        if c["name"] == "empty_directory":
+            r2 = fresh(str(tmp_path / "empty"))
+            assert r2._can_load_existing_index(notes) == c["returned"]
+            continue
+        if c["name"] == "index_file_without_notes_file":
+            dd = str(tmp_path / "only")
+            os.makedirs(dd)
+            with open(os.path.join(dd, "x.faiss"), "wb") as f:
+                f.write(b"junk")
+            assert fresh(dd)._can_load_existing_index(notes) == c["returned"]
+            continue
+        cand = [dict(by_id.get(i, {"note_id": i})) for i in c["candidate_ids"]]
+        r2 = fresh(data_dir)
+        assert r2._can_load_existing_index(cand) == c["returned"], c["name"]
+        assert len(r2.atomic_notes) == c["n_notes_after"] and int(r2.vector_index.total_vectors) == c["total_vectors_after"], c["name"]
+        assert (list(r2.note_embeddings.shape) if r2.note_embeddings is not None else None) == c["embeddings_shape_after"], c["name"]
+        assert dict(r2.note_id_to_index) == c["note_id_to_index_after"], c["name"]
+        r2.cleanup()
+    r5 = fresh(data_dir)
+    em.model.calls = []
+    assert r5.build_index([dict(n) for n in notes], force_rebuild=False, save_index=False) == g["build_reuses_existing"]["returned"]
+    assert len(em.model.calls) == g["build_reuses_existing"]["encoder_calls"] and len(r5.atomic_notes) == g["build_reuses_existing"]["n_notes"]
+    r5.cleanup()
+
+    def stats_of(rr):
+        try:
+            return {"returned": rr.get_retrieval_stats()}
+        except Exception as e:
+            return {"raises": type(e).__name__}
+    r6 = fresh(str(tmp_path / "r6"))
+    _same(stats_of(r6), g["stats_empty"], 0.0, "stats_empty")
+    assert stats_of(r) == g["stats_built"]      # (the reference calls EmbeddingManager.get_embedding_stats, which it does not define)
+    for c in g["f1"]:
+        assert r._calculate_f1_score(c["search_results"], c["ground_truth"]) == pytest.approx(c["expected"], abs=1e-12), c["name"]
+    for n_case, c in enumerate(g["optimize_retrieval"]):
+        em.model.table = Strict({**{k: np.array(v, np.float32) for k, v in c["note_vectors"].items()},
+                                 **{k: np.array(v, np.float32) for k, v in c["query_vectors"].items()}})
+        rr = fresh(str(tmp_path / f"opt{n_case}"), c["index_type"])
+        assert rr.build_index([dict(n) for n in notes], force_rebuild=True, save_index=False)
+        assert rr.similarity_threshold == c["threshold_before"]
+        _same(rr.optimize_retrieval(c["queries"], c["ground_truth"], target_recall=c["target_recall"]), c["expected"], 1e-9,
+              "optimize_retrieval/" + c["index_type"])
+        assert rr.similarity_threshold == c["threshold_after"]
+        rr.cleanup()
+    assert r.optimize_retrieval([], [["a"]]) == g["optimize_retrieval_no_data"]["no_queries"]
+    assert r.optimize_retrieval(["q"], []) == g["optimize_retrieval_no_data"]["no_truth"]
+    r.cleanup()
+
+
+def test_retriever_persistence_and_tuning_match_the_reference_host_logic(monkeypatch, tmp_path):
+    _patch_numpy_index(monkeypatch)
+    _run_retriever_persistence(tmp_path, 1e-6)
+
+
+@pytest.mark.gpu
+def test_retriever_persistence_and_tuning_match_the_reference_on_the_device(tmp_path):
+    _run_retriever_persistence(tmp_path, 1e-4)
+
+
+@pytest.mark.gpu
+def test_compute_similarity_and_find_most_similar_match_the_reference():
+    """the device similarity kernel behind the reference's own call sites, on reference-run outputs: shapes and dtypes of every
+    metric / rank combination (incl. the sentinels), values within 1e-6, and find_most_similar's order on exact ties"""
+    g = _load("similarity_cases.json")
+    em = _manager(4)
+    for c in g["compute_similarity"]:
+        got = em.compute_similarity(_arr(c["a"]), _arr(c["b"]), metric=c["metric"])
+        exp = c["expected"]
+        name = f'{c["name"]}/{c["metric"]}'
+        assert list(np.shape(got)) == exp["shape"] and str(np.asarray(got).dtype) == exp["dtype"], (name, np.shape(got), np.asarray(got).dtype, exp["shape"], exp["dtype"])
+        ref = np.array(exp["values"], np.float64)
+        scale = max(1.0, float(np.max(np.abs(ref), initial=0.0)))
+        assert np.max(np.abs(np.asarray(got, np.float64).reshape(-1) - ref), initial=0.0) <= 2e-6 * scale, name
+    for c in g["find_most_similar"]:
+        got = em.find_most_similar(_arr(c["query"]), _arr(c["candidates"]), top_k=c["top_k"], metric=c["metric"])
+        name = f'{c["name"]}/{c["metric"]}'
+        assert [h["index"] for h in got] == [h["index"] for h in c["expected"]], name
+        _same(got, c["expected"], 2e-6 * max([1.0] + [abs(h["similarity"]) for h in c["expected"]]), name)
