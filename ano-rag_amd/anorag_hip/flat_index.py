@@ -185,10 +185,10 @@ class FlatIndex:
 
     BATCH_LOG_NAMES = ("seq", "host_enqueue_ns", "host_enqueued_ns", "host_retired_ns", "dev_prep_end_ns",
                        "dev_sample_end_ns", "dev_ladder_end_ns", "dev_scan_first_wg_ns", "dev_scan_last_wg_ns",
-                       "dev_scan_end_ns", "dev_select_end_ns", "dev_post_end_ns", "flags")
+                       "dev_scan_end_ns", "dev_select_end_ns", "dev_post_end_ns", "flags", "host_recovery_ns")
 
     def batch_log(self, max_batches: int = 512, correlate: bool = True):
-        """time line of the most recent pipeline batches (anr_index_batch_log): (records [n, 13] int64, device clock
+        """time line of the most recent pipeline batches (anr_index_batch_log): (records [n, 14] int64, device clock
         minus host clock in ns or None); retires the batches in flight first"""
         out = np.zeros((max(1, int(max_batches)), _lib.BATCH_LOG_FIELDS), dtype=np.int64)
         n = C.c_int32(0)

@@ -9,6 +9,7 @@
 // document receives its additions in exactly the reference's order -> bit-identical float64 scores.
 // Then max-normalisation (scores / max when max > 0) as bm25_scores does.
 #include <algorithm>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -111,6 +112,133 @@ __global__ __launch_bounds__(1024) void k_bm25(Bm25Params p) {
         sc[doc] = v / mx;
       }
     }
+  }
+}
+
+// ---- the same scoring split over DOCUMENT RANGES (round 4) -------------------------------------------------------
+// k_bm25 walks a query with ONE workgroup — a barrier per token, the longest query of the batch sets the time (0.95 ms
+// per 200 common-term queries at 1 M notes).  A document's additions only have to stay in token order among THEMSELVES:
+// workgroup (q, r) owns the documents [r N / R, (r + 1) N / R), bisects every posting list of its query to that range once
+// (all tokens' bisections run side by side, their bounds kept in LDS) and walks the tokens in order over its slice —
+// the same additions to every document in the same order, so the same float64 bits.  The row maximum meets in one
+// ordered 64-bit atomic per workgroup; a second launch divides the touched documents (or the whole slice of a query
+// whose postings cover the corpus) exactly as k_bm25 does.
+__device__ __forceinline__ unsigned long long bm_d2ord(double v) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double bm_ord2d(unsigned long long o) {
+  return __longlong_as_double((long long)((o >> 63) ? (o & 0x7fffffffffffffffull) : ~o));
+}
+constexpr int kBmMaxTok = 512;  // tokens of a query whose slice bounds fit the workgroup's table (longer: bisected in place)
+
+struct Bm25RangeParams {
+  Bm25Params b;
+  int n_ranges;
+  unsigned long long *max_ord;  // [nq], zeroed: ordered image of the largest touched score (0 = none)
+};
+
+__device__ __forceinline__ int64_t bm_lower(const int32_t *docs, int64_t a, int64_t b, int64_t doc) {
+  while (a < b) {
+    const int64_t mid = (a + b) >> 1;
+    if (docs[mid] < doc) a = mid + 1;
+    else b = mid;
+  }
+  return a;
+}
+
+// slice bounds of every token's posting list for the workgroup's document range: bounds[2 i], bounds[2 i + 1]
+__device__ __forceinline__ void bm_bounds(const Bm25Params &p, int64_t t_lo, int n_tok, int64_t d0, int64_t d1, int64_t *bounds) {
+  for (int i = threadIdx.x; i < 2 * n_tok; i += blockDim.x) {
+    const int term = p.q_terms[t_lo + (i >> 1)];
+    bounds[i] = bm_lower(p.docs, p.indptr[term], p.indptr[term + 1], (i & 1) ? d1 : d0);
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void k_bm25_range_add(Bm25RangeParams rp) {
+  const Bm25Params &p = rp.b;
+  __shared__ int64_t s_bounds[2 * kBmMaxTok];
+  __shared__ double s_red[16];
+  const int q = blockIdx.x, r = blockIdx.y, tid = threadIdx.x;
+  const int64_t d0 = p.n_docs * r / rp.n_ranges, d1 = p.n_docs * (r + 1) / rp.n_ranges;
+  const int64_t t_lo = p.q_indptr[q], t_hi = p.q_indptr[q + 1];
+  double *sc = p.scores + (int64_t)q * p.n_docs;
+  int64_t touched_all = 0;  // postings of the whole query (every workgroup of the query sees the same figure)
+  for (int64_t t = t_lo; t < t_hi; ++t) touched_all += p.indptr[p.q_terms[t] + 1] - p.indptr[p.q_terms[t]];
+  for (int64_t tb = t_lo; tb < t_hi; tb += kBmMaxTok) {
+    const int n_tok = (int)(t_hi - tb < kBmMaxTok ? t_hi - tb : kBmMaxTok);
+    bm_bounds(p, tb, n_tok, d0, d1, s_bounds);
+    for (int i = 0; i < n_tok; ++i) {
+      const int64_t lo = s_bounds[2 * i], hi = s_bounds[2 * i + 1];
+      for (int64_t e = lo + tid; e < hi; e += 1024) atomicAdd(sc + p.docs[e], p.weights[e]);
+      __syncthreads();  // token order == the reference's addition order
+    }
+  }
+  if (!p.normalize && !p.max_out) return;
+  __threadfence_block();
+  // this slice's share of the row maximum: its touched documents, or every document of the slice when the query's postings
+  // cover the corpus (no document is then known to have kept its 0.0)
+  double m = -__builtin_inf();
+  if (touched_all < p.n_docs) {
+    for (int64_t tb = t_lo; tb < t_hi; tb += kBmMaxTok) {
+      const int n_tok = (int)(t_hi - tb < kBmMaxTok ? t_hi - tb : kBmMaxTok);
+      if (t_hi - t_lo > kBmMaxTok) bm_bounds(p, tb, n_tok, d0, d1, s_bounds);  // (one block of tokens: the table is still valid)
+      for (int i = 0; i < n_tok; ++i)
+        for (int64_t e = s_bounds[2 * i] + tid; e < s_bounds[2 * i + 1]; e += 1024)
+          m = fmax(m, __hip_atomic_load(sc + p.docs[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      if (t_hi - t_lo > kBmMaxTok) __syncthreads();
+    }
+  } else {
+    for (int64_t d = d0 + tid; d < d1; d += 1024) m = fmax(m, __hip_atomic_load(sc + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  }
+  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+  if ((tid & 63) == 0) s_red[tid >> 6] = m;
+  __syncthreads();
+  if (tid == 0) {
+    double mm = s_red[0];
+    for (int w = 1; w < 16; ++w) mm = fmax(mm, s_red[w]);
+    if (mm > -__builtin_inf()) atomicMax(rp.max_ord + q, bm_d2ord(mm));
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_bm25_range_norm(Bm25RangeParams rp) {
+  const Bm25Params &p = rp.b;
+  __shared__ int64_t s_bounds[2 * kBmMaxTok];
+  const int q = blockIdx.x, r = blockIdx.y, tid = threadIdx.x;
+  const int64_t d0 = p.n_docs * r / rp.n_ranges, d1 = p.n_docs * (r + 1) / rp.n_ranges;
+  const int64_t t_lo = p.q_indptr[q], t_hi = p.q_indptr[q + 1];
+  double *sc = p.scores + (int64_t)q * p.n_docs;
+  int64_t touched_all = 0;
+  for (int64_t t = t_lo; t < t_hi; ++t) touched_all += p.indptr[p.q_terms[t] + 1] - p.indptr[p.q_terms[t]];
+  // the row's maximum: the largest touched score, and 0.0 when some document was left untouched (k_bm25's rule)
+  const unsigned long long mo = rp.max_ord[q];
+  double mx = mo ? bm_ord2d(mo) : -__builtin_inf();
+  if (touched_all < p.n_docs) mx = fmax(mx, 0.0);
+  const bool divide = p.normalize && mx > 0.0;
+  if (tid == 0 && r == 0 && p.max_out) p.max_out[q] = divide ? 1.0 : mx;
+  if (!divide) return;
+  if (touched_all >= p.n_docs) {
+    for (int64_t d = d0 + tid; d < d1; d += 1024) sc[d] = sc[d] / mx;
+    return;
+  }
+  // divide every touched document of the slice ONCE: at its first occurrence among the query's tokens
+  for (int64_t tb = t_lo; tb < t_hi; tb += kBmMaxTok) {
+    const int n_tok = (int)(t_hi - tb < kBmMaxTok ? t_hi - tb : kBmMaxTok);
+    bm_bounds(p, tb, n_tok, d0, d1, s_bounds);
+    for (int i = 0; i < n_tok; ++i) {
+      for (int64_t e = s_bounds[2 * i] + tid; e < s_bounds[2 * i + 1]; e += 1024) {
+        const int32_t doc = p.docs[e];
+        bool first = true;
+        for (int64_t u = t_lo; u < tb + i && first; ++u) {
+          const int tu = p.q_terms[u];
+          const int64_t a = bm_lower(p.docs, p.indptr[tu], p.indptr[tu + 1], doc);
+          first = !(a < p.indptr[tu + 1] && p.docs[a] == doc);
+        }
+        if (first) sc[doc] = sc[doc] / mx;
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -299,6 +427,9 @@ struct anr_bm25 {
   int64_t q_cap = 0;
   double *score_buf = nullptr;
   int64_t score_cap = 0;
+  unsigned long long *max_ord = nullptr;  // [max_ord_cap] row maxima of the range-split scoring (ordered images)
+  int64_t max_ord_cap = 0;
+  int n_cu = 256;
 };
 
 namespace {
@@ -371,8 +502,29 @@ int score_chunk(anr_bm25 *h, int64_t nq, const int64_t *q_indptr, const int32_t 
   hipError_t e = hipMemsetAsync(*d_scores, 0, (size_t)nq * h->n_docs * 8, h->stream);
   if (e == hipSuccess) {
     Bm25Params p{h->indptr, h->docs, h->weights, h->n_docs, dq, dt, *d_scores, normalize, max_into};
-    hipLaunchKernelGGL(k_bm25, dim3((unsigned)nq), dim3(1024), 0, h->stream, p);
-    e = hipGetLastError();
+    // document ranges per query: enough workgroups to fill the chip four times over (one query: 32 slices), none for a
+    // corpus too small to be worth slicing
+    int R = (int)std::min<int64_t>(32, std::max<int64_t>(1, ceil_div((int64_t)4 * h->n_cu, nq)));
+    if (h->n_docs < (int64_t)R * 4096) R = (int)std::max<int64_t>(1, h->n_docs / 4096);
+    if (R <= 1 || nq > 65535 || getenv("ANORAG_BM25_ONE_WG")) {
+      hipLaunchKernelGGL(k_bm25, dim3((unsigned)nq), dim3(1024), 0, h->stream, p);
+      e = hipGetLastError();
+    } else {
+      if (h->max_ord_cap < nq) {
+        b_free(h->max_ord);
+        h->max_ord_cap = 0;
+        ANR_TRY(b_alloc(&h->max_ord, nq));
+        h->max_ord_cap = nq;
+      }
+      e = hipMemsetAsync(h->max_ord, 0, (size_t)nq * 8, h->stream);
+      Bm25RangeParams rp{p, R, h->max_ord};
+      if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_bm25_range_add, dim3((unsigned)nq, (unsigned)R), dim3(1024), 0, h->stream, rp);
+        if (normalize || max_into)
+          hipLaunchKernelGGL(k_bm25_range_norm, dim3((unsigned)nq, (unsigned)R), dim3(1024), 0, h->stream, rp);
+        e = hipGetLastError();
+      }
+    }
   }
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);  // (also: `rel` may go out of scope)
   if (e != hipSuccess) return fail(ANR_EHIP, "bm25 scoring failed: %s", hipGetErrorString(e));
@@ -408,6 +560,7 @@ int anr_bm25_create(int32_t device, int64_t n_docs, int64_t n_terms, const int64
   h->n_terms = n_terms;
   h->nnz = nnz;
   int rc = ANR_OK;
+  h->n_cu = device_cu_count(device);
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) rc = fail(ANR_EHIP, "hipStreamCreate failed");
   if (rc == ANR_OK) rc = b_alloc(&h->indptr, n_terms + 1);
   if (rc == ANR_OK) rc = b_alloc(&h->docs, nnz);
@@ -434,6 +587,7 @@ int anr_bm25_destroy(anr_bm25 *h) {
   b_free(h->docs);
   b_free(h->weights);
   b_free(h->q_buf);
+  b_free(h->max_ord);
   b_free(h->score_buf);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;

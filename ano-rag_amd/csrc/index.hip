@@ -59,6 +59,7 @@ struct Workspace {
   unsigned *cnt_dev = nullptr;     // the same memory as the device addresses it
   unsigned long long *stamps = nullptr;  // [kStamps] device time stamps of the batch's kernels (index_kernels.hpp)
   int64_t t_enq0 = 0, t_enq1 = 0;  // host clock (ns) when the batch's enqueue began / returned
+  int64_t log_slot = -1;           // the batch's record in the handle's batch log (recovery time is added to it)
   int64_t seq = 0;
   bool shadow = false;             // the batch's side kernels were the shadow-sized ones
   hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
@@ -561,6 +562,8 @@ int retire(anr_index *h, Workspace &w) {
       rec[3] = host_ns();
       for (int i = 0; i < kStamps; ++i) rec[4 + i] = (int64_t)((double)stp[i] * 1e6 / (double)h->clock_khz);
       rec[4 + kStamps] = (w.shadow ? 1 : 0) | ((int64_t)w.nq << 8);
+      rec[5 + kStamps] = 0;
+      w.log_slot = h->batch_log_n % kBatchLogCap;
       h->batch_log_n += 1;
     }
     if (!w.exact_all) {
@@ -581,6 +584,7 @@ int retire(anr_index *h, Workspace &w) {
     h->stats.n_fallback += (int64_t)fallback.size();
   }
   if (!fallback.empty()) {
+    const int64_t t_rec0 = host_ns();
     std::vector<int> dense;
     if (w.sparse && !w.exact_all) ANR_TRY(run_second_pass(h, w, fallback, &dense));
     else dense = fallback;
@@ -588,7 +592,10 @@ int retire(anr_index *h, Workspace &w) {
       h->stats.n_dense_exact += (int64_t)dense.size();
       ANR_TRY(run_exact(h, w, dense));
     }
+    if (w.log_slot >= 0 && !h->batch_log.empty())  // host time of the recovery passes (synchronous, on the index's own stream)
+      h->batch_log[(size_t)w.log_slot * kBatchLogFields + 5 + kStamps] += host_ns() - t_rec0;
   }
+  w.log_slot = -1;
   w.in_flight = false;
   return ANR_OK;
 }

@@ -279,7 +279,8 @@ def pipeline_leg(rows, dim, batch, k, dev, seed, steps=60, warmup=10, serial=20,
             first = np.sort(rec[:, 7])                                    # first workgroup of each main scan, device clock
             per = np.diff(first) / 1e3
             diag.append({"max_host_enqueue_gap_us": float(host.max()), "max_device_scan_to_scan_us": float(per.max()),
-                         "median_device_scan_to_scan_us": float(np.median(per))})
+                         "median_device_scan_to_scan_us": float(np.median(per)),
+                         "host_recovery_ms_per_batch": float(rec[:, 13].mean()) / 1e6})
     st = idx.last_stats()
     ms_k, bytes_k = serial_kernel_time(idx, Q, nb, serial, batch, k, D[0].data_ptr(), I[0].data_ptr(), S[0].cuda_stream)
     idx.close()

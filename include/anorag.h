@@ -180,9 +180,10 @@ int anr_index_reset_stats(anr_index *h);
  *   [7] first / [8] last workgroup of the main scan started  [9] end of the main scan  [10] end of the candidate select
  *   [11] end of the batch's last kernel
  *   [12] bit 0: shadow-sized side kernels; bits 8..: queries in the batch
+ *   [13] host time (ns) the batch's recovery passes took at its retire (0: every certificate held)
  * (fused post kernel: [10] is 0).  *dev_minus_host_ns (may be NULL) receives an estimate of device clock - host clock,
  * good to a few microseconds, so that the two sets of times can be laid on one axis. */
-#define ANR_BATCH_LOG_FIELDS 13
+#define ANR_BATCH_LOG_FIELDS 14
 int anr_index_batch_log(anr_index *h, int64_t *out, int32_t max_batches, int32_t *n_out, int64_t *dev_minus_host_ns);
 
 /* In-place row normalisation on host memory through the device (vector_index.py:276-280): rows with

@@ -652,5 +652,16 @@ def test_compute_similarity_and_find_most_similar_match_the_reference():
     for c in g["find_most_similar"]:
         got = em.find_most_similar(_arr(c["query"]), _arr(c["candidates"]), top_k=c["top_k"], metric=c["metric"])
         name = f'{c["name"]}/{c["metric"]}'
-        assert [h["index"] for h in got] == [h["index"] for h in c["expected"]], name
-        _same(got, c["expected"], 2e-6 * max([1.0] + [abs(h["similarity"]) for h in c["expected"]]), name)
+        exp = c["expected"]
+        tol = 2e-6 * max([1.0] + [abs(h["similarity"]) for h in exp])
+        assert len(got) == len(exp) and all(list(h) == ["index", "similarity"] for h in got), name
+        # same similarities position by position; the same indices, in the same order EXCEPT among candidates whose reference
+        # similarities agree to within the tolerance: the reference's float32 BLAS product gives duplicated candidate rows
+        # values an ulp apart (fixture "ties/dot": 1 before 4 but 5 before 2 before 0), which no other arithmetic reproduces
+        assert sorted(h["index"] for h in got) == sorted(h["index"] for h in exp), name
+        where = {h["index"]: h["similarity"] for h in exp}
+        for g, e in zip(got, exp):
+            assert abs(g["similarity"] - e["similarity"]) <= tol, name
+            assert g["index"] == e["index"] or abs(where[g["index"]] - e["similarity"]) <= tol, name
+        if c["name"] == "ties" and c["metric"] == "cosine":   # exact ties (normalised duplicates): numpy's reversed ascending order
+            assert [h["index"] for h in got][:3] == [h["index"] for h in exp][:3], name

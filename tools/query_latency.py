@@ -32,6 +32,25 @@ for q in qs[300:]:
     te += t1 - t0; ts += t2 - t1
 n = len(qs) - 300
 print(f"device: encode_queries {1e6*te/n:.0f} us + VectorIndex.search(top_k={K}, {N} x 768) {1e6*ts/n:.0f} us = {1e6*(te+ts)/n:.0f} us per query")
+# the reference's worker threads (main_musique.py:487-494): 8 threads, one question per call, sharing the model — the
+# encoder's combining queue merges the calls that arrive while a forward runs
+import threading
+def burst(nthreads, work):
+    def w(k):
+        for q in work[k::nthreads]:
+            one(q)
+    th = [threading.Thread(target=w, args=(k,)) for k in range(nthreads)]
+    t0 = time.perf_counter()
+    for t in th: t.start()
+    for t in th: t.join()
+    return time.perf_counter() - t0
+work = qs * 2
+burst(8, work[:160])
+t1 = burst(1, work)
+t8 = burst(8, work)
+cb = em.model._combiner
+print(f"threads: encode_queries + search, {len(work)} questions: 1 thread {1e6*t1/len(work):.0f} us per question, 8 threads "
+      f"{1e6*t8/len(work):.0f} us per question ({t1/t8:.1f}x); {cb.served/max(1,cb.forwards):.1f} questions per forward over the run")
 xn = orc.preprocess_vectors(x)
 prefix = "Represent this sentence for searching relevant passages: "
 # the host path with the model loaded ONCE (oracle.encoder.encode reloads it per call): the same float32 pipeline
