@@ -18,6 +18,61 @@ from ._lib import FuseDenseStats, FuseSource
 SOURCES = ("dense", "bm25", "graph", "path")
 
 
+class _DevicePool:
+    """Device buffers of the per-call objects below are kept and handed out again.  ``hipFree`` synchronises the device
+    and costs ~0.5-1 ms apiece: the four buffers of a ``SparseRows`` made and freed around every ``fuse_bm25`` call were
+    4 ms of a 9-ms call (cProfile, tools/bm25_fuse_perf.py, round 4).  Exact-size reuse; at most ``keep_bytes`` idle per
+    device, the oldest idle buffers go first."""
+
+    def __init__(self, keep_bytes: int = 6 << 30):
+        import threading
+        self.lock = threading.Lock()
+        self.idle: Dict[Tuple[int, int], List[int]] = {}
+        self.order: List[Tuple[int, int, int]] = []  # (device, nbytes, ptr), oldest first
+        self.idle_bytes: Dict[int, int] = {}
+        self.keep_bytes = int(keep_bytes)
+
+    def take(self, device: int, nbytes: int) -> int:
+        nbytes = max(int(nbytes), 8)
+        with self.lock:
+            lst = self.idle.get((device, nbytes))
+            if lst:
+                ptr = lst.pop()
+                self.order.remove((device, nbytes, ptr))
+                self.idle_bytes[device] -= nbytes
+                return ptr
+        p = C.c_void_p()
+        _lib.check(_lib.load().anr_device_malloc(int(device), nbytes, C.byref(p)), "anr_device_malloc")
+        return p.value
+
+    def give(self, device: int, nbytes: int, ptr: int) -> None:
+        nbytes = max(int(nbytes), 8)
+        drop = []
+        with self.lock:
+            self.idle.setdefault((device, nbytes), []).append(ptr)
+            self.order.append((device, nbytes, ptr))
+            self.idle_bytes[device] = self.idle_bytes.get(device, 0) + nbytes
+            while self.idle_bytes[device] > self.keep_bytes:
+                i = next((k for k, o in enumerate(self.order) if o[0] == device), None)
+                if i is None:
+                    break
+                d, nb, pt = self.order.pop(i)
+                self.idle[(d, nb)].remove(pt)
+                self.idle_bytes[d] -= nb
+                drop.append((d, pt))
+        for d, pt in drop:
+            _lib.load().anr_device_free(d, C.c_void_p(pt))
+
+    def clear(self) -> None:
+        with self.lock:
+            order, self.order, self.idle, self.idle_bytes = self.order, [], {}, {}
+        for d, _, pt in order:
+            _lib.load().anr_device_free(d, C.c_void_p(pt))
+
+
+_pool = _DevicePool()
+
+
 class DeviceArray:
     """[nq, n] float64 / float32 array in device memory (row-major).  ``row_max`` (optional): a [nq, 1] float64
     ``DeviceArray`` holding each row's maximum, set by the producers that know it (``DeviceBM25.scores_device``);
@@ -30,9 +85,7 @@ class DeviceArray:
         if self.dtype not in (np.dtype(np.float64), np.dtype(np.float32)):
             raise ValueError("DeviceArray holds float64 or float32")
         self.nbytes = self.nq * self.n * self.dtype.itemsize
-        p = C.c_void_p()
-        _lib.check(_lib.load().anr_device_malloc(self.device, self.nbytes, C.byref(p)), "anr_device_malloc")
-        self.ptr = p.value
+        self.ptr = _pool.take(self.device, self.nbytes)
 
     @classmethod
     def wrap(cls, ptr: int, nq: int, n: int, dtype=np.float64, device: int = 0, row_max: "DeviceArray" = None) -> "DeviceArray":
@@ -77,7 +130,7 @@ class DeviceArray:
             self.row_max = None
         if getattr(self, "ptr", None):
             if not getattr(self, "_borrowed", False):
-                _lib.load().anr_device_free(self.device, C.c_void_p(self.ptr))
+                _pool.give(self.device, self.nbytes, self.ptr)  # (kept for the next array of this size: see _DevicePool)
             self.ptr = None
 
     def __del__(self):  # pragma: no cover - best effort
@@ -96,11 +149,9 @@ class SparseRows:
     def __init__(self, nq: int, n: int, cap: int, device: int = 0):
         self.nq, self.n, self.cap, self.device = int(nq), int(n), int(cap), int(device)
         self._bufs = []
-        lib = _lib.load()
-        for nbytes in (self.nq * self.cap * 4, self.nq * self.cap * 8, self.nq * 4, self.nq * 8):
-            p = C.c_void_p()
-            _lib.check(lib.anr_device_malloc(self.device, max(nbytes, 8), C.byref(p)), "anr_device_malloc")
-            self._bufs.append(p.value)
+        self._sizes = (self.nq * self.cap * 4, self.nq * self.cap * 8, self.nq * 4, self.nq * 8)
+        for nbytes in self._sizes:
+            self._bufs.append(_pool.take(self.device, nbytes))
         self.ids_ptr, self.scores_ptr, self.count_ptr, self.max_ptr = self._bufs
         self.counts: Optional[np.ndarray] = None  # host copy of the row lengths, when the producer returned them
 
@@ -156,9 +207,9 @@ class SparseRows:
         return out
 
     def free(self) -> None:
-        for b in getattr(self, "_bufs", []):
+        for b, nbytes in zip(getattr(self, "_bufs", []), getattr(self, "_sizes", ())):
             if b:
-                _lib.load().anr_device_free(self.device, C.c_void_p(b))
+                _pool.give(self.device, nbytes, b)
         self._bufs = []
 
     def __del__(self):  # pragma: no cover - best effort

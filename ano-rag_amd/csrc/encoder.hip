@@ -64,6 +64,34 @@ __global__ void k_pack_rows(const float *src, int64_t R, int H, float *out) {
   out[i] = src[row * H + feat_of(kb, h, j)];
 }
 
+// LayerNorm folded into the linear layer that consumes it (EPI_FOLD_GELU): W' = W diag(gamma) as a second operand image, and per
+// output feature, in accumulator order like the bias: s = the row sum of the ROUNDED f16 W' (what the MFMAs multiply the mean
+// component of u with, so that "- mean s" removes exactly that), c = bias + W beta.  One thread per output feature.
+__global__ void k_fold_ln(const _Float16 *w, const float *g, const float *beta, const float *bias_acc, int N, int K, _Float16 *wf,
+                          float *s_acc, float *c_acc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // accumulator-order index: (nb, h, r)
+  if (i >= N) return;
+  const int KB = K / 16;
+  const int nb = i / 32, rem = i % 32, ha = rem / 16, r = rem % 16;
+  const int n_in = (r & 3) + 8 * (r >> 2) + 4 * ha;  // feature within the 32-block (k_pack_bias_acc's map)
+  double ssum = 0.0, csum = 0.0;
+  for (int kb = 0; kb < KB; ++kb)
+    for (int h = 0; h < 2; ++h) {
+      const int64_t e = (((int64_t)nb * KB + kb) * 64 + n_in + 32 * h) * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float wv = (float)w[e + j];
+        const int gi = (kb * 2 + h) * 8 + j;
+        const _Float16 f = (_Float16)(wv * g[gi]);
+        wf[e + j] = f;
+        ssum += (double)(float)f;
+        csum += (double)wv * (double)beta[gi];
+      }
+    }
+  s_acc[i] = (float)ssum;
+  c_acc[i] = (float)((double)bias_acc[i] + csum);
+}
+
 // ---- embeddings + LayerNorm ----------------------------------------------------------------------
 struct EmbedParams {
   const int *ids;      // [B][L]
@@ -215,9 +243,15 @@ struct LnParams {
   _Float16 *act;          // output (may alias x)
 };
 __device__ __forceinline__ void ln_load8(const LnParams &p, int64_t e, float (&v)[8]) {
-  const half8 a = *reinterpret_cast<const half8 *>(p.x + e), d = *reinterpret_cast<const half8 *>(p.delta + e);
+  const half8 a = *reinterpret_cast<const half8 *>(p.x + e);
+  if (p.delta) {
+    const half8 d = *reinterpret_cast<const half8 *>(p.delta + e);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) v[j] = (float)a[j] + (float)d[j];
+    for (int j = 0; j < 8; ++j) v[j] = (float)a[j] + (float)d[j];
+  } else {  // the residual sum was formed by the producing GEMM's epilogue (EPI_RES_LN)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (float)a[j];
+  }
 }
 
 // one workgroup per 32-token block; each of the 4 waves owns a quarter of the feature blocks, keeps it in
@@ -255,7 +289,7 @@ __global__ __launch_bounds__(NW * 64) void k_layernorm(LnParams p) {
   float c0;
   {
     const int64_t e0 = (tb * p.KB * 64 + (lane & 31)) * 8;
-    c0 = (float)p.x[e0] + (float)p.delta[e0];
+    c0 = (float)p.x[e0] + (p.delta ? (float)p.delta[e0] : 0.f);
   }
   const float c = __shfl(c0, lane & 31);
   float s = 0.f, s2 = 0.f;
@@ -337,7 +371,7 @@ __global__ __launch_bounds__(256) void k_layernorm_wave(LnParams p) {
   float c0;
   {
     const int64_t e0 = (tb * p.KB * 64 + (lane & 31)) * 8;
-    c0 = (float)p.x[e0] + (float)p.delta[e0];
+    c0 = (float)p.x[e0] + (p.delta ? (float)p.delta[e0] : 0.f);
   }
   const float c = __shfl(c0, lane & 31);
   float s = 0.f, s2 = 0.f;
@@ -390,7 +424,17 @@ static void launch_layernorm(const LnParams &p, hipStream_t st) {
 }
 
 // ---- GEMM: out[t][n] = sum_k act[t][k] * W[n][k] + bias[n] -------------------------------------------
-enum { EPI_ACT = 0, EPI_GELU = 1, EPI_VT = 3 };
+// EPI_RES_STATS / EPI_FOLD_GELU / EPI_RES_LN (round 4, large forwards): the first LayerNorm of a layer without a pass of
+// its own.  With u = x + attention projection (the un-normalised residual sum):
+//   EPI_RES_STATS  (output projection)  u = f16(x + acc + bias), and per token the sum and the sum of squares of ITS
+//                  slice of u (the workgroup tile's columns) into a partial-statistics buffer — one slot per column tile,
+//                  summed by the readers in slot order (no atomics: the bits do not depend on timing);
+//   EPI_FOLD_GELU  (FFN up) consumes u itself: LN(u) W^T + b = rstd (u W'^T - mean s) + c with W' = W diag(gamma)
+//                  folded once when the weights are finalised, s = the row sums of the f16 W', c = b + W beta;
+//   EPI_RES_LN     (FFN down) rebuilds the residual it needs, LN(u) = (u - mean) rstd gamma + beta, from u and the same
+//                  statistics, adds its projection and writes the sum for the layer's second LayerNorm (one input).
+enum { EPI_ACT = 0, EPI_GELU = 1, EPI_VT = 3, EPI_RES_STATS = 4, EPI_FOLD_GELU = 5, EPI_RES_LN = 6 };
+constexpr int kStatSlots = 6;  // column tiles of a 768-wide output at the narrowest tile (TN = 4)
 
 struct GemmParams {
   const uint4 *act;   // [TB][KB][64]
@@ -400,7 +444,29 @@ struct GemmParams {
   const float *bias_acc;  // [NB][2][16] (token-on-lane epilogues)
   const float *bias;      // [N] plain (EPI_VT)
   _Float16 *out;          // EPI_ACT / EPI_GELU: [TB][NB*2][64][8]; EPI_VT: [NB][TB*2][64][8]
+  // round 4 (see the EPI list above)
+  const _Float16 *resid;  // EPI_RES_STATS: x; EPI_RES_LN: u (same layout as out; may alias out)
+  float *stats_out;       // EPI_RES_STATS: [TB * 32][kStatSlots][2] partial (sum, sum of squares) of u
+  const float *stats_in;  // EPI_FOLD_GELU / EPI_RES_LN: the same buffer, stat_slots slots filled
+  int stat_slots;         // column tiles the producer of stats_in had
+  int stat_h;             // features the statistics are over (the hidden size)
+  float ln_eps;
+  const float *ln_g, *ln_b;    // EPI_RES_LN: gamma / beta, blocked order [KB][2][8]
+  const float *fold_s;         // EPI_FOLD_GELU: row sums of the folded f16 weights, accumulator order like bias_acc
 };
+
+// per-lane LayerNorm statistics of token (tb, lane & 31) from the partial sums
+__device__ __forceinline__ void gemm_token_stats(const GemmParams &p, int64_t tb, int lane, float &mean, float &rstd) {
+  const float *st = p.stats_in + ((tb * 32 + (lane & 31)) * kStatSlots) * 2;
+  float s = 0.f, q = 0.f;
+  for (int i = 0; i < p.stat_slots; ++i) {
+    s += st[2 * i];
+    q += st[2 * i + 1];
+  }
+  mean = s / p.stat_h;
+  const float var = fmaxf(q / p.stat_h - mean * mean, 0.f);
+  rstd = rsqrtf(var + p.ln_eps);
+}
 
 // gelu(x) = 0.5 x (1 + erf(x / sqrt 2)); erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the f16
 // the value is stored in) — the libm erff costs as much as the GEMM's MFMAs at K = 768
@@ -458,6 +524,54 @@ __device__ __forceinline__ void gemm_store_tile(const GemmParams &p, const float
       for (int j = 0; j < 8; ++j) hv[j] = (_Float16)(EPI == EPI_GELU ? gelu_poly(o[j]) : o[j]);
       *reinterpret_cast<half8 *>(p.out + e) = hv;
     }
+  }
+}
+
+// the round-4 epilogues of one 32 x 32 accumulator tile; mean / rstd: the lane's token (EPI_FOLD_GELU, EPI_RES_LN); ssum /
+// qsum: the lane's running sums over the values it writes (EPI_RES_STATS)
+template <int EPI>
+__device__ __forceinline__ void gemm_store_tile_ln(const GemmParams &p, const floatx16 &c, int64_t tb, int nb, int lane, float mean,
+                                                   float rstd, float &ssum, float &qsum) {
+  const int h = lane >> 5;
+  const float *ba = p.bias_acc + ((int64_t)nb * 2 + h) * 16;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int64_t e = ((tb * (p.NB * 2) + nb * 2 + s) * 64 + lane) * 8;
+    float o[8];
+    half8 hv;
+    if (EPI == EPI_FOLD_GELU) {
+      const float *fs = p.fold_s + ((int64_t)nb * 2 + h) * 16;
+      const float ms = mean * rstd;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = gelu_poly(fmaf(c[8 * s + j], rstd, fmaf(-ms, fs[8 * s + j], ba[8 * s + j])));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) hv[j] = (_Float16)o[j];
+    } else {
+      const half8 r = *reinterpret_cast<const half8 *>(p.resid + e);
+      if (EPI == EPI_RES_LN) {
+        const int gi = ((nb * 2 + s) * 2 + h) * 8;  // blocked order of the 8 features this lane holds
+        const float4 g0 = *reinterpret_cast<const float4 *>(p.ln_g + gi), g1 = *reinterpret_cast<const float4 *>(p.ln_g + gi + 4);
+        const float4 b0 = *reinterpret_cast<const float4 *>(p.ln_b + gi), b1 = *reinterpret_cast<const float4 *>(p.ln_b + gi + 4);
+        const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (((float)r[j] - mean) * rstd * gg[j] + bb[j]) + (c[8 * s + j] + ba[8 * s + j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (float)r[j] + (c[8 * s + j] + ba[8 * s + j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) hv[j] = (_Float16)o[j];
+      if (EPI == EPI_RES_STATS) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {  // statistics of the ROUNDED values: what the readers of u will see
+          const float v = (float)hv[j];
+          ssum += v;
+          qsum = fmaf(v, v, qsum);
+        }
+      }
+    }
+    *reinterpret_cast<half8 *>(p.out + e) = hv;
   }
 }
 
@@ -844,6 +958,46 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmParams p, PatchGrid pg, int
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int n = 0; n < NW; ++n) gemm_keep(acc[m][n]);
+    } else if (EPI == EPI_RES_STATS || EPI == EPI_FOLD_GELU || EPI == EPI_RES_LN) {
+      __shared__ float s_part[2][4][2][32][2];  // [feature half wn][token pair wm][m][token][sum, sum of squares]
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int64_t tb = (int64_t)cm * TM + 2 * wm + m;
+        float mean = 0.f, rstd = 1.f, ssum = 0.f, qsum = 0.f;
+        if (EPI != EPI_RES_STATS && tb < p.TB) gemm_token_stats(p, tb, lane, mean, rstd);
+#pragma unroll
+        for (int n = 0; n < NW; ++n) {
+          const int nb = cn * TN + NW * wn + n;
+          if (tb < p.TB && nb < p.NB) gemm_store_tile_ln<EPI>(p, acc[m][n], tb, nb, lane, mean, rstd, ssum, qsum);
+        }
+        if (EPI == EPI_RES_STATS) {
+          ssum += __shfl_xor(ssum, 32);
+          qsum += __shfl_xor(qsum, 32);
+          if (lane < 32) {
+            s_part[wn][wm][m][lane][0] = ssum;
+            s_part[wn][wm][m][lane][1] = qsum;
+          }
+        }
+      }
+      if (EPI == EPI_RES_STATS) {
+        // the two waves that share a token pair hold its two feature halves: meet in LDS (no vmcnt wait: the next tile's
+        // operand copies stay in flight), wave (wm, 0) writes the tile's slot
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (wn == 0 && lane < 32) {
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            const int64_t tb = (int64_t)cm * TM + 2 * wm + m;
+            if (tb < p.TB) {
+              float *st = p.stats_out + (((tb * 32 + lane) * kStatSlots) + cn) * 2;
+              st[0] = s_part[0][wm][m][lane][0] + s_part[1][wm][m][lane][0];
+              st[1] = s_part[0][wm][m][lane][1] + s_part[1][wm][m][lane][1];
+            }
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // s_part is free for the next tile
+      }
     } else {
 #pragma unroll
       for (int m = 0; m < 2; ++m)
@@ -1233,6 +1387,8 @@ using namespace anr;
 
 // ====================================================================================================
 struct LayerW {
+  _Float16 *w1f = nullptr;                   // W1 diag(ln1 gamma): the FFN-up operand of the folded path
+  float *f1s = nullptr, *f1c = nullptr;      // its row sums and folded bias, accumulator order
   _Float16 *wqk = nullptr, *wv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr;
   float *bqk = nullptr, *bv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;  // bqk/bo/b1/b2 in acc order
   float *ln1g = nullptr, *ln1b = nullptr, *ln2g = nullptr, *ln2b = nullptr;          // blocked
@@ -1261,6 +1417,8 @@ struct anr_encoder {
   float *res = nullptr, *out = nullptr;  // res: the last LayerNorm's output in f32 (pooling input)
   _Float16 *act = nullptr, *delta = nullptr, *qk = nullptr, *vt = nullptr, *ctx = nullptr, *ffn = nullptr;
   _Float16 *big = nullptr;  // the block qk / vt / ctx / ffn point into
+  float *stats = nullptr;   // [tokens][kStatSlots][2] partial LayerNorm statistics of the folded path
+  int fold_ln = 0;          // large forwards: first LayerNorm of a layer folded into the GEMMs around it (ANORAG_ENC_FOLD=1: on)
 };
 
 namespace {
@@ -1363,6 +1521,21 @@ bool use_skinny(const GemmParams &g) {
   return !simple && g.KB % ANR_GEMM_S == 0 && !no_skinny && g.TB <= skinny_max && g.KB % 4 == 0;
 }
 
+// does this GEMM run on the 8-wave ping-pong tile kernel, and with which tile width (32 TN features)?
+bool pp_tile(const anr_encoder *e, const GemmParams &g, int *tn_out) {
+  static const bool simple = getenv("ANORAG_GEMM_SIMPLE") != nullptr;
+  static const bool wide = getenv("ANORAG_GEMM_NARROW") == nullptr;  // developer switch: the 4-wave tile everywhere
+  if (simple || g.KB % ANR_GEMM_S || use_skinny(g) || !(wide && g.KB % 2 == 0 && g.TB >= 8 * 16)) return false;
+  // tile width by grid shape: fewest rounds of workgroups over the CUs, weighted by the work per workgroup.  The
+  // 128-wide tile exists for mid-sized inputs (8 K tokens x N = 768: 96 / 128 / 192 tiles at width 256 / 192 / 128 on
+  // 256 CUs — one round each way, so the narrowest tile, which spreads the same work over the most CUs, wins).
+  const int64_t rt = ceil_div(g.TB, 8);
+  const int64_t b8 = rt * ceil_div(g.NB, 8), b6 = rt * ceil_div(g.NB, 6), b4 = rt * ceil_div(g.NB, 4);
+  const int64_t cost8 = ceil_div(b8, e->n_cu) * 8, cost6 = ceil_div(b6, e->n_cu) * 6, cost4 = ceil_div(b4, e->n_cu) * 4;
+  if (tn_out) *tn_out = (cost4 < cost6 && cost4 < cost8) ? 4 : (cost6 < cost8 ? 6 : 8);
+  return true;
+}
+
 template <int EPI>
 void launch_gemm(anr_encoder *e, GemmParams &g) {
   static const bool simple = getenv("ANORAG_GEMM_SIMPLE") != nullptr;  // developer switch: the LDS-free kernel
@@ -1377,19 +1550,15 @@ void launch_gemm(anr_encoder *e, GemmParams &g) {
     hipLaunchKernelGGL((k_gemm_skinny<EPI>), dim3((unsigned)blocks), dim3(256), 0, e->stream, g);
     return;
   }
-  static const bool wide = getenv("ANORAG_GEMM_NARROW") == nullptr;  // developer switch: the 4-wave tile everywhere
-  if (wide && g.KB % 2 == 0 && g.TB >= 8 * 16) {
-    // tile width by grid shape: fewest rounds of workgroups over the CUs, weighted by the work per workgroup.  The
-    // 128-wide tile exists for mid-sized inputs (8 K tokens x N = 768: 96 / 128 / 192 tiles at width 256 / 192 / 128 on
-    // 256 CUs — one round each way, so the narrowest tile, which spreads the same work over the most CUs, wins).
-    const int64_t rt = ceil_div(g.TB, 8);
-    const int64_t b8 = rt * ceil_div(g.NB, 8), b6 = rt * ceil_div(g.NB, 6), b4 = rt * ceil_div(g.NB, 4);
-    const int64_t cost8 = ceil_div(b8, e->n_cu) * 8, cost6 = ceil_div(b6, e->n_cu) * 6, cost4 = ceil_div(b4, e->n_cu) * 4;
-    if (cost4 < cost6 && cost4 < cost8) launch_gemm8<EPI, 4>(e, g, b4);
-    else if (cost6 < cost8) launch_gemm8<EPI, 6>(e, g, b6);
-    else launch_gemm8<EPI, 8>(e, g, b8);
+  int tn = 0;
+  if (pp_tile(e, g, &tn)) {
+    const int64_t blocks = ceil_div(g.TB, 8) * ceil_div(g.NB, tn);
+    if (tn == 4) launch_gemm8<EPI, 4>(e, g, blocks);
+    else if (tn == 6) launch_gemm8<EPI, 6>(e, g, blocks);
+    else launch_gemm8<EPI, 8>(e, g, blocks);
     return;
   }
+  if (EPI == EPI_RES_STATS || EPI == EPI_FOLD_GELU || EPI == EPI_RES_LN) return;  // (only ever launched on the 8-wave tile kernel)
   const int64_t blocks = ceil_div(g.TB, 4) * ceil_div(g.NB, 8);
   constexpr int lds_bytes = 3 * ANR_GEMM_S * 12 * 1024;
   if (lds_bytes > 64 * 1024) (void)ensure_dynamic_lds(reinterpret_cast<const void *>(&k_gemm_lds<EPI>), lds_bytes);
@@ -1405,6 +1574,8 @@ int ensure_ws(anr_encoder *e, int B, int L, int Lp) {
     enc_free(e->act);
     enc_free(e->big);
     e->qk = e->vt = e->ctx = e->ffn = nullptr;
+    enc_free(e->stats);
+    ANR_TRY(enc_alloc(&e->stats, T * kStatSlots * 2));
     ANR_TRY(enc_alloc(&e->res, T * c.hidden));
     ANR_TRY(enc_alloc(&e->delta, T * c.hidden));
     ANR_TRY(enc_alloc(&e->act, T * c.hidden));
@@ -1491,11 +1662,13 @@ int anr_encoder_destroy(anr_encoder *e) {
     enc_free(l.wqk); enc_free(l.wv); enc_free(l.wo); enc_free(l.w1); enc_free(l.w2);
     enc_free(l.bqk); enc_free(l.bv); enc_free(l.bo); enc_free(l.b1); enc_free(l.b2);
     enc_free(l.ln1g); enc_free(l.ln1b); enc_free(l.ln2g); enc_free(l.ln2b);
+    enc_free(l.w1f); enc_free(l.f1s); enc_free(l.f1c);
   }
   enc_free(e->d_in);
   if (e->pin_in) (void)hipHostFree(e->pin_in);
   if (e->pin_out) (void)hipHostFree(e->pin_out);
-  enc_free(e->res); enc_free(e->delta); enc_free(e->out);
+  enc_free(e->res); enc_free(e->stats);
+  enc_free(e->delta); enc_free(e->out);
   enc_free(e->act); enc_free(e->big);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
@@ -1562,6 +1735,21 @@ int anr_encoder_finalize(anr_encoder *e) {
   for (size_t li = 0; li < e->layers.size(); ++li)
     for (int i = 0; i < 16; ++i)
       if (!e->layers[li].have[i]) return fail(ANR_ESTATE, "layer %zu: tensor slot %d was not set", li, i);
+  {  // the folded FFN-up operands (EPI_FOLD_GELU)
+    DeviceGuard g(e->device);
+    const int H = e->cfg.hidden, I = e->cfg.intermediate;
+    for (auto &l : e->layers) {
+      if (!l.w1f) ANR_TRY(enc_alloc(&l.w1f, (int64_t)I * H));
+      if (!l.f1s) ANR_TRY(enc_alloc(&l.f1s, I));
+      if (!l.f1c) ANR_TRY(enc_alloc(&l.f1c, I));
+      hipLaunchKernelGGL(k_fold_ln, dim3((unsigned)ceil_div(I, 64)), dim3(64), 0, e->stream, l.w1, l.ln1g, l.ln1b, l.b1, I, H, l.w1f,
+                         l.f1s, l.f1c);
+    }
+    ANR_HIP(hipGetLastError());
+    ANR_HIP(hipStreamSynchronize(e->stream));
+    // OFF by default: measured SLOWER than the LayerNorm pass it removes (3.72 vs 3.67 ms per 256 x 64 forward)
+    e->fold_ln = getenv("ANORAG_ENC_FOLD") ? atoi(getenv("ANORAG_ENC_FOLD")) : 0;
+  }
   e->finalized = true;
   return ANR_OK;
 }
@@ -1637,16 +1825,36 @@ void enqueue_forward(anr_encoder *e, int B, int L, int Lp, bool use_types, int n
     GemmParams go{};
     go.act = reinterpret_cast<const uint4 *>(e->ctx); go.w = reinterpret_cast<const uint4 *>(l.wo);
     go.TB = TB; go.NB = H / 32; go.KB = KB; go.bias_acc = l.bo; go.out = e->delta;
-    launch_gemm<EPI_ACT>(e, go);
-    LnParams l1{e->act, e->delta, TB, H, KB, l.ln1g, l.ln1b, c.ln_eps, nullptr, e->act};
-    launch_layernorm(l1, st);
     GemmParams g1{};
     g1.act = reinterpret_cast<const uint4 *>(e->act); g1.w = reinterpret_cast<const uint4 *>(l.w1);
     g1.TB = TB; g1.NB = I / 32; g1.KB = KB; g1.bias_acc = l.b1; g1.out = e->ffn;
-    launch_gemm<EPI_GELU>(e, g1);
     GemmParams g2{};
     g2.act = reinterpret_cast<const uint4 *>(e->ffn); g2.w = reinterpret_cast<const uint4 *>(l.w2);
     g2.TB = TB; g2.NB = H / 32; g2.KB = I / 16; g2.bias_acc = l.b2; g2.out = e->delta;
+    // Large forwards (all three GEMMs on the 8-wave tile kernel): the layer's FIRST LayerNorm has no pass of its own —
+    // the output projection writes u = x + projection and its per-token partial sums, FFN-up consumes u through the folded
+    // weights, FFN-down rebuilds LN(u) for its residual and writes the sum the second LayerNorm reads alone (EPI list above).
+    int tn_o = 0;
+    const bool fold = e->fold_ln && pp_tile(e, go, &tn_o) && pp_tile(e, g1, nullptr) && pp_tile(e, g2, nullptr) &&
+                      ceil_div(go.NB, tn_o) <= kStatSlots;
+    if (fold) {
+      go.resid = e->act; go.stats_out = e->stats; go.stat_h = H;
+      launch_gemm<EPI_RES_STATS>(e, go);  // delta <- u
+      g1.act = reinterpret_cast<const uint4 *>(e->delta); g1.w = reinterpret_cast<const uint4 *>(l.w1f);
+      g1.bias_acc = l.f1c; g1.fold_s = l.f1s;
+      g1.stats_in = e->stats; g1.stat_slots = (int)ceil_div(go.NB, tn_o); g1.stat_h = H; g1.ln_eps = c.ln_eps;
+      launch_gemm<EPI_FOLD_GELU>(e, g1);
+      g2.resid = e->delta; g2.stats_in = e->stats; g2.stat_slots = g1.stat_slots; g2.stat_h = H; g2.ln_eps = c.ln_eps;
+      g2.ln_g = l.ln1g; g2.ln_b = l.ln1b;
+      launch_gemm<EPI_RES_LN>(e, g2);     // delta <- LN1(u) + projection, in place
+      LnParams l2{e->delta, nullptr, TB, H, KB, l.ln2g, l.ln2b, c.ln_eps, li + 1 == c.n_layers ? e->res : nullptr, e->act};
+      launch_layernorm(l2, st);
+      continue;
+    }
+    launch_gemm<EPI_ACT>(e, go);
+    LnParams l1{e->act, e->delta, TB, H, KB, l.ln1g, l.ln1b, c.ln_eps, nullptr, e->act};
+    launch_layernorm(l1, st);
+    launch_gemm<EPI_GELU>(e, g1);
     launch_gemm<EPI_ACT>(e, g2);
     // the last LayerNorm of the forward also leaves its output in f32: the pooling input
     LnParams l2{e->act, e->delta, TB, H, KB, l.ln2g, l.ln2b, c.ln_eps, li + 1 == c.n_layers ? e->res : nullptr, e->act};

@@ -2,6 +2,8 @@
 against the float32 CPU oracle (transformers forward through the sentence-transformers pipeline) on seeded
 random weights of the reference's model shapes.  Tolerance (f16 operands): cosine >= 0.9995 and max abs
 difference of the unit-norm embeddings <= 5e-3; the pooled (un-normalised) output within 2 % relative."""
+import os
+
 import numpy as np
 import pytest
 
@@ -267,3 +269,40 @@ def test_concurrent_single_query_encodes_share_forwards(tmp_path):
     assert t_serial / best >= 3.0, (t_serial, best)
     EmbeddingManager._reset_singleton()
     cfg.reset()
+
+
+def test_folded_first_layernorm_equals_the_separate_pass(tmp_path, monkeypatch):
+    """Large forwards fold a layer's first LayerNorm into the GEMMs around it (EPI_RES_STATS / EPI_FOLD_GELU / EPI_RES_LN in
+    csrc/encoder.hip): same embeddings as the path with the LayerNorm pass (ANORAG_ENC_FOLD=0) to well inside the
+    encoder's tolerance, and both against the float32 oracle — plain weights, LayerNorm gains / shifts far from 1 / 0 (the
+    fold multiplies them into the weights), and outlier features."""
+    from anorag_hip.encoder import SentenceEncoder
+    for case in ("plain", "gains", "outliers"):
+        d = oenc.make_synthetic_model(str(tmp_path / f"bge-{case}"), layers=4, hidden=768, heads=12, intermediate=3072,
+                                      vocab=30522, pooling="cls", weight_std=0.03)
+        if case != "plain":
+            from safetensors.numpy import load_file, save_file
+            path = os.path.join(d, "model.safetensors")
+            t = load_file(path)
+            rng = np.random.default_rng(5)
+            for name in list(t):
+                if "attention.output.LayerNorm.weight" in name:
+                    g = (1.0 + 0.5 * rng.standard_normal(768)).astype(np.float32)
+                    if case == "outliers":
+                        g[rng.choice(768, 6, replace=False)] *= 25.0
+                    t[name] = g
+                elif "attention.output.LayerNorm.bias" in name:
+                    t[name] = (0.3 * rng.standard_normal(768)).astype(np.float32)
+            save_file(t, path)
+        sents = oenc.synthetic_sentences(d, 256, seed=3, min_words=20, max_words=44)   # 256 x 64 padded tokens: the tile kernels
+        ref = oenc.encode(d, sents, batch_size=256, normalize=True)
+        outs = []
+        for fold in ("1", "0"):
+            monkeypatch.setenv("ANORAG_ENC_FOLD", fold)
+            enc = SentenceEncoder(d)
+            outs.append(enc.encode(sents, batch_size=256, normalize_embeddings=True))
+            enc.close()
+        for got in outs:
+            assert np.sum(got * ref, axis=1).min() >= 0.9995 and np.max(np.abs(got - ref)) <= 5e-3, case
+        assert not np.array_equal(outs[0], outs[1]), "the two paths are different arithmetic: identical bits mean the fold did not run"
+        assert np.sum(outs[0] * outs[1], axis=1).min() >= 0.99999 and np.max(np.abs(outs[0] - outs[1])) <= 1.5e-3, case
