@@ -60,6 +60,12 @@ struct Workspace {
   unsigned long long *stamps = nullptr;  // [kStamps] device time stamps of the batch's kernels (index_kernels.hpp)
   int64_t t_enq0 = 0, t_enq1 = 0;  // host clock (ns) when the batch's enqueue began / returned
   int64_t log_slot = -1;           // the batch's record in the handle's batch log (recovery time is added to it)
+  // recovery of the queries whose certificate failed: launched without waiting (launch_recovery), finished at the retire
+  bool rec_launched = false;
+  hipEvent_t ev_rec = nullptr;
+  int *qslots_pin = nullptr;       // pinned [2][64]: query slots of the two recovery chains (source of their uploads)
+  float *lad_pin = nullptr;        // pinned [64][kLadder]: the fixed-threshold ladder of a second scan
+  std::vector<int> rec_lists, rec_scan, rec_dense;
   int64_t seq = 0;
   bool shadow = false;             // the batch's side kernels were the shadow-sized ones
   hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
@@ -214,15 +220,18 @@ int alloc_workspaces(anr_index *h) {
     ANR_TRY(dev_alloc(&w.ladder, kQB * kLadder, true));
     ANR_TRY(dev_alloc(&w.cntb, (int64_t)kQB * h->n_cu, true));
     ANR_TRY(dev_alloc(&w.ncand, 4 * kQB, true));
-    ANR_TRY(dev_alloc(&w.qslots, kQB, true));
+    ANR_TRY(dev_alloc(&w.qslots, 2 * kQB, true));
     ANR_TRY(dev_alloc(&w.lvlmax, kQB, true));
     ANR_TRY(dev_alloc(&w.sel_rank, kQB * kMaxSel, true));
     ANR_TRY(dev_alloc(&w.sel_row, kQB * kMaxSel, true));
     ANR_TRY(dev_alloc(&w.sel_m, kQB, true));
     ANR_TRY(dev_alloc(&w.exact, kQB * kMaxSel, true));
     ANR_TRY(dev_alloc(&w.stamps, kStamps, true));
-    ANR_HIP(hipHostMalloc(reinterpret_cast<void **>(&w.cnt_host), 6 * kQB * sizeof(unsigned), hipHostMallocDefault));
-    memset(w.cnt_host, 0, 6 * kQB * sizeof(unsigned));
+    ANR_HIP(hipHostMalloc(reinterpret_cast<void **>(&w.cnt_host), 7 * kQB * sizeof(unsigned), hipHostMallocDefault));
+    memset(w.cnt_host, 0, 7 * kQB * sizeof(unsigned));
+    ANR_HIP(hipHostMalloc(reinterpret_cast<void **>(&w.qslots_pin), 2 * kQB * sizeof(int), hipHostMallocDefault));
+    ANR_HIP(hipHostMalloc(reinterpret_cast<void **>(&w.lad_pin), kQB * kLadder * sizeof(float), hipHostMallocDefault));
+    ANR_HIP(hipEventCreateWithFlags(&w.ev_rec, hipEventDisableTiming));
     ANR_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&w.cnt_dev), w.cnt_host, 0));
     ANR_HIP(hipEventCreateWithFlags(&w.ev_in, hipEventDisableTiming));
     ANR_HIP(hipEventCreateWithFlags(&w.ev_pre, hipEventDisableTiming | hipEventDisableSystemFence));
@@ -438,36 +447,35 @@ int run_exact(anr_index *h, Workspace &w, const std::vector<int> &slots) {
   return ANR_OK;
 }
 
-// Second pass for the queries whose certificate failed (sparse path): a scan with the fixed per-query threshold
-// theta = rank(k-th exact) - eps, which every row of the true top-k must pass, then the exact value of EVERY
-// emitted row and a select on those exact values.  Always exact; costs one more scan for the whole batch
-// however many queries failed.  Queries whose lists overflow are left to the dense exact path (returned).
-int run_second_pass(anr_index *h, Workspace &w, const std::vector<int> &slots, std::vector<int> *still_failed) {
+// Recovery of the queries whose certificate failed (threshold-gated scan), in two halves so that the host never waits for
+// it inside the pipeline: launch_recovery() only ENQUEUES (on the index's own stream, from pinned buffers; everything it
+// decides on is in the pinned status block the batch's last kernel wrote), finish_recovery() waits at the retire.  A batch
+// that is complete while later ones are still being enqueued gets its recovery launched by enqueue_batch — until round 4
+// the retire did it all synchronously (two read-backs, three stream synchronisations) and a batch with ONE failed query
+// cost the pipeline as much as a batch of 64.
+//   * theta (below which no row of the true top-k can score) at or above the threshold EVERY workgroup emitted at: the lists
+//     already hold every row that matters — their entries >= theta re-scored exactly (k_rescore_lists), a select, k_emit;
+//   * otherwise a second scan with the fixed per-query threshold theta, then the same chain over its lists;
+//   * no theta (fewer than k results) or a list overflow: the dense exact path at the retire.
+int launch_recovery(anr_index *h, Workspace &w, const std::vector<int> &slots) {
   hipStream_t st = h->stream;
   const float inf = __builtin_inff();
   const float *theta = reinterpret_cast<const float *>(w.cnt_host + 3 * kQB);
-  // The first scan emitted EVERY row whose scan score reached the threshold of the highest level any workgroup
-  // ended at.  Where theta (below which no row of the true top-k can score) is at or above that threshold, the
-  // lists already hold every row that matters: re-score those entries exactly and select — no second scan.
-  std::vector<float> lad0((size_t)kQB * kLadder);
-  std::vector<int> lvlmax(kQB);
-  ANR_HIP(hipMemcpyAsync(lad0.data(), w.ladder, lad0.size() * sizeof(float), hipMemcpyDeviceToHost, st));
-  ANR_HIP(hipMemcpyAsync(lvlmax.data(), w.lvlmax, kQB * sizeof(int), hipMemcpyDeviceToHost, st));
-  ANR_HIP(hipStreamSynchronize(st));
-  std::vector<int> from_lists, rescan;
+  const float *emitted = reinterpret_cast<const float *>(w.cnt_host + 6 * kQB);
+  w.rec_lists.clear();
+  w.rec_scan.clear();
+  w.rec_dense.clear();
   for (int q : slots) {
-    if (!(theta[q] > -inf)) {
-      still_failed->push_back(q);
-    } else if (!w.cnt_host[kQB + q] && lvlmax[q] >= 0 && lvlmax[q] < kLadder &&
-               theta[q] >= lad0[(size_t)q * kLadder + lvlmax[q]]) {
-      from_lists.push_back(q);
-    } else {
-      rescan.push_back(q);
-    }
+    if (!(theta[q] > -inf)) w.rec_dense.push_back(q);
+    else if (!w.cnt_host[kQB + q] && theta[q] >= emitted[q]) w.rec_lists.push_back(q);
+    else w.rec_scan.push_back(q);
   }
-  auto finish_from_lists = [&](const std::vector<int> &run, int grid, bool filter) -> int {
-    ANR_HIP(hipMemcpyAsync(w.qslots, run.data(), run.size() * sizeof(int), hipMemcpyHostToDevice, st));
-    RescoreListsParams rl{h->x32, w.q32, h->dim, h->dimp, h->metric, w.cand, w.cntb, grid, (unsigned)h->cand_cap, w.qslots,
+  auto chain = [&](const std::vector<int> &run, int which, int grid, bool filter) -> int {
+    int *pin = w.qslots_pin + which * kQB;
+    for (size_t i = 0; i < run.size(); ++i) pin[i] = run[i];
+    ANR_HIP(hipMemcpyAsync(w.qslots + which * kQB, pin, run.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    const int *qs = w.qslots + which * kQB;
+    RescoreListsParams rl{h->x32, w.q32, h->dim, h->dimp, h->metric, w.cand, w.cntb, grid, (unsigned)h->cand_cap, qs,
                           filter ? reinterpret_cast<const float *>(w.ncand + 3 * kQB) : nullptr};
     hipLaunchKernelGGL(k_rescore_lists, dim3((unsigned)run.size(), 4), dim3(1024), 0, st, rl);
     SelParams sp{};
@@ -481,57 +489,69 @@ int run_second_pass(anr_index *h, Workspace &w, const std::vector<int> &slots, s
     sp.out_row = w.sel_row;
     sp.out_m = w.sel_m;
     sp.overflow = w.ncand + kQB;
-    sp.qslots = w.qslots;
+    sp.qslots = qs;
     ANR_TRY(launch_select((int)run.size(), sp, st));
     EmitParams mp{};
     mp.rank = w.sel_rank;
     mp.row = w.sel_row;
     mp.m = w.sel_m;
     mp.nf = (int)run.size();
-    mp.qslots = w.qslots;
+    mp.qslots = qs;
     mp.out_off = w.out_off;
     mp.k = w.k;
     mp.metric = h->metric;
     mp.D = w.D;
     mp.I = w.I;
     mp.id_offset = h->id_offset;
+    mp.overflow = w.ncand + kQB;
+    mp.status_host = w.cnt_dev;  // the slot's overflow flag lands in the pinned status block: no read-back
     hipLaunchKernelGGL(k_emit, dim3(mp.nf), dim3(256), 0, st, mp);
     ANR_HIP(hipGetLastError());
-    ANR_HIP(hipMemcpyAsync(w.cnt_host + kQB, w.ncand + kQB, kQB * sizeof(unsigned), hipMemcpyDeviceToHost, st));
-    ANR_HIP(hipStreamSynchronize(st));
-    for (int q : run)
-      if (w.cnt_host[kQB + q]) still_failed->push_back(q);  // a list overflowed: dense exact path
     return ANR_OK;
   };
-  if (!from_lists.empty()) {
-    h->stats.n_from_lists += (int64_t)from_lists.size();
-    ANR_TRY(finish_from_lists(from_lists, w.scan_grid, true));
+  if (!w.rec_lists.empty()) {
+    h->stats.n_from_lists += (int64_t)w.rec_lists.size();
+    ANR_TRY(chain(w.rec_lists, 0, w.scan_grid, true));
   }
-  if (rescan.empty()) return ANR_OK;
-  // the remaining queries: a scan with the fixed per-query threshold theta
-  std::vector<float> lad((size_t)kQB * kLadder, inf);
-  for (int q : rescan)
-    for (int j = 0; j < kLadder; ++j) lad[(size_t)q * kLadder + j] = theta[q];
-  ANR_TRY(ensure_cand(h, w));
-  ANR_HIP(hipMemcpyAsync(w.ladder, lad.data(), lad.size() * sizeof(float), hipMemcpyHostToDevice, st));
-  ScanParams sc{};
-  sc.x16 = reinterpret_cast<const uint4 *>(h->x16);
-  sc.q16 = reinterpret_cast<const uint4 *>(w.q16);
-  sc.kb = h->kb;
-  sc.n_rows = h->ntotal;
-  sc.rowbias = h->rowbias;
-  sc.tile0 = 0;
-  sc.tile_stride = 1;
-  sc.n_tiles = ceil_div(h->ntotal, kTileRows);
-  sc.ladder = w.ladder;
-  sc.lvl0 = 0;
-  sc.cntb = w.cntb;
-  sc.cand = w.cand;
-  sc.capb = (unsigned)h->cand_cap;
-  sc.kprime = 0x7fffffffu;  // levels never advance: the threshold stays theta
-  int grid = 0;
-  ANR_TRY(launch_scan<false>(h, sc, st, h->n_cu, &grid));
-  return finish_from_lists(rescan, grid, false);
+  if (!w.rec_scan.empty()) {
+    for (int i = 0; i < kQB * kLadder; ++i) w.lad_pin[i] = inf;
+    for (int q : w.rec_scan)
+      for (int j = 0; j < kLadder; ++j) w.lad_pin[(size_t)q * kLadder + j] = theta[q];
+    ANR_TRY(ensure_cand(h, w));
+    ANR_HIP(hipMemcpyAsync(w.ladder, w.lad_pin, (size_t)kQB * kLadder * sizeof(float), hipMemcpyHostToDevice, st));
+    ScanParams sc{};
+    sc.x16 = reinterpret_cast<const uint4 *>(h->x16);
+    sc.q16 = reinterpret_cast<const uint4 *>(w.q16);
+    sc.kb = h->kb;
+    sc.n_rows = h->ntotal;
+    sc.rowbias = h->rowbias;
+    sc.tile0 = 0;
+    sc.tile_stride = 1;
+    sc.n_tiles = ceil_div(h->ntotal, kTileRows);
+    sc.ladder = w.ladder;
+    sc.lvl0 = 0;
+    sc.cntb = w.cntb;
+    sc.cand = w.cand;
+    sc.capb = (unsigned)h->cand_cap;
+    sc.kprime = 0x7fffffffu;  // levels never advance: the threshold stays theta
+    int grid = 0;
+    ANR_TRY(launch_scan<false>(h, sc, st, h->n_cu, &grid));
+    ANR_TRY(chain(w.rec_scan, 1, grid, false));
+  }
+  ANR_HIP(hipEventRecord(w.ev_rec, st));
+  w.rec_launched = true;
+  return ANR_OK;
+}
+
+// the recovery's results are in place; returns the queries that still need the dense exact path
+int finish_recovery(anr_index *h, Workspace &w, std::vector<int> *dense) {
+  (void)h;
+  ANR_HIP(hipEventSynchronize(w.ev_rec));
+  *dense = w.rec_dense;
+  for (const std::vector<int> *run : {&w.rec_lists, &w.rec_scan})
+    for (int q : *run)
+      if (w.cnt_host[kQB + q]) dense->push_back(q);  // a list overflowed
+  return ANR_OK;
 }
 
 // wait for a workspace's batch, fold its statistics, run the exact path where the certificate failed.
@@ -586,8 +606,12 @@ int retire(anr_index *h, Workspace &w) {
   if (!fallback.empty()) {
     const int64_t t_rec0 = host_ns();
     std::vector<int> dense;
-    if (w.sparse && !w.exact_all) ANR_TRY(run_second_pass(h, w, fallback, &dense));
-    else dense = fallback;
+    if (w.sparse && !w.exact_all) {
+      if (!w.rec_launched) ANR_TRY(launch_recovery(h, w, fallback));
+      ANR_TRY(finish_recovery(h, w, &dense));
+    } else {
+      dense = fallback;
+    }
     if (!dense.empty()) {
       h->stats.n_dense_exact += (int64_t)dense.size();
       ANR_TRY(run_exact(h, w, dense));
@@ -596,6 +620,7 @@ int retire(anr_index *h, Workspace &w) {
       h->batch_log[(size_t)w.log_slot * kBatchLogFields + 5 + kStamps] += host_ns() - t_rec0;
   }
   w.log_slot = -1;
+  w.rec_launched = false;
   w.in_flight = false;
   return ANR_OK;
 }
@@ -619,6 +644,18 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
   // run BESIDE the resident workgroups of the scan in front of them instead of after it (ANR_OPT_SHADOW)
   bool others_in_flight = false;
   for (int i = 0; i < kWorkspaces; ++i) others_in_flight |= (i != ws_index && h->ws[i].in_flight);
+  // a batch that has completed meanwhile and holds failed certificates: its recovery starts NOW, beside the batches being
+  // enqueued, instead of when its workspace comes round again (retire() then only waits for it)
+  for (int i = 0; i < kWorkspaces; ++i) {
+    Workspace &o = h->ws[i];
+    if (i == ws_index || !o.in_flight || o.rec_launched || !o.sparse || o.exact_all) continue;
+    if (hipEventQuery(o.ev_done) != hipSuccess) continue;
+    std::vector<int> fb;
+    for (int q = 0; q < o.nq; ++q)
+      if (o.cnt_host[2 * kQB + q]) fb.push_back(q);
+    if (!fb.empty()) ANR_TRY(launch_recovery(h, o, fb));
+  }
+  (void)hipGetLastError();  // (hipEventQuery reports hipErrorNotReady through the sticky error too)
   w.t_enq0 = t_enq0;
   w.seq = h->batch_seq++;
   w.shadow = false;
@@ -855,6 +892,8 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
     pp.status_host = w.cnt_dev;
     pp.host_out = host_out ? 1 : 0;
     pp.stamps = sparse ? w.stamps : nullptr;
+    pp.ladder = sparse ? w.ladder : nullptr;
+    pp.lvlmax = sparse ? w.lvlmax : nullptr;
     ANR_TRY(launch_post(nq, sp, pp, ps));
     ANR_HIP(hipEventRecord(w.ev_done, ps));
     w.in_flight = true;
@@ -912,6 +951,8 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
   fp.status_host = w.cnt_dev;
   fp.host_out = host_out ? 1 : 0;
   fp.stamps = sparse ? w.stamps : nullptr;
+  fp.ladder = sparse ? w.ladder : nullptr;
+  fp.lvlmax = sparse ? w.lvlmax : nullptr;
   hipLaunchKernelGGL(k_finalize, dim3(nq), dim3(256), 0, ps, fp);
   ANR_HIP(hipGetLastError());
   ANR_HIP(hipEventRecord(w.ev_done, ps));
@@ -1259,11 +1300,15 @@ void free_workspaces(anr_index *h) {
     dev_free(w.sel_rank); dev_free(w.sel_row); dev_free(w.sel_m); dev_free(w.exact); dev_free(w.stamps);
     if (w.cnt_host) (void)hipHostFree(w.cnt_host);
     if (w.qpin) (void)hipHostFree(w.qpin);
+    if (w.qslots_pin) (void)hipHostFree(w.qslots_pin);
+    if (w.lad_pin) (void)hipHostFree(w.lad_pin);
     w.cnt_host = w.cnt_dev = nullptr;
     w.qpin = nullptr;
+    w.qslots_pin = nullptr;
+    w.lad_pin = nullptr;
     w.cand_alloc = 0;
     w.dense_ld = 0;
-    for (hipEvent_t *e : {&w.ev_in, &w.ev_done, &w.ev_t0, &w.ev_t1, &w.ev_pre, &w.ev_scan}) {
+    for (hipEvent_t *e : {&w.ev_in, &w.ev_done, &w.ev_t0, &w.ev_t1, &w.ev_pre, &w.ev_scan, &w.ev_rec}) {
       if (*e) (void)hipEventDestroy(*e);
       *e = nullptr;
     }

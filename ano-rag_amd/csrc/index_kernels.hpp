@@ -972,7 +972,16 @@ struct PostParams {
   unsigned *status_host;
   int host_out;
   unsigned long long *stamps;  // optional; copied to status_host[4 * 64 ...] by query 0's workgroup
+  const float *ladder;       // optional (threshold-gated scan): with lvlmax, the threshold every workgroup emitted at
+  const int *lvlmax;         // -> status_host[6 * 64 + q], what the host needs to choose a recovery without a read-back
 };
+
+// the scan emitted EVERY row at or above the threshold of the highest level any workgroup ended at: +inf when unknown
+__device__ __forceinline__ float emitted_threshold(const float *ladder, const int *lvlmax, int q) {
+  if (!ladder || !lvlmax) return __builtin_inff();
+  const int l = lvlmax[q];
+  return (l >= 0 && l < kLadder) ? ladder[q * kLadder + l] : __builtin_inff();
+}
 
 // the batch's stamps travel to the host in the status block (rows 4 and 5: kStamps u64 words)
 __device__ __forceinline__ void stamps_to_host(unsigned long long *stamps, unsigned *status_host) {
@@ -1103,6 +1112,7 @@ __global__ __launch_bounds__(1024) void k_post(SelParams p, PostParams pp) {
       pp.status_host[kQB + q] = ovf ? 1u : 0u;
       pp.status_host[2 * kQB + q] = (unsigned)flag;
       pp.status_host[3 * kQB + q] = __float_as_uint(theta);
+      pp.status_host[6 * kQB + q] = __float_as_uint(emitted_threshold(pp.ladder, pp.lvlmax, q));
       if (q == 0) stamps_to_host(pp.stamps, pp.status_host);
       __threadfence_system();
     }
@@ -1370,9 +1380,11 @@ struct FinalParams {
   float *theta;              // [64] scan-score threshold of the second pass: rank(k-th exact) - eps
   int64_t id_offset;
   const unsigned *ncand;     // may be null: [64] candidates seen (statistics)
-  unsigned *status_host;     // pinned host memory [6][64]: candidates | overflow | flag | theta bits | time stamps (2 rows)
+  unsigned *status_host;     // pinned host memory [7][64]: candidates | overflow | flag | theta bits | time stamps (2 rows) | emitted threshold
   int host_out;              // D / I are pinned host memory: fence the writes at system scope
   unsigned long long *stamps;  // optional
+  const float *ladder;       // optional, see PostParams
+  const int *lvlmax;
 };
 
 __global__ __launch_bounds__(256) void k_finalize(FinalParams p) {
@@ -1437,6 +1449,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinalParams p) {
       p.status_host[kQB + q] = p.overflow ? p.overflow[q] : 0u;
       p.status_host[2 * kQB + q] = (unsigned)flag;
       p.status_host[3 * kQB + q] = __float_as_uint(theta);
+      p.status_host[6 * kQB + q] = __float_as_uint(emitted_threshold(p.ladder, p.lvlmax, q));
       if (q == 0) stamps_to_host(p.stamps, p.status_host);
       __threadfence_system();
     }
@@ -1498,12 +1511,15 @@ struct EmitParams {
   float *D;
   int64_t *I;
   int64_t id_offset;
+  const unsigned *overflow;  // optional [64] (with qslots): the select's overflow flag of the slot ...
+  unsigned *status_host;     // ... copied to the pinned status block, row 1 (the recovery's only read-back)
 };
 
 __global__ __launch_bounds__(256) void k_emit(EmitParams p) {
   const int f = blockIdx.x;
   if (f >= p.nf) return;
   const int s = p.qslots ? p.qslots[f] : p.slot[f];
+  if (threadIdx.x == 0 && p.qslots && p.overflow && p.status_host) p.status_host[kQB + s] = p.overflow[s];
   const int64_t oq = p.qslots ? p.out_off + s : p.outq[f];
   const int m = p.m[s];
   for (int i = threadIdx.x; i < p.k; i += 256) {

@@ -66,6 +66,11 @@ def parse():
     ap.add_argument("--serial-launches", type=int, default=20,
                     help="serialised batches after the timed region from which the kernel-only scan time is taken")
     ap.add_argument("--no-facade", action="store_true", help="skip the VectorIndex.search (host in, dicts out) leg")
+    ap.add_argument("--in-flight", type=int, default=3,
+                    help="batches left in flight (default 3).  1: every batch is retired before the next is enqueued — the form "
+                         "the rocprofv3 kernel statistics are taken on: with batches in flight the NEXT scan's workgroups "
+                         "take over CU by CU while the previous scan retires, so a profiler's per-kernel span (first "
+                         "workgroup start to last workgroup end) includes that wait and is not the kernel's time")
     ap.add_argument("--exchange-group", type=int, default=2,
                     help="N > 1: batches whose partial top-k lists travel in one all-gather")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsal)")
@@ -176,8 +181,8 @@ def recall_from_partials(parts, I_gpu, k):
 def pmc_traffic(rows_per_gpu, dim, notes):
     """HBM bytes per k_scan launch from the committed PMC passes (profiles/*_pmc_traffic_k_scan.json: FETCH_SIZE
     doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE, separate --pmc runs), scaled by rows when the
-    shard differs.  The file records the sha256 of csrc/index_kernels.hpp it was measured on: when the kernel source
-    has changed since, the figure is stale and is NOT reported (traffic = null, the reason goes to `traffic_note` and
+    shard differs.  The file records the sha256 of the k_scan region of csrc/index_kernels.hpp it was measured on
+    (tools/scan_source_hash.py): when the kernel source has changed since, the figure is stale and is NOT reported (traffic = null, the reason goes to `traffic_note` and
     stderr) — re-run tools/refresh_profiles.sh."""
     import glob
     import hashlib
@@ -187,8 +192,11 @@ def pmc_traffic(rows_per_gpu, dim, notes):
         return None
     with open(files[-1]) as f:
         p = json.load(f)
-    src = os.path.join(ROOT, "ano-rag_amd", "csrc", "index_kernels.hpp")
-    sha = hashlib.sha256(open(src, "rb").read()).hexdigest()
+    src = open(os.path.join(ROOT, "ano-rag_amd", "csrc", "index_kernels.hpp"), "rb").read()
+    if p.get("kernel_source_region") == "k_scan":   # (round 4: the scan kernel's own text, not the whole header)
+        a = src.index(b"// scan: the dominant kernel.")
+        src = src[a:src.index(b"// sample (shadow form of k_scan<DENSE>", a)]
+    sha = hashlib.sha256(src).hexdigest()
     if p.get("kernel_source_sha256") != sha:
         msg = (f"{os.path.basename(files[-1])} was measured on another version of index_kernels.hpp "
                f"(recorded {str(p.get('kernel_source_sha256'))[:12]}, current {sha[:12]}): traffic not reported")
@@ -588,6 +596,8 @@ def main():
             issued[0] += 1
             idx.search_device_async(Q[i].data_ptr(), args.batch, args.k, Dl[s].data_ptr(), Il[s].data_ptr(),
                                     streams[s].cuda_stream)
+            if args.in_flight < NSLOT:
+                idx.wait(max(0, args.in_flight - 1))
             merged["last"] = (Dl[s], Il[s])
             return
         done = stream.submit(Q[i], tag=i)

@@ -622,3 +622,54 @@ def test_shadow_side_kernels_and_role_streams_equal_the_wide_pipeline():
     idx.add(x)
     _check(idx, x, q, 100, "ip", True)
     idx.close()
+
+
+def test_pipelined_batches_with_failed_certificates_recover_beside_the_pipeline():
+    """Asynchronous batches on a corpus of tight clusters (every certificate fails; some queries need the fixed-threshold second
+    scan): the recovery of a completed batch is launched while later batches are still being enqueued (round 4:
+    launch_recovery / finish_recovery) and must leave exactly the results of the one-batch-at-a-time search — and the
+    oracle's."""
+    import torch
+    from anorag_hip import FlatIndex, METRIC_IP
+    from anorag_hip._lib import OPT_OVERFETCH
+    rng = np.random.default_rng(12)
+    n, d, B, k, nb = 400_000, 256, 64, 50, 9
+    cent = rng.standard_normal((400, d)).astype(np.float32)
+    x = (cent[rng.integers(0, 400, n)] + 0.02 * rng.standard_normal((n, d))).astype(np.float32)
+    q = (cent[rng.integers(0, 400, (nb, B))] + 0.02 * rng.standard_normal((nb, B, d))).astype(np.float32)
+    q[:, ::7] = rng.standard_normal((nb, len(range(0, B, 7)), d)).astype(np.float32)   # some queries far from every cluster
+    idx = FlatIndex(d, METRIC_IP, normalize=True)
+    idx.set_option(OPT_OVERFETCH, 64)    # a fixed, small K': certificates keep failing in every batch (no adaptation)
+    idx.add(x)
+    dev = torch.device("cuda", 0)
+    Q = torch.from_numpy(q).to(dev)
+    ref = []
+    for b in range(nb):
+        D = torch.empty((B, k), device=dev)
+        I = torch.empty((B, k), device=dev, dtype=torch.int64)
+        idx.search_device(Q[b].data_ptr(), B, k, D.data_ptr(), I.data_ptr())
+        torch.cuda.synchronize()
+        ref.append((D.cpu().numpy(), I.cpu().numpy()))
+    st0 = idx.last_stats()
+    assert st0["n_fallback"] > 0
+    idx.reset_stats()
+    S = [torch.cuda.Stream() for _ in range(3)]
+    Ds = [torch.empty((B, k), device=dev) for _ in range(nb)]
+    Is = [torch.empty((B, k), device=dev, dtype=torch.int64) for _ in range(nb)]
+    for rep in range(2):
+        for b in range(nb):
+            idx.search_device_async(Q[b].data_ptr(), B, k, Ds[b].data_ptr(), Is[b].data_ptr(), S[b % 3].cuda_stream)
+        idx.sync()
+        torch.cuda.synchronize()
+        for b in range(nb):
+            assert np.array_equal(Is[b].cpu().numpy(), ref[b][1]) and np.array_equal(Ds[b].cpu().numpy(), ref[b][0]), (rep, b)
+    st = idx.last_stats()
+    assert st["n_fallback"] >= nb * 10 and st["n_dense_exact"] == 0, st
+    assert st["n_from_lists"] > 0
+    rec, _ = idx.batch_log(2 * nb, correlate=False)
+    assert rec.shape[0] == 2 * nb
+    xn = orc.preprocess_vectors(x)
+    qn = orc.preprocess_vectors(q[nb - 1])
+    Dr, Ir = orc.flat_search(qn, xn, k, "ip")
+    assert orc.near_tie_equal(ref[nb - 1][1], Ir, orc.exact_scores(qn, xn, "ip"), k, 1e-6)
+    idx.close()

@@ -16,9 +16,9 @@ ap.add_argument("--dim", type=int, default=768)
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--k", type=int, default=100)
 ap.add_argument("--steps", type=int, default=120)
-ap.add_argument("--shadow", type=int, default=1)
+ap.add_argument("--shadow", type=int, default=0)
 ap.add_argument("--timing", type=int, default=0)
-ap.add_argument("--schedule", type=int, default=1)
+ap.add_argument("--schedule", type=int, default=0)
 ap.add_argument("--stream-wait", type=int, default=0)
 ap.add_argument("--clustered", action="store_true")
 ap.add_argument("--sigma", type=float, default=0.3)

@@ -9,7 +9,7 @@
 #   5 N-array fusion (C5) kernel stats
 set -e
 R=$GRAFT_REPO_ROOT
-ROUND=${ROUND:-r03}
+ROUND=${ROUND:-r04}
 O=$R/gpurun_out/prof
 STEPS=${STEPS:-12345}   # which parts to run (a gpurun call is limited to 20 minutes: e.g. STEPS=12, then STEPS=345)
 mkdir -p $O
@@ -22,6 +22,11 @@ python3 $R/bench.py > $O/${ROUND}_bench_1gpu.json 2> $O/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats -- python3 $R/bench.py --no-cpu --recall-queries 0 --no-facade --no-legs > $O/bench_prof.json 2> $O/bench_prof.err
 cp $(ls $O/kstats/*/*kernel_stats.csv | head -1) $O/${ROUND}_bench_10m_1gpu_kernel_stats.csv
 rm -rf $O/kstats
+# the same command with ONE batch in flight: scans never overlap, so rocprofv3's average k_scan<false,...> duration IS the kernel's
+# time (with three in flight the next scan's workgroups take over CU by CU and the profiler's span of a scan includes that wait)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats1 -- python3 $R/bench.py --in-flight 1 --no-cpu --recall-queries 0 --no-facade --no-legs > $O/bench_prof_serial.json 2> $O/bench_prof_serial.err
+cp $(ls $O/kstats1/*/*kernel_stats.csv | head -1) $O/${ROUND}_bench_10m_1gpu_in_flight_1_kernel_stats.csv
+rm -rf $O/kstats1
 fi
 if [[ $STEPS == *2* ]]; then
 echo "[2] pmc traffic" >&2
@@ -42,13 +47,14 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
 fetch = sum(out["FETCH_SIZE"]) / len(out["FETCH_SIZE"]); write = sum(out["WRITE_SIZE"]) / len(out["WRITE_SIZE"])
 rows_n, dim = 10_000_000, 768
 traffic = (2 * fetch + write) * 1024
-src = open(f"{R}/ano-rag_amd/csrc/index_kernels.hpp", "rb").read()
+sys.path.insert(0, f"{R}/tools")
+from scan_source_hash import scan_source_sha256
 json.dump({"kernel": kernel.replace("void anr::", "").split("(")[0], "rows": rows_n, "dim": dim,
            "algorithmic_bytes_per_launch": rows_n * dim * 2, "FETCH_SIZE_KiB_per_launch": fetch,
            "WRITE_SIZE_KiB_per_launch": write,
            "correction": "gfx950: FETCH_SIZE counts half of a wide coalesced stream -> doubled (MI355X_MICROARCH.md HBM section); WRITE_SIZE exact; unit KiB",
            "traffic_bytes_per_launch": traffic, "traffic_over_algorithmic": traffic / (rows_n * dim * 2),
-           "kernel_source_sha256": hashlib.sha256(src).hexdigest(),
+           "kernel_source_sha256": scan_source_sha256(), "kernel_source_region": "k_scan",
            "command": "rocprofv3 --pmc <counter> --kernel-trace --output-format csv -- python3 tools/scan_perf.py --rows 10000000 --steps 4 --mode sync (one pass per counter; tools/refresh_profiles.sh)"},
           open(f"{O}/{ROUND}_pmc_traffic_k_scan.json", "w"), indent=1)
 print("traffic/algorithmic", traffic / (rows_n * dim * 2))
@@ -58,6 +64,8 @@ fi
 if [[ $STEPS == *3* ]]; then
 echo "[3] shard sizes + configs" >&2
 { python3 $R/tools/scan_perf.py --rows 1000000 --steps 60; python3 $R/tools/scan_perf.py --rows 1250000 --steps 60; python3 $R/tools/scan_perf.py --rows 1250000 --steps 60 --clustered; } 2>&1 | grep -v amdgpu > $O/${ROUND}_shard_size_lines.txt
+# the pipeline's own time line (batch log) at the shard size: default, with the round-3 completion marker, shadow kernels, role streams
+{ for cfg in "0 0 0" "0 1 0" "0 0 2" "1 0 0" "1 0 2"; do set -- $cfg; python3 $R/tools/pipeline_log.py --rows 1250000 --steps 200 --schedule $1 --stream-wait $2 --shadow $3; done; python3 $R/tools/pipeline_log.py --rows 1250000 --steps 60 --clustered --sigma 0.02; } 2>&1 | grep -v amdgpu > $O/${ROUND}_pipeline_log_shard_1250k.txt
 python3 $R/tools/bench_configs.py > $O/configs.log 2>&1 && cp $R/gpurun_out/configs.json $O/${ROUND}_configs_c1_c2_c4_c5.json
 { python3 $R/tools/tiny_perf.py; echo "--- K=32"; K=32 python3 $R/tools/tiny_perf.py; echo "--- 20k x 768"; ROWS=20000 DIM=768 python3 $R/tools/tiny_perf.py; echo "--- 100k x 768"; ROWS=100000 DIM=768 python3 $R/tools/tiny_perf.py; } 2>&1 | grep -v amdgpu > $O/${ROUND}_c1_tiny_path.txt
 fi
