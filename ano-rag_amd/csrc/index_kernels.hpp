@@ -1343,7 +1343,31 @@ __global__ __launch_bounds__(1024) void k_rescore_lists(RescoreListsParams p) {
     const unsigned row = ent->y;
     const float *x = p.x32 + (int64_t)row * p.dim;
     double acc = 0.0;
-    if (p.metric == 0) {
+    if ((p.dim & 3) == 0) {
+      // 16-byte loads, the whole row in flight at once, products added in k_rescore's order (the same bits as the scores
+      // the post kernel computes for the same row); the scalar loop below took ~5 us per row and wave
+      typedef float f32x4 __attribute__((ext_vector_type(4)));
+      const f32x4 *x4 = reinterpret_cast<const f32x4 *>(x), *q4 = reinterpret_cast<const f32x4 *>(qv);
+      const int n4 = p.dim >> 2;
+#pragma unroll 4
+      for (int k = lane; k < n4; k += 64) {
+        const f32x4 a = __builtin_nontemporal_load(x4 + k), b = q4[k];
+        if (p.metric == 0) {
+          acc += (double)a.x * (double)b.x;
+          acc += (double)a.y * (double)b.y;
+          acc += (double)a.z * (double)b.z;
+          acc += (double)a.w * (double)b.w;
+        } else {
+          const double d0 = (double)b.x - (double)a.x, d1 = (double)b.y - (double)a.y;
+          const double d2 = (double)b.z - (double)a.z, d3 = (double)b.w - (double)a.w;
+          acc += d0 * d0;
+          acc += d1 * d1;
+          acc += d2 * d2;
+          acc += d3 * d3;
+        }
+      }
+      if (p.metric != 0) acc = -acc;
+    } else if (p.metric == 0) {
       for (int k = lane; k < p.dim; k += 64) acc += (double)x[k] * (double)qv[k];
     } else {
       for (int k = lane; k < p.dim; k += 64) {
