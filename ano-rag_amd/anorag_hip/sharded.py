@@ -48,9 +48,12 @@ class ExchangePlan:
     """Book-keeping of a pipelined search loop whose batches are exchanged (all-gather + merge) in GROUPS, `lag` batches
     behind the search front (bench.py, N > 1): which send-buffer slot a batch writes, and which batches travel together.
 
-    Slots rotate over ``nslot = lag + group`` rounded up to a multiple of `group`; batch number j of a run (counted from
+    Slots rotate over ``nslot = lag + 2 group`` rounded up to a multiple of `group`; batch number j of a run (counted from
     the last ``drain``) writes slot ``j % nslot``, so every group starts on a multiple of `group` and its slots are
-    consecutive: with the slots laid out back to back, a group is ONE contiguous send buffer.  A slot is handed out again
+    consecutive: with the slots laid out back to back, a group is ONE contiguous send buffer.  (``lag + group`` slots —
+    rounds 2-3 — hand a slot out again ONE submit after its group's collective was launched: the new search then waits for
+    an all-gather that only gets a CU when a scan retires, and every other scan started ~60 us late at the 8-GPU shard
+    size; a spare group of slots puts a whole group of submits between the two.)  A slot is handed out again
     only after the group that last used it has been returned by ``issue`` / ``drain`` (the caller then orders the new
     write behind that group's collective with an event)."""
 
@@ -58,7 +61,7 @@ class ExchangePlan:
         if lag < 0 or group < 1:
             raise ValueError("lag >= 0 and group >= 1")
         self.lag, self.group = int(lag), int(group)
-        self.nslot = (self.lag + self.group + self.group - 1) // self.group * self.group
+        self.nslot = (self.lag + 2 * self.group + self.group - 1) // self.group * self.group
         self.pending: List[Tuple[int, int]] = []  # (batch, slot) issued and not yet handed back, oldest first
         self.issued = 0
 
@@ -348,9 +351,9 @@ class ShardedSearcher:
         Ip = np.stack([p[id_off:].numpy().view(np.int64).reshape(B, k) for p in parts])
         return merge_topk_host_c(Dp, Ip, self.larger)
 
-    def stream(self, nq: int, k: int, lag: int = 2, group: int = 2) -> "ShardedStream":
+    def stream(self, nq: int, k: int, lag: int = 2, group: int = 2, order_caller: bool = True) -> "ShardedStream":
         """pipelined searches of a stream of [nq, dim] batches, `group` batches per exchange (``ShardedStream``)"""
-        return ShardedStream(self, nq, k, lag, group)
+        return ShardedStream(self, nq, k, lag, group, order_caller)
 
     def search(self, q: np.ndarray, k: int):
         q = np.asarray(q)
@@ -366,12 +369,14 @@ class ShardedStream:
     final on this shard; ``submit`` / ``flush`` hand back the merges that completed, as ``(tag, D, I)``.
 
     Device form (FlatIndex + nccl, or force_device): nothing leaves the GPU — D / I are torch CUDA tensors [nq, k], ordered
-    on the caller's current stream and valid until ``nslot`` further submits; queries are a CUDA tensor (or a numpy array, uploaded).  Host form (gloo, or a
+    on the caller's current stream (``order_caller``; else complete after ``wait()``) and valid until ``nslot`` further submits; queries are a CUDA tensor (or a numpy array, uploaded).  Host form (gloo, or a
     callable shard search): the shard search is synchronous, the grouped exchange and the merge run on the host, D / I
     are numpy arrays."""
 
-    def __init__(self, searcher: "ShardedSearcher", nq: int, k: int, lag: int = 2, group: int = 2):
+    def __init__(self, searcher: "ShardedSearcher", nq: int, k: int, lag: int = 2, group: int = 2, order_caller: bool = True):
         self.s = searcher
+        self.order_caller = bool(order_caller)  # False: read the merged lists after ``wait()`` instead (no marker in the caller's stream)
+        self.last_event = None
         self.nq, self.k = int(nq), int(k)
         self.plan = ExchangePlan(lag, group)
         self.nres = self.nq * self.k
@@ -384,7 +389,12 @@ class ShardedStream:
             self.torch = torch
             dev = torch.device("cuda", s.index.device)
             self.dev = dev
-            self.streams = [torch.cuda.Stream(device=dev) for _ in range(ns)]
+            # ONE stream for every collective and merge.  (Rounds 2-3 gave every slot its own stream and passed it to the search
+            # as "the stream the queries come from": the process's ~10 streams share four hardware queues, and a slot
+            # stream's wait-for-the-last-collective marker then sat in front of another batch's kernels — with the exchange
+            # on, the scans of the 8-GPU shard size ran ~100 us apart instead of back to back.)
+            self.xstream = torch.cuda.Stream(device=dev)
+            self.qstream = torch.cuda.Stream(device=dev)  # stands in for the null stream (see submit)
             # the slots' send buffers are contiguous, so a group of them is one send buffer
             self.send = torch.empty(ns * self.part, device=dev, dtype=torch.uint8)
             self.recv = [torch.empty(s.world * G * self.part, device=dev, dtype=torch.uint8) for _ in range(ns // G)]
@@ -400,8 +410,8 @@ class ShardedStream:
         from . import _lib
         torch, s = self.torch, self.s
         n, s0 = len(grp), grp[0][1]
-        st = self.streams[grp[-1][1]]
-        s.index.wait(len(self.plan.pending))  # everything older than the still-pending batches is final on this shard
+        st = self.xstream
+        s.index.wait(len(self.plan.pending))  # everything older than the still-pending batches is final on this shard (host wait)
         recv = self.recv[s0 // self.plan.group][: s.world * n * self.part]
         out = []
         with torch.cuda.stream(st):
@@ -417,8 +427,10 @@ class ShardedStream:
             ev.record(st)
         for _, slot in grp:
             self.slot_free[slot] = ev
-        # the caller's stream sees the merged lists complete (a device-side wait: nothing blocks on the host)
-        torch.cuda.current_stream(self.dev).wait_event(ev)
+        self.last_event = ev
+        if self.order_caller:
+            # the caller's stream sees the merged lists complete (a device-side wait: nothing blocks on the host)
+            torch.cuda.current_stream(self.dev).wait_event(ev)
         return out
 
     def _exchange_host(self, grp):
@@ -447,22 +459,28 @@ class ShardedStream:
         if self.device_form:
             torch = self.torch
             slot, grp = self.plan.issue(tag)
-            if self.slot_free[slot] is not None:  # the group that last sent this slot was gathered on another stream
-                self.streams[slot].wait_event(self.slot_free[slot])
+            if self.slot_free[slot] is not None:
+                # the collective that last read this slot's send buffer was launched a whole group of submits ago: a host
+                # wait that is over before it starts, instead of a marker in a stream
+                self.slot_free[slot].synchronize()
                 self.slot_free[slot] = None
             if isinstance(q, np.ndarray):
                 q = torch.from_numpy(np.ascontiguousarray(q, dtype=np.float32)).to(self.dev)
-            else:
-                # a device tensor may still be being WRITTEN by work queued on the caller's stream: the slot's stream (the
-                # one the library is told the queries come from) waits for that stream first, and the caching allocator
-                # learns that the tensor is in use there (without this the scan could read q before its producer
-                # had run, and bench.py / the tests only passed because they synchronise after generating their queries)
-                self.streams[slot].wait_stream(torch.cuda.current_stream(self.dev))
-                q.record_stream(self.streams[slot])
+            # the stream the queries come from is the CALLER's current stream: the library orders the batch behind it when it
+            # is busy (a query tensor whose producer is still queued there is safe to pass — ADVICE r3).  The C-ABI reads a
+            # null stream handle as "the index's own stream", and torch's default stream IS handle 0: a busy default stream
+            # is therefore handed over as a private stream whose only work is a wait for it.
+            cur = torch.cuda.current_stream(self.dev)
+            user = cur.cuda_stream
+            if user == 0:
+                if cur.query():
+                    user = 0  # nothing queued before the queries: no ordering to carry
+                else:
+                    self.qstream.wait_stream(cur)
+                    user = self.qstream.cuda_stream
             self._keep[slot] = q  # alive until the slot comes round again (its batch has been retired by then)
             base = self.send.data_ptr() + slot * self.part
-            s.index.search_device_async(q.data_ptr(), self.nq, self.k, base, base + self.id_off,
-                                        self.streams[slot].cuda_stream)
+            s.index.search_device_async(q.data_ptr(), self.nq, self.k, base, base + self.id_off, user)
             return self._exchange_device(grp) if grp is not None else []
         if hasattr(q, "detach"):
             q = q.detach().cpu().numpy()
@@ -484,6 +502,11 @@ class ShardedStream:
         for grp in self.plan.drain():
             out += self._exchange_device(grp) if self.device_form else self._exchange_host(grp)
         return out
+
+    def wait(self) -> None:
+        """host wait for every merge handed back so far (device form with ``order_caller=False``)"""
+        if self.device_form and self.last_event is not None:
+            self.last_event.synchronize()
 
 
 def merge_topk_device(device: int, Dg, Ig, k: int, larger_is_better: bool, D_out, I_out, stream: int = 0) -> None:

@@ -584,7 +584,7 @@ def main():
         from anorag_hip.sharded import ShardedSearcher
         # (the searcher makes the shard return global ids: ANR_OPT_ID_OFFSET = row0; every shard holds >= k rows)
         searcher = ShardedSearcher(idx, row0, force_device=(world == 1 and args.backend == "nccl"))
-        stream = searcher.stream(args.batch, args.k, lag=LAG, group=G)
+        stream = searcher.stream(args.batch, args.k, lag=LAG, group=G, order_caller=False)  # (finish() waits on the host)
     torch.cuda.synchronize()
 
     issued = [0]   # N = 1: batches issued since the last finish()
@@ -610,6 +610,7 @@ def main():
             done = stream.flush()
             if done:
                 merged["last"] = done[-1][1:]
+            stream.wait()
         torch.cuda.synchronize()
         issued[0] = 0
 

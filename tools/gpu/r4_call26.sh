@@ -1,0 +1,4 @@
+set -e
+cd $GRAFT_REPO_ROOT
+for g in 1 2 3 4 6; do python3 bench.py --force-dist --rows 1250000 --exchange-group $g --no-legs --no-cpu --no-facade --recall-queries 0 --steps 120 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('group', $g, d['config']['rows_total'], round(d['ms_per_step'],4), round(d['value']), d['roofline']['in_timed_region']['scan_to_scan_ms_median'])"; done
+python3 bench.py --rows 1250000 --no-legs --no-cpu --no-facade --recall-queries 0 --steps 120 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('no exchange', round(d['ms_per_step'],4))"
