@@ -16,7 +16,7 @@ import ctypes as C
 import math
 import re
 from collections import Counter
-from typing import Any, Callable, Dict, List, Sequence
+from typing import Optional, Any, Callable, Dict, List, Sequence
 
 import numpy as np
 
@@ -71,6 +71,7 @@ class DeviceBM25:
             weights = self.idf[term_of] * (numerator / denominator)
         else:
             weights = np.zeros(0, dtype=np.float64)
+        self._post_len = np.diff(indptr)  # documents per term: sizes the sparse rows (scores_sparse_device)
         self._lib = _lib.load()
         h = C.c_void_p()
         _lib.check(self._lib.anr_bm25_create(int(device), self.doc_count, n_terms, indptr.ctypes.data_as(C.c_void_p),
@@ -110,17 +111,26 @@ class DeviceBM25:
                                                  C.c_void_p(out.ptr), C.c_void_p(out.row_max.ptr)), "anr_bm25_scores_dev")
         return out
 
-    SPARSE_CAP = 6144  # documents one query's postings may touch on the sparse path (kSpMaxCap, csrc/bm25.hip)
+    SPARSE_CAP = 6144        # documents of a row that one LDS hash table holds (kSpMaxCap, csrc/bm25.hip): rows unordered
+    SPARSE_CAP_MAX = 65536   # ... of a row cut into document-range slices (kSpMaxCapBig): rows ascending by id
 
-    def scores_sparse_device(self, queries: Sequence[Sequence[str]], normalize: bool = True, cap: int = SPARSE_CAP,
+    def scores_sparse_device(self, queries: Sequence[Sequence[str]], normalize: bool = True, cap: Optional[int] = None,
                              allow_overflow: bool = False):
         """the same scores as ``scores_device`` in SPARSE form (``anorag_hip.fusion.SparseRows``): per query the
         documents its postings touch and their scores, left in device memory for ``fuse_dense`` — the N-vector is never
-        formed.  A query that touches more than `cap` documents cannot be held: with ``allow_overflow`` its row is
-        marked (``counts[i] == -1``: score that query with ``scores_device``), otherwise None is returned."""
+        formed.  ``cap`` (documents per row, at most ``SPARSE_CAP_MAX``) defaults to what the batch needs: the largest
+        summed posting length of its queries (an upper bound of the documents a query touches), ``SPARSE_CAP`` when that
+        fits one table.  A query that touches more than `cap` documents cannot be held: with ``allow_overflow`` its row
+        is marked (``counts[i] == -1``: score that query with ``scores_device``), otherwise None is returned."""
         from .fusion import SparseRows
         indptr, terms = self._encode_queries(queries)
         nq = len(queries)
+        if cap is None:
+            need = 0
+            if len(terms):
+                csum = np.concatenate(([0], np.cumsum(self._post_len[terms])))
+                need = int((csum[indptr[1:]] - csum[indptr[:-1]]).max()) if nq else 0
+            cap = self.SPARSE_CAP if need <= self.SPARSE_CAP else min(self.SPARSE_CAP_MAX, -(-need // 1024) * 1024)
         out = SparseRows(nq, self.doc_count, cap, self.device)
         cnt = np.empty((nq,), dtype=np.int32)
         _lib.check(self._lib.anr_bm25_sparse_dev(self._h, nq, indptr.ctypes.data_as(C.c_void_p),

@@ -142,7 +142,8 @@ class DeviceArray:
 
 class SparseRows:
     """[nq] rows over ``n`` ids in SPARSE form, in device memory: per row up to ``cap`` explicit (id, value) entries
-    (uint32 / float64, any order, ids distinct), every other id holds 0.0 — ``anr_fuse_source.sparse_*``.  What
+    (uint32 / float64, ids distinct; any order while ``cap`` <= 8192, ascending ids beyond, up to 65536), every other id
+    holds 0.0 — ``anr_fuse_source.sparse_*``.  What
     ``DeviceBM25.scores_sparse_device`` returns; ``fuse_dense`` takes it wherever it takes a ``DeviceArray`` and gives
     the same results without streaming n scores per query."""
 
@@ -168,9 +169,16 @@ class SparseRows:
     @classmethod
     def from_numpy(cls, rows: Sequence[Tuple[np.ndarray, np.ndarray]], n: int, cap: Optional[int] = None,
                    device: int = 0) -> "SparseRows":
-        """rows[i] = (ids, values) of row i"""
+        """rows[i] = (ids, values) of row i (rows of more than 8192 entries are put in id order here: the fusion sorts
+        shorter rows itself and asks that of its caller beyond — ``anr_fuse_source.sparse_cap``)"""
         nq = len(rows)
         cap = int(cap or max([len(a) for a, _ in rows] + [1]))
+        if cap > 8192:
+            srt = []
+            for a, b in rows:
+                order = np.argsort(np.asarray(a, dtype=np.uint32), kind="stable")
+                srt.append((np.asarray(a)[order], np.asarray(b)[order]))
+            rows = srt
         ids = np.zeros((nq, cap), dtype=np.uint32)
         val = np.zeros((nq, cap), dtype=np.float64)
         cnt = np.zeros((nq,), dtype=np.int32)

@@ -148,7 +148,8 @@ __device__ __forceinline__ int64_t bm_lower(const int32_t *docs, int64_t a, int6
 }
 
 // slice bounds of every token's posting list for the workgroup's document range: bounds[2 i], bounds[2 i + 1]
-__device__ __forceinline__ void bm_bounds(const Bm25Params &p, int64_t t_lo, int n_tok, int64_t d0, int64_t d1, int64_t *bounds) {
+template <typename P>
+__device__ __forceinline__ void bm_bounds(const P &p, int64_t t_lo, int n_tok, int64_t d0, int64_t d1, int64_t *bounds) {
   for (int i = threadIdx.x; i < 2 * n_tok; i += blockDim.x) {
     const int term = p.q_terms[t_lo + (i >> 1)];
     bounds[i] = bm_lower(p.docs, p.indptr[term], p.indptr[term + 1], (i & 1) ? d1 : d0);
@@ -337,6 +338,201 @@ __global__ __launch_bounds__(1024) void k_bm25_sparse(Bm25SparseParams p) {
   }
 }
 
+// ---- sparse rows beyond one LDS table (round 4): up to kSpMaxCapBig documents per row ---------------------------
+// A frequent-word query touches 10 K - 60 K documents — more than one workgroup's table holds.  The row is cut into SLICES
+// of the document range (query q owns slices [slice_base[q], slice_base[q + 1]): the host sizes them from the summed
+// posting lengths, about kSrTarget postings each, and no wider than kSrWidth ids).  One workgroup per slice:
+//   mark    one presence bit per document of the slice, from the slice of every posting list (bisected once, as above)
+//   rank    prefix sum of the bit counts: a touched document's position among the slice's touched documents IS its slot —
+//           no hashing, no probing, and the slots come out in ascending document order
+//   add     tokens in query order, a barrier between them, `vals[slot] += weight` (a list holds a document once): the
+//           additions of every document in the reference's order, one at a time -> the float64 sums of k_bm25
+//   out     (id, sum) into the slice's staging run, its count, its share of the row maximum (ordered 64-bit atomicMax)
+// k_bm25_slice_pack then strings a query's slices together — slices ascend in document range and each is ascending inside,
+// so the packed row is SORTED BY ID, which is what anr_fuse_dense asks of rows beyond its own LDS sort — dividing by the
+// row maximum exactly as k_bm25_sparse does.  A slice with more than kSrSlice documents or a row with more than `cap`
+// gives the row up (count -1), like the small kernel.
+constexpr int kSrSlice = 4096;     // documents per slice (float64 sums in LDS)
+constexpr int kSrWidth = 131072;   // ids a slice may span
+constexpr int kSrTarget = 2048;    // postings per slice the host aims at (>= documents: half the capacity as slack)
+constexpr int kSrMaxSlices = 1024; // slices per query (the pack kernel's prefix table)
+constexpr int kSpMaxCapBig = 65536;
+constexpr int kSrLds = kSrWidth / 8 + (kSrWidth / 32) * 4 + kSrSlice * 8;
+
+struct Bm25SliceParams {
+  const int64_t *indptr;
+  const int32_t *docs;
+  const double *weights;
+  int64_t n_docs;
+  const int64_t *q_indptr;
+  const int32_t *q_terms;
+  const int *slice_base;  // [nq + 1]
+  int nq, normalize, cap;
+  unsigned *st_id;        // [slices][kSrSlice]
+  double *st_val;
+  int *st_cnt;            // [slices]: documents, or -1 (more than kSrSlice)
+  unsigned long long *max_ord;  // [nq], zeroed
+  unsigned *out_id;       // [nq][cap]
+  double *out_val;
+  int *out_cnt;
+  double *max_out;        // [nq] or nullptr
+};
+
+__global__ __launch_bounds__(1024) void k_bm25_slice(Bm25SliceParams p) {
+  extern __shared__ unsigned char bm_smem[];
+  unsigned *bits = reinterpret_cast<unsigned *>(bm_smem);
+  unsigned *pre = bits + kSrWidth / 32;
+  double *vals = reinterpret_cast<double *>(pre + kSrWidth / 32);
+  __shared__ int64_t s_bounds[2 * kBmMaxTok];
+  __shared__ unsigned s_wave[16];
+  __shared__ double s_red[16];
+  const int sl = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int q;
+  {
+    int lo = 0, hi = p.nq - 1;  // the query whose slices hold sl
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (p.slice_base[mid] <= sl) lo = mid;
+      else hi = mid - 1;
+    }
+    q = lo;
+  }
+  const int R = p.slice_base[q + 1] - p.slice_base[q], r = sl - p.slice_base[q];
+  const int64_t d0 = p.n_docs * r / R, d1 = p.n_docs * (r + 1) / R;
+  const int nW = (int)((d1 - d0 + 31) >> 5);  // <= kSrWidth / 32 (the host's R)
+  const int64_t t_lo = p.q_indptr[q], t_hi = p.q_indptr[q + 1];
+  const bool one_block = t_hi - t_lo <= kBmMaxTok;
+  for (int i = tid; i < nW; i += 1024) bits[i] = 0u;
+  for (int i = tid; i < kSrSlice; i += 1024) vals[i] = 0.0;
+  __syncthreads();
+  for (int64_t tb = t_lo; tb < t_hi; tb += kBmMaxTok) {
+    const int n_tok = (int)(t_hi - tb < kBmMaxTok ? t_hi - tb : kBmMaxTok);
+    bm_bounds(p, tb, n_tok, d0, d1, s_bounds);
+    for (int i = 0; i < n_tok; ++i)
+      for (int64_t e = s_bounds[2 * i] + tid; e < s_bounds[2 * i + 1]; e += 1024) {
+        const unsigned rel = (unsigned)(p.docs[e] - d0);
+        atomicOr(&bits[rel >> 5], 1u << (rel & 31));
+      }
+    __syncthreads();
+  }
+  // exclusive prefix of the words' bit counts: four consecutive words per thread, a wave scan, the waves' totals
+  unsigned c[4], mine = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int w = tid * 4 + j;
+    c[j] = w < nW ? (unsigned)__popc(bits[w]) : 0u;
+    mine += c[j];
+  }
+  unsigned incl = mine;
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned t = __shfl_up(incl, o);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  unsigned base = incl - mine, total = 0;
+  for (int w = 0; w < 16; ++w) {
+    if (w < wave) base += s_wave[w];
+    total += s_wave[w];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int w = tid * 4 + j;
+    if (w < nW) pre[w] = base;
+    base += c[j];
+  }
+  if (total > (unsigned)kSrSlice) {  // (uniform)
+    if (tid == 0) p.st_cnt[sl] = -1;
+    return;
+  }
+  __syncthreads();
+  for (int64_t tb = t_lo; tb < t_hi; tb += kBmMaxTok) {
+    const int n_tok = (int)(t_hi - tb < kBmMaxTok ? t_hi - tb : kBmMaxTok);
+    if (!one_block) bm_bounds(p, tb, n_tok, d0, d1, s_bounds);  // (one block: the table is still valid)
+    for (int i = 0; i < n_tok; ++i) {
+      for (int64_t e = s_bounds[2 * i] + tid; e < s_bounds[2 * i + 1]; e += 1024) {
+        const unsigned rel = (unsigned)(p.docs[e] - d0);
+        const unsigned slot = pre[rel >> 5] + (unsigned)__popc(bits[rel >> 5] & ((1u << (rel & 31)) - 1u));
+        vals[slot] += p.weights[e];  // this token's only posting of the document
+      }
+      __syncthreads();  // token order == the reference's addition order
+    }
+  }
+  unsigned *oi = p.st_id + (int64_t)sl * kSrSlice;
+  double *ov = p.st_val + (int64_t)sl * kSrSlice;
+  for (int w = tid; w < nW; w += 1024) {
+    unsigned b = bits[w], pos = pre[w];
+    while (b) {
+      const int k = __ffs((int)b) - 1;
+      oi[pos++] = (unsigned)(d0 + (int64_t)w * 32 + k);
+      b &= b - 1u;
+    }
+  }
+  double m = -__builtin_inf();
+  for (int i = tid; i < (int)total; i += 1024) {
+    const double v = vals[i];
+    ov[i] = v;
+    m = fmax(m, v);
+  }
+  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+  if (lane == 0) s_red[wave] = m;
+  __syncthreads();
+  if (tid == 0) {
+    double mm = s_red[0];
+    for (int w = 1; w < 16; ++w) mm = fmax(mm, s_red[w]);
+    if (mm > -__builtin_inf()) atomicMax(p.max_ord + q, bm_d2ord(mm));
+    p.st_cnt[sl] = (int)total;
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_bm25_slice_pack(Bm25SliceParams p) {
+  __shared__ int s_off[kSrMaxSlices + 1];
+  __shared__ int s_bad;
+  const int q = blockIdx.x, tid = threadIdx.x;
+  const int s0 = p.slice_base[q], R = p.slice_base[q + 1] - s0;
+  if (tid == 0) s_bad = R == 0 ? 1 : 0;  // (no slices: the host gave the row up — postings beyond any capacity)
+  __syncthreads();
+  for (int r = tid; r < R; r += 1024) {
+    const int c = p.st_cnt[s0 + r];
+    s_off[r + 1] = c;
+    if (c < 0) s_bad = 1;
+  }
+  __syncthreads();
+  if (tid == 0 && !s_bad) {
+    s_off[0] = 0;
+    for (int r = 0; r < R; ++r) s_off[r + 1] += s_off[r];
+    if (s_off[R] > p.cap) s_bad = 1;
+  }
+  __syncthreads();
+  if (s_bad) {
+    if (tid == 0) {
+      p.out_cnt[q] = -1;
+      if (p.max_out) p.max_out[q] = __builtin_nan("");
+    }
+    return;
+  }
+  const int count = s_off[R];
+  // the row's maximum over all n_docs scores: the touched ones, and 0.0 when a document was left untouched
+  const unsigned long long mo = p.max_ord[q];
+  double mx = mo ? bm_ord2d(mo) : -__builtin_inf();
+  if ((int64_t)count < p.n_docs) mx = fmax(mx, 0.0);
+  const bool divide = p.normalize && mx > 0.0;
+  for (int r = 0; r < R; ++r) {
+    const int n = s_off[r + 1] - s_off[r];
+    const unsigned *si = p.st_id + (int64_t)(s0 + r) * kSrSlice;
+    const double *sv = p.st_val + (int64_t)(s0 + r) * kSrSlice;
+    for (int i = tid; i < n; i += 1024) {
+      const int64_t at = (int64_t)q * p.cap + s_off[r] + i;
+      p.out_id[at] = si[i];
+      p.out_val[at] = divide ? sv[i] / mx : sv[i];
+    }
+  }
+  if (tid == 0) {
+    p.out_cnt[q] = count;
+    if (p.max_out) p.max_out[q] = divide ? 1.0 : mx;
+  }
+}
+
 // compaction of the non-zero scores of each query: (doc, score) pairs, unordered
 struct NzParams {
   const double *scores;
@@ -430,6 +626,15 @@ struct anr_bm25 {
   unsigned long long *max_ord = nullptr;  // [max_ord_cap] row maxima of the range-split scoring (ordered images)
   int64_t max_ord_cap = 0;
   int n_cu = 256;
+  // the sliced sparse rows (cap > kSpMaxCap): host copy of the posting-list offsets (the slices are sized from the summed
+  // list lengths), the slices' staging runs and the slice table
+  std::vector<int64_t> h_indptr;
+  unsigned *st_id = nullptr;
+  double *st_val = nullptr;
+  int *st_cnt = nullptr;
+  int64_t st_cap = 0;      // slices the staging buffers hold
+  int *slice_base = nullptr;
+  int64_t slice_base_cap = 0;
 };
 
 namespace {
@@ -530,6 +735,77 @@ int score_chunk(anr_bm25 *h, int64_t nq, const int64_t *q_indptr, const int32_t 
   if (e != hipSuccess) return fail(ANR_EHIP, "bm25 scoring failed: %s", hipGetErrorString(e));
   return ANR_OK;
 }
+
+// rows of up to kSpMaxCapBig documents: k_bm25_slice + k_bm25_slice_pack, a sub-batch of queries at a time so that the
+// staging runs stay below ~768 MB
+int sparse_sliced(anr_bm25 *h, int64_t nq, const int64_t *q_indptr, const int32_t *q_terms, int normalize, int cap,
+                  uint32_t *ids_dev, double *scores_dev, int32_t *count_dev, double *max_dev, int32_t *out_count_host) {
+  const int64_t width_slices = std::max<int64_t>(1, ceil_div(h->n_docs, (int64_t)kSrWidth));
+  if (width_slices > kSrMaxSlices)
+    return fail(ANR_EINVAL, "sparse rows beyond %d documents need a corpus of at most %lld documents", kSpMaxCap,
+                (long long)kSrMaxSlices * kSrWidth);
+  // slices per query from the summed posting lengths (an upper bound of the documents touched); a query whose postings
+  // exceed four times the row capacity is given up here (no slices: count -1)
+  std::vector<int> n_sl((size_t)nq);
+  for (int64_t q = 0; q < nq; ++q) {
+    int64_t sum = 0;
+    for (int64_t t = q_indptr[q]; t < q_indptr[q + 1]; ++t) sum += h->h_indptr[q_terms[t] + 1] - h->h_indptr[q_terms[t]];
+    n_sl[q] = sum > 4 * (int64_t)cap ? 0 : (int)std::min<int64_t>(kSrMaxSlices, std::max<int64_t>(width_slices, ceil_div(sum, (int64_t)kSrTarget)));
+  }
+  ANR_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_bm25_slice), kSrLds));
+  const int64_t kMaxSlices = 16384;
+  std::vector<int64_t> rel;
+  std::vector<int> base;
+  for (int64_t q0 = 0; q0 < nq;) {
+    int64_t q1 = q0, total = 0;
+    while (q1 < nq && (q1 == q0 || total + n_sl[q1] <= kMaxSlices)) total += n_sl[q1++];
+    const int64_t m = q1 - q0;
+    base.assign((size_t)m + 1, 0);
+    for (int64_t i = 0; i < m; ++i) base[i + 1] = base[i] + n_sl[q0 + i];
+    if (total > h->st_cap) {
+      b_free(h->st_id);
+      b_free(h->st_val);
+      b_free(h->st_cnt);
+      h->st_cap = 0;
+      const int64_t want = total + total / 4;
+      ANR_TRY(b_alloc(&h->st_id, want * kSrSlice));
+      ANR_TRY(b_alloc(&h->st_val, want * kSrSlice));
+      ANR_TRY(b_alloc(&h->st_cnt, want));
+      h->st_cap = want;
+    }
+    if (m + 1 > h->slice_base_cap) {
+      b_free(h->slice_base);
+      h->slice_base_cap = 0;
+      ANR_TRY(b_alloc(&h->slice_base, 2 * (m + 1)));
+      h->slice_base_cap = 2 * (m + 1);
+    }
+    if (h->max_ord_cap < m) {
+      b_free(h->max_ord);
+      h->max_ord_cap = 0;
+      ANR_TRY(b_alloc(&h->max_ord, m));
+      h->max_ord_cap = m;
+    }
+    int64_t *dq = nullptr;
+    int32_t *dt = nullptr;
+    ANR_TRY(upload_queries(h, m, q_indptr + q0, q_terms, rel, &dq, &dt));
+    hipError_t e = hipMemcpyAsync(h->slice_base, base.data(), (size_t)(m + 1) * 4, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->max_ord, 0, (size_t)m * 8, h->stream);
+    if (e == hipSuccess) {
+      Bm25SliceParams p{h->indptr, h->docs, h->weights, h->n_docs, dq, dt, h->slice_base, (int)m, normalize, cap,
+                        h->st_id, h->st_val, h->st_cnt, h->max_ord, ids_dev + q0 * cap, scores_dev + q0 * cap,
+                        count_dev + q0, max_dev ? max_dev + q0 : nullptr};
+      if (total > 0) hipLaunchKernelGGL(k_bm25_slice, dim3((unsigned)total), dim3(1024), (size_t)kSrLds, h->stream, p);
+      hipLaunchKernelGGL(k_bm25_slice_pack, dim3((unsigned)m), dim3(1024), 0, h->stream, p);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess && out_count_host)
+      e = hipMemcpyAsync(out_count_host + q0, count_dev + q0, (size_t)m * 4, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);  // (`rel` / `base` are re-used by the next sub-batch)
+    if (e != hipSuccess) return fail(ANR_EHIP, "bm25 sparse scoring (sliced rows) failed: %s", hipGetErrorString(e));
+    q0 = q1;
+  }
+  return ANR_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -559,6 +835,7 @@ int anr_bm25_create(int32_t device, int64_t n_docs, int64_t n_terms, const int64
   h->n_docs = n_docs;
   h->n_terms = n_terms;
   h->nnz = nnz;
+  h->h_indptr.assign(indptr, indptr + n_terms + 1);
   int rc = ANR_OK;
   h->n_cu = device_cu_count(device);
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) rc = fail(ANR_EHIP, "hipStreamCreate failed");
@@ -588,6 +865,10 @@ int anr_bm25_destroy(anr_bm25 *h) {
   b_free(h->weights);
   b_free(h->q_buf);
   b_free(h->max_ord);
+  b_free(h->st_id);
+  b_free(h->st_val);
+  b_free(h->st_cnt);
+  b_free(h->slice_base);
   b_free(h->score_buf);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -630,11 +911,12 @@ int anr_bm25_sparse_dev(anr_bm25 *h, int64_t nq, const int64_t *q_indptr, const 
                         int32_t cap, uint32_t *ids_dev, double *scores_dev, int32_t *count_dev, double *max_dev,
                         int32_t *out_count_host) {
   ANR_TRY(validate_queries(h, nq, q_indptr, q_terms));
-  if (cap <= 0 || cap > kSpMaxCap) return fail(ANR_EINVAL, "cap must be in [1, %d]", kSpMaxCap);
+  if (cap <= 0 || cap > kSpMaxCapBig) return fail(ANR_EINVAL, "cap must be in [1, %d]", kSpMaxCapBig);
   if (!ids_dev || !scores_dev || !count_dev) return fail(ANR_EINVAL, "null output arrays");
   if (nq == 0) return ANR_OK;
   DeviceGuard g(h->device);
   std::lock_guard<std::mutex> lk(h->mu);
+  if (cap > kSpMaxCap) return sparse_sliced(h, nq, q_indptr, q_terms, normalize, cap, ids_dev, scores_dev, count_dev, max_dev, out_count_host);
   std::vector<int64_t> rel;
   int64_t *dq = nullptr;
   int32_t *dt = nullptr;

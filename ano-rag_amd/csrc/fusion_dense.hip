@@ -68,19 +68,21 @@ struct FdSrc {
 
 // An array source handed over in SPARSE form (anr_fuse_source.sparse_*): explicit (id, value) entries, every other id of
 // the row is 0.0.  Kept out of FdSrc so that the streaming scan's code and registers do not change.
-constexpr int kFsSpMax = 8192;  // explicit entries per row
+constexpr int kFsSpMax = 8192;      // explicit entries per row that k_fs_sort orders itself (one LDS bitonic network)
+constexpr int kFsSpMaxBig = 65536;  // ... per row when the caller hands the rows over SORTED BY ID (anr_bm25_sparse_dev does)
 struct FdSparse {
   int src;              // the source (0..2) given in this form, -1: none
   int cap;
-  const unsigned *in_id;   // the caller's rows [nq_total][cap], any order (indexed by q0 + q)
+  const unsigned *in_id;   // the caller's rows [nq_total][cap], any order — cap > kFsSpMax: ascending ids (indexed by q0 + q)
   const double *in_val;
   const int *in_cnt;
   unsigned *id;         // [nq][cap] this sub-batch's rows sorted by id (k_fs_sort), values beside them
   double *val;
   int *cnt;             // [nq]
   unsigned *err;        // one word, zeroed per sub-batch: bit 0 a row count < 0 (the producer's overflow mark), bit 1 a count
-                        // above cap, bit 2 an id >= the array length, bit 3 an id listed twice — anr_fuse_dense returns
-                        // ANR_EINVAL instead of fusing such a row as if its missing scores were 0.0
+                        // above cap, bit 2 an id >= the array length, bit 3 an id listed twice, bit 4 a row of a call with
+                        // cap > kFsSpMax that is not sorted by id — anr_fuse_dense returns ANR_EINVAL instead of fusing
+                        // such a row as if its missing scores were 0.0
 };
 
 struct FdParams {
@@ -1527,12 +1529,43 @@ __device__ __forceinline__ void fs_bitonic_u64(unsigned long long *key, int P2) 
     }
 }
 
+// the row's count; linear: its maximum (an implicit zero takes part when the row does not list every id) -> smax_ord
+__device__ __forceinline__ void fs_row_finish(const FdParams &p, int q, int nnz, double best, bool any, double *s_best,
+                                              int *s_any) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) p.sp.cnt[q] = nnz;
+  if (p.method != 0) return;
+  for (int o = 32; o > 0; o >>= 1) {
+    const double t = __shfl_xor(best, o);
+    const bool ta = __shfl_xor((int)any, o) != 0;
+    best = (ta && (!any || t > best)) ? t : best;
+    any = any || ta;
+  }
+  if (lane == 0) {
+    s_best[wave] = best;
+    s_any[wave] = any ? 1 : 0;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < kFsSortThreads / 64; ++w)
+      if (s_any[w] && (!any || s_best[w] > best)) {
+        best = s_best[w];
+        any = true;
+      }
+    if ((int64_t)nnz < p.src[p.sp.src].len) {  // an id that is not listed holds 0.0
+      best = (!any || 0.0 > best) ? 0.0 : best;
+      any = true;
+    }
+    p.smax_ord[(int64_t)q * 4 + p.sp.src] = any ? d2ord(best) : 0ull;
+  }
+}
+
 __global__ __launch_bounds__(kFsSortThreads) void k_fs_sort(FdParams p, int P2max) {
   extern __shared__ unsigned char fd_smem[];
   unsigned long long *key = reinterpret_cast<unsigned long long *>(fd_smem);  // (id << 32) | position in the caller's row
   __shared__ double s_best[kFsSortThreads / 64];
   __shared__ int s_any[kFsSortThreads / 64];
-  const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = blockIdx.x, tid = threadIdx.x;
   const int cap = p.sp.cap;
   int nnz = p.sp.in_cnt[p.q0 + q];
   if (tid == 0 && (nnz < 0 || nnz > cap)) atomicOr(p.sp.err, nnz < 0 ? 1u : 2u);
@@ -1562,31 +1595,36 @@ __global__ __launch_bounds__(kFsSortThreads) void k_fs_sort(FdParams p, int P2ma
       any = true;
     }
   }
-  if (tid == 0) p.sp.cnt[q] = nnz;
-  if (p.method != 0) return;
-  for (int o = 32; o > 0; o >>= 1) {
-    const double t = __shfl_xor(best, o);
-    const bool ta = __shfl_xor((int)any, o) != 0;
-    best = (ta && (!any || t > best)) ? t : best;
-    any = any || ta;
-  }
-  if (lane == 0) {
-    s_best[wave] = best;
-    s_any[wave] = any ? 1 : 0;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    for (int w = 1; w < kFsSortThreads / 64; ++w)
-      if (s_any[w] && (!any || s_best[w] > best)) {
-        best = s_best[w];
-        any = true;
-      }
-    if ((int64_t)nnz < p.src[p.sp.src].len) {  // an id that is not listed holds 0.0
-      best = (!any || 0.0 > best) ? 0.0 : best;
+  fs_row_finish(p, q, nnz, best, any, s_best, s_any);
+}
+
+// rows beyond the LDS sort arrive sorted by id: checked (strictly ascending, below the array length), copied, finished
+__global__ __launch_bounds__(kFsSortThreads) void k_fs_take(FdParams p) {
+  __shared__ double s_best[kFsSortThreads / 64];
+  __shared__ int s_any[kFsSortThreads / 64];
+  const int q = blockIdx.x, tid = threadIdx.x;
+  const int cap = p.sp.cap;
+  int nnz = p.sp.in_cnt[p.q0 + q];
+  if (tid == 0 && (nnz < 0 || nnz > cap)) atomicOr(p.sp.err, nnz < 0 ? 1u : 2u);
+  nnz = nnz < 0 ? 0 : (nnz > cap ? cap : nnz);
+  const unsigned *gi = p.sp.in_id + (p.q0 + q) * (int64_t)cap;
+  const double *gv = p.sp.in_val + (p.q0 + q) * (int64_t)cap;
+  const unsigned alen = (unsigned)(p.src[p.sp.src].len > 0xffffffffll ? 0xffffffffll : p.src[p.sp.src].len);
+  double best = 0.0;
+  bool any = false;
+  for (int i = tid; i < nnz; i += kFsSortThreads) {
+    const unsigned id = gi[i];
+    const double v = gv[i];
+    if (id >= alen) atomicOr(p.sp.err, 4u);
+    if (i > 0 && gi[i - 1] >= id) atomicOr(p.sp.err, gi[i - 1] == id ? 8u : 16u);
+    p.sp.id[(int64_t)q * cap + i] = id;
+    p.sp.val[(int64_t)q * cap + i] = v;
+    if (v == v) {
+      best = (!any || v > best) ? v : best;
       any = true;
     }
-    p.smax_ord[(int64_t)q * 4 + p.sp.src] = any ? d2ord(best) : 0ull;
   }
+  fs_row_finish(p, q, nnz, best, any, s_best, s_any);
 }
 
 struct FsStageShared {
@@ -1597,6 +1635,8 @@ struct FsStageShared {
   unsigned nzc[kFdMaxSparse + 1];  // listed entries that are not zeros, per interval of the zero-valued short-list ids
 };
 
+// BIG (rows beyond kFsSpMax entries): the sorted ids are bisected where they lie, in global memory
+template <bool BIG>
 __global__ __launch_bounds__(kFdThreads) void k_fs_stage(FdParams p) {
   extern __shared__ unsigned char fd_smem[];
   FsStageShared &sh = *reinterpret_cast<FsStageShared *>(fd_smem);
@@ -1607,7 +1647,12 @@ __global__ __launch_bounds__(kFdThreads) void k_fs_stage(FdParams p) {
   const unsigned *gid = p.sp.id + (int64_t)q * cap;
   const double *gval = p.sp.val + (int64_t)q * cap;
   const unsigned long long kzero = 0x8000000000000000ull;  // d2ord(0.0)
-  for (int i = tid; i < nnz; i += kFdThreads) sh.sid[i] = gid[i];
+  if constexpr (!BIG)
+    for (int i = tid; i < nnz; i += kFdThreads) sh.sid[i] = gid[i];
+  auto sid = [&](int i) -> unsigned {
+    if constexpr (BIG) return gid[i];
+    else return sh.sid[i];
+  };
   int skn = 0;
   if (p.method == 1) {
     skn = p.sk_n[q];
@@ -1642,7 +1687,7 @@ __global__ __launch_bounds__(kFdThreads) void k_fs_stage(FdParams p) {
     p.c_hi[at] = key;
     p.c_id[at] = id;
   };
-  for (int i = tid; i < nnz; i += kFdThreads) emit(i, key_of(gval[i]), sh.sid[i]);
+  for (int i = tid; i < nnz; i += kFdThreads) emit(i, key_of(gval[i]), sid(i));
   // the j-th id that is not listed = j + (listed ids below it): the first i with sid[i] - i > j
   const int64_t missing = N - nnz;
   const int nz = (int)(missing < kp ? (missing > 0 ? missing : 0) : kp);
@@ -1651,7 +1696,7 @@ __global__ __launch_bounds__(kFdThreads) void k_fs_stage(FdParams p) {
     int lo = 0, hi = nnz;
     while (lo < hi) {
       const int mid = (lo + hi) >> 1;
-      if ((int64_t)sh.sid[mid] - mid > j) hi = mid;
+      if ((int64_t)sid(mid) - mid > j) hi = mid;
       else lo = mid + 1;
     }
     emit(nnz + j, kz, (unsigned)(j + lo));
@@ -1685,7 +1730,7 @@ __global__ __launch_bounds__(kFdThreads) void k_fs_stage(FdParams p) {
   const unsigned *Z = sh.sk_id + z_lo;
   for (int i = tid; i < nnz; i += kFdThreads) {
     const double v = gval[i];
-    const unsigned id = sh.sid[i];
+    const unsigned id = sid(i);
     if (v == 0.0) continue;  // counted with the zeros below
     int lo = 0, hi = m;      // zero-valued short-list ids below this id
     while (lo < hi) {
@@ -1756,8 +1801,8 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
       if (src[s].array_dev || src[s].list_offs) return fail(ANR_EINVAL, "source %d is given in two forms", s);
       if (s == 3 || sp_src >= 0) return fail(ANR_EINVAL, "one of dense / bm25 / graph may be given in sparse form");
       if (!src[s].sparse_scores_dev || !src[s].sparse_count_dev) return fail(ANR_EINVAL, "source %d: null sparse arrays", s);
-      if (src[s].sparse_cap <= 0 || src[s].sparse_cap > kFsSpMax)
-        return fail(ANR_EINVAL, "source %d: sparse_cap must be in [1, %d]", s, kFsSpMax);
+      if (src[s].sparse_cap <= 0 || src[s].sparse_cap > kFsSpMaxBig)
+        return fail(ANR_EINVAL, "source %d: sparse_cap must be in [1, %d]", s, kFsSpMaxBig);
       if (src[s].array_len <= 0 || src[s].array_len > 0xfffffff0ll) return fail(ANR_EINVAL, "source %d: bad array length", s);
       sp_src = s;
       ++n_arr;
@@ -1826,8 +1871,9 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
   const int sp_cap = sparse ? (int)src[sp_src].sparse_cap : 0;
   // (sparse: the "chunks" are just consecutive runs of the staged candidates — the entries and up to K' unlisted ids)
   const int n_chunks = sparse ? (int)ceil_div(sp_cap + kFdMaxK, lcap) : (int)ceil_div(U, kFsChunk);
+  const bool sp_big = sp_cap > kFsSpMax;  // rows the caller sorted by id (k_fs_take checks)
   int sp_p2 = 2;
-  while (sp_p2 < sp_cap) sp_p2 <<= 1;
+  while (sp_p2 < sp_cap && !sp_big) sp_p2 <<= 1;
   // query sub-batches so that the candidate lists stay below ~1 GiB
   const int64_t per_q = (int64_t)n_chunks * lcap * 12;
   const int64_t QB = std::max<int64_t>(1, std::min<int64_t>(nq, ((int64_t)1 << 30) / std::max<int64_t>(per_q, 1)));
@@ -1865,8 +1911,9 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
   ANR_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_fd_scan<1, 1>), (int)sizeof(FsShared)));
   ANR_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_fd_build), (int)sizeof(FdShared)));
   if (sparse) {
-    ANR_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_fs_sort), sp_p2 * 8));
-    ANR_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_fs_stage), (int)sizeof(FsStageShared)));
+    if (!sp_big) ANR_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_fs_sort), sp_p2 * 8));
+    ANR_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_fs_stage<false>), (int)sizeof(FsStageShared)));
+    ANR_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_fs_stage<true>), (int)sizeof(FsStageShared)));
   }
   ANR_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_fuse<true>), (int)sizeof(FuseShared)));
   hipEvent_t ev[2] = {nullptr, nullptr};
@@ -1950,9 +1997,11 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
       // the entries replace the stream: sort them by id (the lookup table of prep / build), then stage what the scan
       // would have left — candidates, the rank histogram, the row maximum
       if (timed) (void)hipEventRecord(ev[0], st);
-      hipLaunchKernelGGL(k_fs_sort, dim3((unsigned)nb), dim3(kFsSortThreads), (size_t)sp_p2 * 8, st, p, sp_p2);
+      if (sp_big) hipLaunchKernelGGL(k_fs_take, dim3((unsigned)nb), dim3(kFsSortThreads), 0, st, p);
+      else hipLaunchKernelGGL(k_fs_sort, dim3((unsigned)nb), dim3(kFsSortThreads), (size_t)sp_p2 * 8, st, p, sp_p2);
       hipLaunchKernelGGL(k_fd_prep, dim3((unsigned)nb), dim3(kFdThreads), 0, st, p);
-      hipLaunchKernelGGL(k_fs_stage, dim3((unsigned)nb), dim3(kFdThreads), sizeof(FsStageShared), st, p);
+      if (sp_big) hipLaunchKernelGGL(k_fs_stage<true>, dim3((unsigned)nb), dim3(kFdThreads), sizeof(FsStageShared), st, p);
+      else hipLaunchKernelGGL(k_fs_stage<false>, dim3((unsigned)nb), dim3(kFdThreads), sizeof(FsStageShared), st, p);
     } else {
       hipLaunchKernelGGL(k_fd_prep, dim3((unsigned)nb), dim3(kFdThreads), 0, st, p);
       if (timed) (void)hipEventRecord(ev[0], st);
@@ -2024,10 +2073,11 @@ extern "C" int anr_fuse_dense(int32_t device, int32_t method, int64_t nq, const 
       unsigned err = 0;
       std::memcpy(&err, Hs + h_out + o_err, 4);
       if (err) {
-        rc = fail(ANR_EINVAL, "fuse_dense: malformed sparse rows in queries %lld..%lld:%s%s%s%s", (long long)q0, (long long)(q0 + nb - 1),
+        rc = fail(ANR_EINVAL, "fuse_dense: malformed sparse rows in queries %lld..%lld:%s%s%s%s%s", (long long)q0, (long long)(q0 + nb - 1),
                   (err & 1u) ? " a row count < 0 (the producer's overflow mark: that query needs the N-vector form)" : "",
                   (err & 2u) ? " a row count above the row capacity" : "", (err & 4u) ? " an id >= array_len" : "",
-                  (err & 8u) ? " an id listed twice" : "");
+                  (err & 8u) ? " an id listed twice" : "",
+                  (err & 16u) ? " a row of a call with sparse_cap > 8192 that is not sorted by id" : "");
         break;
       }
     }

@@ -331,8 +331,8 @@ class HybridSearcher:
         """EXTENSION: BM25 scoring and fusion back to back on the device — ``bm25_scores`` (utils/bm25_search.py:286-340)
         feeding ``fuse`` (hybrid_search.py:34-103) for a batch of tokenised queries, same results as
         ``fuse_arrays(bm25=corpus.scores_device(queries))``.  A query whose postings touch at most
-        ``corpus.SPARSE_CAP`` documents is handed over in sparse form (its N-vector is never formed); the others take
-        the N-vector path.  ``corpus``: a ``DeviceBM25``; dense / graph / path: per query ``(ids, scores)`` or None."""
+        ``corpus.SPARSE_CAP_MAX`` (65 536) documents is handed over in sparse form (its N-vector is never formed); the
+        others take the N-vector path.  ``corpus``: a ``DeviceBM25``; dense / graph / path: per query ``(ids, scores)`` or None."""
         nq = len(queries)
         if not self.enabled or int(self.candidate_pool) <= 0 or nq == 0:
             return [[] for _ in range(nq)]

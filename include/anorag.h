@@ -79,7 +79,9 @@ int anr_index_search_dev(anr_index *h, const float *q_dev, int64_t nq, int32_t k
 
 /* Asynchronous form: enqueues the search and returns.  Up to three batches are in flight (rotating workspaces), so
  * successive calls queue back to back on the device with no host synchronisation in between; `stream` is the stream the
- * queries were produced on (the batch waits for it when it is busy).  D_dev / I_dev of calls still in flight must be
+ * queries were produced on (the batch waits for it when it is busy; NULL is the handle's own stream, NOT the legacy null
+ * stream — queries produced on the null stream are handed over through a stream that waits for it, as
+ * anorag_hip.sharded.ShardedStream.submit does).  D_dev / I_dev of calls still in flight must be
  * distinct buffers.  Results may be READ only after anr_index_wait() / anr_index_sync() have retired the batch: retiring
  * waits for it, runs the exact path for the queries whose certificate failed (patching D_dev / I_dev) and folds the
  * statistics.  (Until round 4 every call also made `stream` wait for the batch — ANR_OPT_STREAM_WAIT 1 restores that; the
@@ -246,7 +248,9 @@ typedef struct anr_fuse_source {
    * < N; every other id < N holds 0.0 (an explicit NaN marks an absent id) — what anr_bm25_sparse_dev leaves on the device
    * for a query whose postings touch a few thousand of the N notes.  Results are bit-identical to the same row handed
    * over as a dense array; the corpus-wide stream is replaced by work proportional to the entries.  At most ONE source
-   * may be sparse (dense / bm25 / graph), the others are then short lists; sparse_cap <= 8192. */
+   * may be sparse (dense / bm25 / graph), the others are then short lists.  sparse_cap <= 8192: rows in any order (sorted
+   * in LDS here); 8192 < sparse_cap <= 65536: every row of the call ASCENDING BY ID (checked on the device, ANR_EINVAL
+   * otherwise) — the form anr_bm25_sparse_dev produces beyond 6144 documents. */
   const uint32_t *sparse_ids_dev;   /* device [nq][sparse_cap], or NULL */
   const double *sparse_scores_dev;  /* device [nq][sparse_cap]          */
   const int32_t *sparse_count_dev;  /* device [nq]                      */
@@ -361,11 +365,15 @@ int anr_bm25_combine_fields(int32_t device, int32_t n_fields, const double *cons
                             const double *weights, int64_t nq, int64_t n_docs, int32_t normalize, double *out_dev,
                             double *max_dev);
 /* The scores of anr_bm25_scores_dev in SPARSE form, left on the device for anr_fuse_dense (anr_fuse_source.sparse_*): per
- * query the documents its postings touch, unordered — ids_dev / scores_dev [nq][cap] (cap <= 6144), count_dev [nq], max_dev
+ * query the documents its postings touch — ids_dev / scores_dev [nq][cap] (cap <= 65536), count_dev [nq], max_dev
  * [nq] (may be NULL; the maximum over all n_docs scores, the untouched zeros included).  The N-vector is never
- * materialised: a workgroup accumulates its query in an LDS table, additions in the reference's token order, so every
- * score equals anr_bm25_scores' bit for bit.  A query that touches more than cap documents gets count -1 (its row is
- * unusable: score that query with anr_bm25_scores_dev).  out_count_host (may be NULL): the counts, copied back. */
+ * materialised.  cap <= 6144: a workgroup accumulates its query in an LDS hash table, rows unordered; 6144 < cap <= 65536
+ * (round 4): the row is cut into slices of the document range, one workgroup per slice (presence bits -> rank = slot, sums
+ * in LDS), rows ASCENDING BY ID — what anr_fuse_dense asks of rows beyond 8192 entries.  Either way a document's additions
+ * happen one at a time in the reference's token order, so every score equals anr_bm25_scores' bit for bit.  A query that
+ * touches more than cap documents gets count -1 (its row is unusable: score that query with anr_bm25_scores_dev); so does
+ * (cap > 6144) one whose summed posting lengths exceed 4 cap or one slice of which holds more than 4096 documents.
+ * out_count_host (may be NULL): the counts, copied back. */
 int anr_bm25_sparse_dev(anr_bm25 *h, int64_t nq, const int64_t *q_indptr, const int32_t *q_terms, int32_t normalize,
                         int32_t cap, uint32_t *ids_dev, double *scores_dev, int32_t *count_dev, double *max_dev,
                         int32_t *out_count_host);

@@ -98,7 +98,10 @@ def _short_lists(rng, rows, n, m, nq):
     (7, 5, 10, 6, ("zeros",)),
     (1, 1, 5, 1, ()),
     (4096, 0, 30, 50, ()),                             # rows without a single entry
-    (200_000, 8192, 100, 1000, ("zeros", "neg", "ties", "nan")),   # the largest row, the longest short lists
+    (200_000, 8192, 100, 1000, ("zeros", "neg", "ties", "nan")),   # the largest row the fusion sorts itself, the longest short lists
+    (1_000_000, 20_000, 80, 100, ("zeros",)),          # rows beyond the LDS sort (handed over sorted by id): a frequent-word query
+    (70_000, 65_536, 100, 400, ("zeros", "neg", "ties", "nan")),   # the largest row there is
+    (9000, 9000, 300, 900, ("zeros", "neg")),          # ... and one that lists every id
 ])
 def test_sparse_rows_fuse_like_the_dense_array(method, n, nnz_max, pool, m, kinds):
     from anorag_hip.fusion import DeviceArray, SparseRows, fuse_dense
@@ -181,8 +184,62 @@ def test_bm25_sparse_rows_equal_the_dense_scores_bit_for_bit():
             mask[ids] = False
             assert not full[i][mask].any()
         sp.free()
-    # a frequent word touches more documents than a row holds: the caller is told to take the dense path
-    assert dev.scores_sparse_device([[vocab[0]]] + toks[:3]) is None
+    # a frequent word touches more documents than ONE table holds: refused at that capacity, held by the sliced rows
+    assert dev.scores_sparse_device([[vocab[0]]] + toks[:3], cap=dev.SPARSE_CAP) is None
+    sp = dev.scores_sparse_device([[vocab[0]]] + toks[:3])
+    assert sp is not None and sp.cap > dev.SPARSE_CAP and int(sp.counts[0]) > dev.SPARSE_CAP
+    sp.free()
+    dev.close()
+
+
+def test_bm25_sliced_sparse_rows_equal_the_dense_scores_bit_for_bit():
+    """rows of up to 65 536 documents (anr_bm25_sparse_dev beyond one LDS table: document-range slices, rank = slot):
+    every entry equals anr_bm25_scores' bit for bit, every other document is 0.0, ids ascending"""
+    from anorag_hip import bm25_search as dbm
+    rng = np.random.default_rng(21)
+    vocab, probs, notes = _corpus(rng, 150_000, 20_000, 14)     # more documents than one slice may span (131 072 ids)
+    dev = dbm.build_bm25_corpus(notes, lambda n: f"{n.get('title', '')} {n.get('content', '')}")
+    queries = [" ".join(rng.choice(vocab[4:300], size=rng.integers(1, 7), p=probs[4:300] / probs[4:300].sum())) for _ in range(20)]
+    queries += [f"{vocab[3]} {vocab[3]} {vocab[4]} {vocab[900]}",   # a token twice
+                " ".join(vocab[5:45]),                              # forty frequent words
+                vocab[1], vocab[15000], "zzz", ""]
+    toks = [dbm.tokenize_text(q) for q in queries]
+    heavy = [dbm.tokenize_text(f"{vocab[0]} {vocab[1]}")]            # more than half the corpus: more than any row holds
+    for normalize in (True, False):
+        full = dev.scores_batch(toks, normalize=normalize)
+        sp = dev.scores_sparse_device(toks, normalize=normalize, allow_overflow=True)
+        assert sp.cap > dev.SPARSE_CAP
+        lib_rows = sp.numpy()
+        ids_raw = np.empty((sp.nq, sp.cap), dtype=np.uint32)
+        from anorag_hip import _lib
+        _lib.check(_lib.load().anr_device_copy(sp.device, ids_raw.ctypes.data, sp.ids_ptr, ids_raw.nbytes, 1), "anr_device_copy")
+        n_big = 0
+        for i in range(len(queries)):
+            nz = np.nonzero(full[i])[0]
+            if sp.counts[i] < 0:                                    # given up: it must really not fit
+                assert len(nz) > sp.cap, (i, len(nz), sp.cap)
+                continue
+            ids, val = lib_rows[i]
+            k = int(sp.counts[i])
+            assert len(ids) == k and np.all(np.diff(ids_raw[i, :k].astype(np.int64)) > 0)     # ascending on the device
+            assert set(nz.tolist()) <= set(ids.tolist())
+            assert val.tobytes() == full[i][ids].tobytes()
+            mask = np.ones(full.shape[1], dtype=bool)
+            mask[ids] = False
+            assert not full[i][mask].any()
+            n_big += k > dev.SPARSE_CAP
+        assert n_big >= 8 and (sp.counts >= 0).sum() >= len(queries) // 2, (n_big, sp.counts.tolist())
+        sp.free()
+    rows = dev.scores_sparse_device(heavy + toks[:2], allow_overflow=True)
+    assert rows.cap == dev.SPARSE_CAP_MAX and rows.counts[0] == -1 and (rows.counts[1:] > 0).all()
+    rows.free()
+    # a capacity between the two forms that the query does not fit / fits
+    one = [dbm.tokenize_text(vocab[40])]
+    need = int(np.count_nonzero(dev.scores_batch(one, normalize=False)[0]))
+    assert need > 100
+    r = dev.scores_sparse_device(one, cap=7000, allow_overflow=True)
+    assert r.counts.tolist() == ([need] if need <= 7000 else [-1])
+    r.free()
     dev.close()
 
 
@@ -237,12 +294,22 @@ def test_fuse_bm25_sends_heavy_queries_down_the_vector_path(method):
     hs = HybridSearcher({"retrieval": {"candidate_pool": 50, "hybrid": {
         "enabled": True, "fusion_method": method, "rrf_k": 60,
         "weights": {"dense": 1.0, "bm25": 0.5, "graph": 0.5, "path": 0.1}}}})
-    rows = dev.scores_sparse_device(toks, allow_overflow=True)
+    rows = dev.scores_sparse_device(toks, cap=dev.SPARSE_CAP, allow_overflow=True)
     assert rows.counts[2] == -1 and rows.counts[7] == -1 and (rows.counts >= 0).sum() >= 6
     rows.free()
     full = dev.scores_device(toks, normalize=True)
     exp = hs.fuse_arrays(nq, dense=dense, bm25=full)
     full.free()
+    # the rows as large as they come (round 4): no query leaves the sparse path
+    rows = dev.scores_sparse_device(toks, allow_overflow=True)
+    assert (rows.counts >= 0).all() and rows.counts[2] > dev.SPARSE_CAP
+    rows.free()
+    assert hs.fuse_bm25(dev, toks, dense=dense) == exp
+    # ... and with rows too small for the frequent words: those two queries take the N-vector
+    dev.SPARSE_CAP_MAX = 8192
+    rows = dev.scores_sparse_device(toks, allow_overflow=True)
+    assert rows.counts[2] == -1 and rows.counts[7] == -1 and (rows.counts >= 0).sum() >= 6
+    rows.free()
     assert hs.fuse_bm25(dev, toks, dense=dense) == exp
     # mostly frequent-word queries: the whole batch takes the N-vector path
     toks2 = [dbm.tokenize_text(f"{vocab[i % 3]} {vocab[50 + i]}") for i in range(6)] + toks[:2]
@@ -260,8 +327,8 @@ def test_sparse_producer_and_consumer_refuse_what_they_cannot_hold():
     vocab, probs, notes = _corpus(rng, 2000, 500, 12)
     dev = dbm.build_bm25_corpus(notes, lambda n: n["content"])
     toks = [dbm.tokenize_text(vocab[20])]
-    with pytest.raises(_lib.AnoragError):          # more than the LDS table can take
-        dev.scores_sparse_device(toks, cap=dev.SPARSE_CAP + 1)
+    with pytest.raises(_lib.AnoragError):          # more than a row can take
+        dev.scores_sparse_device(toks, cap=dev.SPARSE_CAP_MAX + 1)
     with pytest.raises(_lib.AnoragError):
         dev.scores_sparse_device(toks, cap=0)
     assert dev.scores_sparse_device([], cap=16).nq == 0          # no queries: nothing to do
@@ -291,6 +358,14 @@ def test_sparse_producer_and_consumer_refuse_what_they_cannot_hold():
         with pytest.raises(_lib.AnoragError, match=what):
             fuse_dense("linear", w0, 60.0, 5, 1, {"dense": dl, "bm25": r})
         r.free()
+    # rows beyond the fusion's own sort must arrive in id order
+    big_ids = np.arange(9000, dtype=np.uint32)
+    big_ids[[10, 11]] = big_ids[[11, 10]]
+    r = SparseRows.from_numpy([(np.arange(9000), np.ones(9000))], 20_000)
+    _lib.check(_lib.load().anr_device_copy(0, r.ids_ptr, big_ids.ctypes.data, big_ids.nbytes, 0), "anr_device_copy")
+    with pytest.raises(_lib.AnoragError, match="not sorted"):
+        fuse_dense("linear", w0, 60.0, 5, 1, {"dense": dl, "bm25": r})
+    r.free()
     r = SparseRows.from_numpy([(np.array([1, 2]), np.array([1.0, 2.0]))], 50, cap=4)
     cnt = np.array([9], dtype=np.int32)
     _lib.check(_lib.load().anr_device_copy(0, r.count_ptr, cnt.ctypes.data, 4, 0), "anr_device_copy")
