@@ -177,6 +177,11 @@ SIGNATURES = {
         C.c_int,
         [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p],
     ),
+    "anr_encoder_forward_shared": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p],
+    ),
+    "anr_encoder_shared_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 _lib = None

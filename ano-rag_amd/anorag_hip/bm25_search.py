@@ -74,8 +74,8 @@ class DeviceBM25:
         self._post_len = np.diff(indptr)  # documents per term: sizes the sparse rows (scores_sparse_device)
         self._lib = _lib.load()
         h = C.c_void_p()
-        _lib.check(self._lib.anr_bm25_create(int(device), self.doc_count, n_terms, indptr.ctypes.data_as(C.c_void_p),
-                                             docs.ctypes.data_as(C.c_void_p), weights.ctypes.data_as(C.c_void_p),
+        _lib.check(self._lib.anr_bm25_create(int(device), self.doc_count, n_terms, indptr.ctypes.data,
+                                             docs.ctypes.data, weights.ctypes.data,
                                              C.byref(h)), "anr_bm25_create")
         self._h = h
 
@@ -94,9 +94,9 @@ class DeviceBM25:
         """[nq, n_docs] float64"""
         indptr, terms = self._encode_queries(queries)
         out = np.zeros((len(queries), self.doc_count), dtype=np.float64)
-        _lib.check(self._lib.anr_bm25_scores(self._h, len(queries), indptr.ctypes.data_as(C.c_void_p),
-                                             terms.ctypes.data_as(C.c_void_p), int(bool(normalize)),
-                                             out.ctypes.data_as(C.c_void_p)), "anr_bm25_scores")
+        _lib.check(self._lib.anr_bm25_scores(self._h, len(queries), indptr.ctypes.data,
+                                             terms.ctypes.data, int(bool(normalize)),
+                                             out.ctypes.data), "anr_bm25_scores")
         return out
 
     def scores_device(self, queries: Sequence[Sequence[str]], normalize: bool = True):
@@ -106,8 +106,8 @@ class DeviceBM25:
         indptr, terms = self._encode_queries(queries)
         out = DeviceArray(len(queries), self.doc_count, np.float64, self.device)
         out.row_max = DeviceArray(len(queries), 1, np.float64, self.device)  # by-product: each row's maximum
-        _lib.check(self._lib.anr_bm25_scores_dev(self._h, len(queries), indptr.ctypes.data_as(C.c_void_p),
-                                                 terms.ctypes.data_as(C.c_void_p), int(bool(normalize)),
+        _lib.check(self._lib.anr_bm25_scores_dev(self._h, len(queries), indptr.ctypes.data,
+                                                 terms.ctypes.data, int(bool(normalize)),
                                                  C.c_void_p(out.ptr), C.c_void_p(out.row_max.ptr)), "anr_bm25_scores_dev")
         return out
 
@@ -133,11 +133,11 @@ class DeviceBM25:
             cap = self.SPARSE_CAP if need <= self.SPARSE_CAP else min(self.SPARSE_CAP_MAX, -(-need // 1024) * 1024)
         out = SparseRows(nq, self.doc_count, cap, self.device)
         cnt = np.empty((nq,), dtype=np.int32)
-        _lib.check(self._lib.anr_bm25_sparse_dev(self._h, nq, indptr.ctypes.data_as(C.c_void_p),
-                                                 terms.ctypes.data_as(C.c_void_p), int(bool(normalize)), int(cap),
+        _lib.check(self._lib.anr_bm25_sparse_dev(self._h, nq, indptr.ctypes.data,
+                                                 terms.ctypes.data, int(bool(normalize)), int(cap),
                                                  C.c_void_p(out.ids_ptr), C.c_void_p(out.scores_ptr),
                                                  C.c_void_p(out.count_ptr), C.c_void_p(out.max_ptr),
-                                                 cnt.ctypes.data_as(C.c_void_p)), "anr_bm25_sparse_dev")
+                                                 cnt.ctypes.data), "anr_bm25_sparse_dev")
         if nq and int(cnt.min()) < 0 and not allow_overflow:
             out.free()
             return None
@@ -151,10 +151,10 @@ class DeviceBM25:
         docs = np.empty((nq, cap), dtype=np.int32)
         sc = np.empty((nq, cap), dtype=np.float64)
         cnt = np.empty((nq,), dtype=np.int32)
-        _lib.check(self._lib.anr_bm25_nonzero(self._h, nq, indptr.ctypes.data_as(C.c_void_p),
-                                              terms.ctypes.data_as(C.c_void_p), int(bool(normalize)), int(cap),
-                                              docs.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p),
-                                              cnt.ctypes.data_as(C.c_void_p)), "anr_bm25_nonzero")
+        _lib.check(self._lib.anr_bm25_nonzero(self._h, nq, indptr.ctypes.data,
+                                              terms.ctypes.data, int(bool(normalize)), int(cap),
+                                              docs.ctypes.data, sc.ctypes.data,
+                                              cnt.ctypes.data), "anr_bm25_nonzero")
         out = []
         for i in range(nq):
             n = min(int(cnt[i]), cap)
@@ -205,7 +205,7 @@ class DeviceFieldWeightedBM25:
         ptrs = (C.c_void_p * len(parts))(*[p.ptr for p in parts])
         w = np.asarray([float(v) for v in self.field_weights.values()], dtype=np.float64)
         try:
-            _lib.check(_lib.load().anr_bm25_combine_fields(self.device, len(parts), ptrs, w.ctypes.data_as(C.c_void_p), nq,
+            _lib.check(_lib.load().anr_bm25_combine_fields(self.device, len(parts), ptrs, w.ctypes.data, nq,
                                                            self.doc_count, int(bool(normalize)), C.c_void_p(out.ptr),
                                                            C.c_void_p(out.row_max.ptr)),
                        "anr_bm25_combine_fields")

@@ -68,7 +68,7 @@ def fuse_candidates(mode: str, vector_scores: Sequence[Sequence[float]], bm25_sc
     order = np.empty(total, dtype=np.int32)
 
     def ptr(x):
-        return x.ctypes.data_as(C.c_void_p) if x is not None else None
+        return x.ctypes.data if x is not None else None
     _lib.check(_lib.load().anr_fuse_candidates(int(device), MODES[mode], nq, ptr(offs), ptr(a), ptr(b), ptr(fl), ptr(ne),
                                                ptr(npd), ptr(mult), float(vector_weight), float(bm25_weight),
                                                float(rrf_k), float(noise_threshold), ptr(score), ptr(order)),

@@ -206,12 +206,14 @@ class DeviceEncoder:
         self._h = h
         for name, arr in tensors.items():
             a = np.ascontiguousarray(arr, dtype=np.float32)
-            _lib.check(self._lib.anr_encoder_set_tensor(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), a.size),
+            _lib.check(self._lib.anr_encoder_set_tensor(self._h, name.encode(), a.ctypes.data, a.size),
                        f"anr_encoder_set_tensor({name})")
         _lib.check(self._lib.anr_encoder_finalize(self._h), "anr_encoder_finalize")
 
     def forward(self, ids: np.ndarray, lengths: np.ndarray, type_ids: Optional[np.ndarray] = None,
-                normalize: bool = False) -> np.ndarray:
+                normalize: bool = False, shared: bool = False) -> np.ndarray:
+        """``shared``: through ``anr_encoder_forward_shared`` — calls from other threads that arrive while a forward runs
+        are merged into the next one (small requests only; bit-identical results)"""
         ids = np.ascontiguousarray(ids, dtype=np.int32)
         lengths = np.ascontiguousarray(lengths, dtype=np.int32)
         B, L = ids.shape
@@ -219,11 +221,17 @@ class DeviceEncoder:
         tp = None
         if type_ids is not None:
             type_ids = np.ascontiguousarray(type_ids, dtype=np.int32)
-            tp = type_ids.ctypes.data_as(C.c_void_p)
-        _lib.check(self._lib.anr_encoder_forward(self._h, ids.ctypes.data_as(C.c_void_p),
-                                                 lengths.ctypes.data_as(C.c_void_p), tp, B, L, int(bool(normalize)),
-                                                 out.ctypes.data_as(C.c_void_p)), "anr_encoder_forward")
+            tp = type_ids.ctypes.data
+        fn = self._lib.anr_encoder_forward_shared if shared else self._lib.anr_encoder_forward
+        _lib.check(fn(self._h, ids.ctypes.data, lengths.ctypes.data, tp, B, L,
+                      int(bool(normalize)), out.ctypes.data), "anr_encoder_forward")
         return out
+
+    def shared_stats(self):
+        """(forwards run, requests served) by the combining queue of ``forward(shared=True)``"""
+        f, r = C.c_int64(0), C.c_int64(0)
+        _lib.check(self._lib.anr_encoder_shared_stats(self._h, C.byref(f), C.byref(r)), "anr_encoder_shared_stats")
+        return int(f.value), int(r.value)
 
     def forward_device(self, ids: np.ndarray, lengths: np.ndarray, type_ids: Optional[np.ndarray], normalize: bool,
                        out_ptr: int, out_rows: Optional[np.ndarray] = None) -> None:
@@ -234,12 +242,12 @@ class DeviceEncoder:
         tp = rows = None
         if type_ids is not None:
             type_ids = np.ascontiguousarray(type_ids, dtype=np.int32)
-            tp = type_ids.ctypes.data_as(C.c_void_p)
+            tp = type_ids.ctypes.data
         if out_rows is not None:
             out_rows = np.ascontiguousarray(out_rows, dtype=np.int32)
-            rows = out_rows.ctypes.data_as(C.c_void_p)
-        _lib.check(self._lib.anr_encoder_forward_dev(self._h, ids.ctypes.data_as(C.c_void_p),
-                                                     lengths.ctypes.data_as(C.c_void_p), tp, B, L, int(bool(normalize)),
+            rows = out_rows.ctypes.data
+        _lib.check(self._lib.anr_encoder_forward_dev(self._h, ids.ctypes.data,
+                                                     lengths.ctypes.data, tp, B, L, int(bool(normalize)),
                                                      C.c_void_p(out_ptr), rows), "anr_encoder_forward_dev")
 
     def close(self):
@@ -252,124 +260,6 @@ class DeviceEncoder:
             self.close()
         except Exception:
             pass
-
-
-class _ForwardCombiner:
-    """Concurrent small encodes share forwards.  The reference answers questions from worker threads that share ONE
-    model and call it with a single query each (main_musique.py:487-494, query/query_processor.py:2761-2766): eight such
-    calls used to queue at the encoder handle's mutex, 8 x 0.73 ms back to back, while one forward of eight queries costs
-    ~0.9 ms.  Here a call that arrives while a forward is running waits in a queue; whoever holds the lead takes EVERYTHING
-    queued, runs one forward per group of requests and hands each caller its rows, then passes the lead to the next waiter
-    (so no caller serves others for longer than three rounds).  Requests are only merged when the per-sequence arithmetic is
-    unchanged — same flags, and at most ``max_tokens`` padded tokens per forward, which keeps the merged forward in the
-    kernel regime of a single query (skinny GEMMs, latency LayerNorm; token rows are independent in every kernel, and a key
-    block that lies wholly in a sequence's padding adds exact zeros to its attention sums) — so an embedding does not depend
-    on who else was in flight: bit-identical to the one-at-a-time call (tests/test_encoder_gpu.py asserts the equality)."""
-
-    def __init__(self, enc: "DeviceEncoder", pad_id: int, max_tokens: int = 2048):
-        self.enc, self.pad, self.max_tokens = enc, int(pad_id), int(max_tokens)
-        self.lock = threading.Lock()
-        self.queue: List["_ForwardCombiner._Req"] = []
-        self.running = False
-        self.forwards = 0   # statistics: forwards run / requests served
-        self.served = 0
-        # (No gathering window: with T caller threads the queue settles into two alternating groups of ~T / 2 — the threads
-        # served by forward k are back in the queue while forward k + 1 serves the others — and the device never idles.
-        # Holding a forward back until the just-served callers return was measured: 0.3 ms of window gathered 5.3 instead of
-        # 3.7 questions per forward at 8 threads and cost more than it won, 0.238 vs 0.207 ms per question; a thread needs
-        # longer than that to come back through the interpreter lock.)
-
-    class _Req:
-        __slots__ = ("ids", "lens", "types", "norm", "event", "lead", "out", "err")
-
-        def __init__(self, ids, lens, types, norm):
-            self.ids, self.lens, self.types, self.norm = ids, lens, types, norm
-            self.event, self.lead, self.out, self.err = threading.Event(), False, None, None
-
-    def run(self, ids, lens, types, normalize: bool) -> np.ndarray:
-        req = self._Req(ids, lens, types, bool(normalize))
-        with self.lock:
-            self.queue.append(req)
-            if not self.running:
-                self.running = True
-                req.lead = True
-        if not req.lead:
-            req.event.wait()
-            if not req.lead:  # served by another caller's round
-                if req.err is not None:
-                    raise req.err
-                return req.out
-            req.event.clear()  # promoted: this request is still queued, lead the next round
-        # lead: serve what is queued (this request included); while more has arrived meanwhile, serve up to two more rounds
-        # before handing the lead to a waiter — waking the next leader costs ~0.2 ms during which the device would idle
-        rounds = 0
-        while True:
-            with self.lock:
-                batch, self.queue = self.queue, []
-            try:
-                self._serve(batch)
-            finally:
-                rounds += 1
-                with self.lock:
-                    again = bool(self.queue) and rounds < 3
-                    if not again:
-                        if self.queue:
-                            self.queue[0].lead = True
-                            self.queue[0].event.set()
-                        else:
-                            self.running = False
-                for r in batch:
-                    if r is not req:
-                        r.event.set()
-            if not again:
-                break
-        if req.err is not None:
-            raise req.err
-        return req.out
-
-    def _serve(self, batch):
-        groups: Dict[tuple, list] = {}
-        for r in batch:
-            groups.setdefault((r.norm, r.types is not None), []).append(r)
-        for (norm, typed), reqs in groups.items():
-            i = 0
-            while i < len(reqs):  # forwards of at most max_tokens padded tokens (a single larger request goes alone)
-                j, rows, Lp = i, 0, 0
-                while j < len(reqs):
-                    Lq = max(Lp, (reqs[j].ids.shape[1] + 31) // 32 * 32)
-                    if j > i and (rows + reqs[j].ids.shape[0]) * Lq > self.max_tokens:
-                        break
-                    rows += reqs[j].ids.shape[0]
-                    Lp = Lq
-                    j += 1
-                part = reqs[i:j]
-                try:
-                    if len(part) == 1:
-                        r = part[0]
-                        r.out = self.enc.forward(r.ids, r.lens, r.types, normalize=norm)
-                    else:
-                        L = max(r.ids.shape[1] for r in part)
-                        ids = np.full((rows, L), self.pad, dtype=np.int32)
-                        types = np.zeros((rows, L), dtype=np.int32) if typed else None
-                        a = 0
-                        for r in part:
-                            b = a + r.ids.shape[0]
-                            ids[a:b, :r.ids.shape[1]] = r.ids
-                            if typed:
-                                types[a:b, :r.types.shape[1]] = r.types
-                            a = b
-                        out = self.enc.forward(ids, np.concatenate([r.lens for r in part]), types, normalize=norm)
-                        a = 0
-                        for r in part:
-                            b = a + r.ids.shape[0]
-                            r.out = out[a:b].copy()
-                            a = b
-                    self.forwards += 1
-                    self.served += len(part)
-                except Exception as e:  # every caller of the failed forward gets the error
-                    for r in part:
-                        r.err = e
-                i = j
 
 
 class SentenceEncoder:
@@ -392,9 +282,9 @@ class SentenceEncoder:
         # padded tokens (sequences x padded length) one forward may hold: the workspace is 16 H + 2 I bytes per token
         # (6.4 GB at this budget for XLM-R large) — the role SentenceTransformer.encode's batch_size plays as a memory knob
         self.max_forward_tokens = 1 << 18
-        # encodes of a few sentences (a query at a time from worker threads) go through the combining queue
+        # encodes of a few sentences (a query at a time from worker threads) go through the library's combining queue
+        # (anr_encoder_forward_shared, csrc/combine.hpp)
         self.combine_max_sentences = 8
-        self._combiner = _ForwardCombiner(self._enc, self._pad)
 
     def get_sentence_embedding_dimension(self) -> int:
         return self._enc.hidden
@@ -493,9 +383,9 @@ class SentenceEncoder:
         if 0 < n <= self.combine_max_sentences:
             # the reference's query-time call (one question per call, many worker threads): concurrent calls share forwards
             ids, lens, types = self.tokenize(sentences)
-            if ids.shape[0] * ((ids.shape[1] + 31) // 32 * 32) <= self._combiner.max_tokens:
-                out[:] = self._combiner.run(ids, lens, types if use_types else None, want_norm)
-                return out[0] if single else out
+            if ids.shape[0] * ((ids.shape[1] + 31) // 32 * 32) <= 2048:
+                res = self._enc.forward(ids, lens, types if use_types else None, normalize=want_norm, shared=True)
+                return res[0] if single else res
         for sel, (ids, lens, types) in self._batches(sentences, batch_size):
             for a, b, L in self._token_slices(lens):
                 out[sel[a:b]] = self._enc.forward(ids[a:b, :L], lens[a:b], types[a:b, :L] if use_types else None,

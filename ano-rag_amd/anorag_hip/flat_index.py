@@ -60,7 +60,7 @@ class FlatIndex:
 
     def add(self, x) -> None:
         x = _f32_matrix(x, self.d, "add")
-        _lib.check(self._lib.anr_index_add(self._h, x.ctypes.data_as(C.c_void_p), x.shape[0]), "anr_index_add")
+        _lib.check(self._lib.anr_index_add(self._h, x.ctypes.data, x.shape[0]), "anr_index_add")
 
     def add_npy(self, path: str, chunk_rows: int = 1 << 18) -> int:
         """Stream an [N, d] ``.npy`` file (the reference's ``embeddings.npy``, doc/document_processor.py:164-172, or an
@@ -82,8 +82,8 @@ class FlatIndex:
         D = np.empty((nq, k), dtype=np.float32)
         I = np.empty((nq, k), dtype=np.int64)
         _lib.check(
-            self._lib.anr_index_search(self._h, q.ctypes.data_as(C.c_void_p), nq, int(k),
-                                       D.ctypes.data_as(C.c_void_p), I.ctypes.data_as(C.c_void_p)),
+            self._lib.anr_index_search(self._h, q.ctypes.data, nq, int(k),
+                                       D.ctypes.data, I.ctypes.data),
             "anr_index_search",
         )
         return D, I
@@ -95,9 +95,9 @@ class FlatIndex:
         if ids.ndim != 2 or ids.shape[0] != q.shape[0]:
             raise ValueError("ids must be [nq, per_query]")
         out = np.empty(ids.shape, dtype=np.float32)
-        _lib.check(self._lib.anr_index_score_rows(self._h, q.ctypes.data_as(C.c_void_p), q.shape[0],
-                                                  ids.ctypes.data_as(C.c_void_p), ids.shape[1],
-                                                  out.ctypes.data_as(C.c_void_p)), "anr_index_score_rows")
+        _lib.check(self._lib.anr_index_score_rows(self._h, q.ctypes.data, q.shape[0],
+                                                  ids.ctypes.data, ids.shape[1],
+                                                  out.ctypes.data), "anr_index_score_rows")
         return out
 
     def self_join(self, threshold: float, cap_hint: int = 0, sort: bool = True):
@@ -110,8 +110,8 @@ class FlatIndex:
             J = np.empty((cap,), dtype=np.int64)
             S = np.empty((cap,), dtype=np.float32)
             _lib.check(self._lib.anr_index_self_join(self._h, C.c_float(float(threshold)), cap,
-                                                     I.ctypes.data_as(C.c_void_p), J.ctypes.data_as(C.c_void_p),
-                                                     S.ctypes.data_as(C.c_void_p), C.byref(n)), "anr_index_self_join")
+                                                     I.ctypes.data, J.ctypes.data,
+                                                     S.ctypes.data, C.byref(n)), "anr_index_self_join")
             if n.value >= 0:
                 break
             cap = -n.value  # the lists were too small: the library reports an upper bound
@@ -128,7 +128,7 @@ class FlatIndex:
 
     def reconstruct_n(self, i0: int, n: int):
         out = np.empty((n, self.d), dtype=np.float32)
-        _lib.check(self._lib.anr_index_reconstruct(self._h, int(i0), int(n), out.ctypes.data_as(C.c_void_p)),
+        _lib.check(self._lib.anr_index_reconstruct(self._h, int(i0), int(n), out.ctypes.data),
                    "anr_index_reconstruct")
         return out
 
@@ -146,7 +146,7 @@ class FlatIndex:
         D = np.empty((nq, k), dtype=np.float32)
         I = np.empty((nq, k), dtype=np.int64)
         _lib.check(self._lib.anr_index_search_devq(self._h, C.c_void_p(q_ptr), int(nq), int(k),
-                                                   D.ctypes.data_as(C.c_void_p), I.ctypes.data_as(C.c_void_p)),
+                                                   D.ctypes.data, I.ctypes.data),
                    "anr_index_search_devq")
         return D, I
 

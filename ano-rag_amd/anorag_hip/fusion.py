@@ -111,7 +111,7 @@ class DeviceArray:
         if a.dtype not in (np.float64, np.float32):
             a = a.astype(np.float64)
         out = cls(a.shape[0], a.shape[1], a.dtype, device)
-        _lib.check(_lib.load().anr_device_copy(device, C.c_void_p(out.ptr), a.ctypes.data_as(C.c_void_p), a.nbytes, 0),
+        _lib.check(_lib.load().anr_device_copy(device, C.c_void_p(out.ptr), a.ctypes.data, a.nbytes, 0),
                    "anr_device_copy")
         if with_max and a.shape[1] > 0:
             m = np.fmax.reduce(a.astype(np.float64, copy=False), axis=1).reshape(-1, 1)  # fmax skips NaN; all-NaN row -> NaN
@@ -120,7 +120,7 @@ class DeviceArray:
 
     def numpy(self) -> np.ndarray:
         out = np.empty((self.nq, self.n), dtype=self.dtype)
-        _lib.check(_lib.load().anr_device_copy(self.device, out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr),
+        _lib.check(_lib.load().anr_device_copy(self.device, out.ctypes.data, C.c_void_p(self.ptr),
                                                self.nbytes, 1), "anr_device_copy")
         return out
 
@@ -192,7 +192,7 @@ class SparseRows:
         lib = _lib.load()
         for ptr, arr in ((out.ids_ptr, ids), (out.scores_ptr, val), (out.count_ptr, cnt)):
             if arr.nbytes:
-                _lib.check(lib.anr_device_copy(device, C.c_void_p(ptr), arr.ctypes.data_as(C.c_void_p), arr.nbytes, 0),
+                _lib.check(lib.anr_device_copy(device, C.c_void_p(ptr), arr.ctypes.data, arr.nbytes, 0),
                            "anr_device_copy")
         out.counts = cnt
         return out
@@ -205,7 +205,7 @@ class SparseRows:
         cnt = np.empty((self.nq,), dtype=np.int32)
         for ptr, arr in ((self.ids_ptr, ids), (self.scores_ptr, val), (self.count_ptr, cnt)):
             if arr.nbytes:
-                _lib.check(lib.anr_device_copy(self.device, arr.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), arr.nbytes, 1),
+                _lib.check(lib.anr_device_copy(self.device, arr.ctypes.data, C.c_void_p(ptr), arr.nbytes, 1),
                            "anr_device_copy")
         out = []
         for i in range(self.nq):
@@ -285,10 +285,10 @@ def fuse_dense(method: str, weights: Dict[str, float], rrf_k: float, pool: int, 
     o_src = np.empty((nq, pool, 4), dtype=np.float64)
     o_cnt = np.empty((nq,), dtype=np.int32)
     st = FuseDenseStats()
-    _lib.check(lib.anr_fuse_dense(int(device), 1 if method == "rrf" else 0, int(nq), src, w.ctypes.data_as(C.c_void_p),
-                                  float(rrf_k), int(pool), o_ids.ctypes.data_as(C.c_void_p),
-                                  o_fin.ctypes.data_as(C.c_void_p), o_src.ctypes.data_as(C.c_void_p),
-                                  o_cnt.ctypes.data_as(C.c_void_p), C.byref(st) if want_stats else None),
+    _lib.check(lib.anr_fuse_dense(int(device), 1 if method == "rrf" else 0, int(nq), src, w.ctypes.data,
+                                  float(rrf_k), int(pool), o_ids.ctypes.data,
+                                  o_fin.ctypes.data, o_src.ctypes.data,
+                                  o_cnt.ctypes.data, C.byref(st) if want_stats else None),
                "anr_fuse_dense")
     if want_stats:
         return o_ids, o_fin, o_src, o_cnt, {k: getattr(st, k) for k, _ in st._fields_}

@@ -106,9 +106,9 @@ def merge_topk_host_c(Dp: np.ndarray, Ip: np.ndarray, larger_is_better: bool = T
     Ip = np.ascontiguousarray(Ip, dtype=np.int64)
     D = np.empty((B, k), dtype=np.float32)
     I = np.empty((B, k), dtype=np.int64)
-    _lib.check(_lib.load().anr_merge_topk_host(Dp.ctypes.data_as(C.c_void_p), Ip.ctypes.data_as(C.c_void_p), int(P),
+    _lib.check(_lib.load().anr_merge_topk_host(Dp.ctypes.data, Ip.ctypes.data, int(P),
                                                int(B), int(k), int(bool(larger_is_better)),
-                                               D.ctypes.data_as(C.c_void_p), I.ctypes.data_as(C.c_void_p)),
+                                               D.ctypes.data, I.ctypes.data),
                "anr_merge_topk_host")
     return D, I
 

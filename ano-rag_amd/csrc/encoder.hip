@@ -22,6 +22,7 @@
 #include <string>
 #include <vector>
 
+#include "combine.hpp"
 #include "common.hpp"
 
 namespace anr {
@@ -433,7 +434,9 @@ static void launch_layernorm(const LnParams &p, hipStream_t st) {
 //                  folded once when the weights are finalised, s = the row sums of the f16 W', c = b + W beta;
 //   EPI_RES_LN     (FFN down) rebuilds the residual it needs, LN(u) = (u - mean) rstd gamma + beta, from u and the same
 //                  statistics, adds its projection and writes the sum for the layer's second LayerNorm (one input).
-enum { EPI_ACT = 0, EPI_GELU = 1, EPI_VT = 3, EPI_RES_STATS = 4, EPI_FOLD_GELU = 5, EPI_RES_LN = 6 };
+//   EPI_RES        (either 768-wide projection) out = f16(resid + acc + bias): the residual sum formed where the projection
+//                  is still in registers, so that the LayerNorm behind it reads ONE tensor instead of two.
+enum { EPI_ACT = 0, EPI_GELU = 1, EPI_VT = 3, EPI_RES_STATS = 4, EPI_FOLD_GELU = 5, EPI_RES_LN = 6, EPI_RES = 7 };
 constexpr int kStatSlots = 6;  // column tiles of a 768-wide output at the narrowest tile (TN = 4)
 
 struct GemmParams {
@@ -958,13 +961,13 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmParams p, PatchGrid pg, int
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int n = 0; n < NW; ++n) gemm_keep(acc[m][n]);
-    } else if (EPI == EPI_RES_STATS || EPI == EPI_FOLD_GELU || EPI == EPI_RES_LN) {
+    } else if (EPI == EPI_RES_STATS || EPI == EPI_FOLD_GELU || EPI == EPI_RES_LN || EPI == EPI_RES) {
       __shared__ float s_part[2][4][2][32][2];  // [feature half wn][token pair wm][m][token][sum, sum of squares]
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
         const int64_t tb = (int64_t)cm * TM + 2 * wm + m;
         float mean = 0.f, rstd = 1.f, ssum = 0.f, qsum = 0.f;
-        if (EPI != EPI_RES_STATS && tb < p.TB) gemm_token_stats(p, tb, lane, mean, rstd);
+        if (EPI != EPI_RES_STATS && EPI != EPI_RES && tb < p.TB) gemm_token_stats(p, tb, lane, mean, rstd);
 #pragma unroll
         for (int n = 0; n < NW; ++n) {
           const int nb = cn * TN + NW * wn + n;
@@ -1419,6 +1422,17 @@ struct anr_encoder {
   _Float16 *big = nullptr;  // the block qk / vt / ctx / ffn point into
   float *stats = nullptr;   // [tokens][kStatSlots][2] partial LayerNorm statistics of the folded path
   int fold_ln = 0;          // large forwards: first LayerNorm of a layer folded into the GEMMs around it (ANORAG_ENC_FOLD=1: on)
+  // anr_encoder_forward_shared: the combining queue of concurrent small forwards (combine.hpp) and its second LANE — a view
+  // of this handle that shares the weights and owns a stream and a workspace of its own, so that two small forwards (each a
+  // chain of ~90 dependent tiny launches) run side by side.  ANORAG_ENC_LANES=1: one lane.
+  static int shared_lanes() {
+    const char *v = getenv("ANORAG_ENC_LANES");
+    return v ? (atoi(v) >= 2 ? 2 : 1) : 2;
+  }
+  ForwardCombiner shared{shared_lanes()};
+  bool view = false;            // a lane: the weights belong to the handle it was made from
+  anr_encoder *lane1 = nullptr;
+  std::mutex lane_mu;
 };
 
 namespace {
@@ -1558,7 +1572,7 @@ void launch_gemm(anr_encoder *e, GemmParams &g) {
     else launch_gemm8<EPI, 8>(e, g, blocks);
     return;
   }
-  if (EPI == EPI_RES_STATS || EPI == EPI_FOLD_GELU || EPI == EPI_RES_LN) return;  // (only ever launched on the 8-wave tile kernel)
+  if (EPI == EPI_RES_STATS || EPI == EPI_FOLD_GELU || EPI == EPI_RES_LN || EPI == EPI_RES) return;  // (only ever launched on the 8-wave tile kernel)
   const int64_t blocks = ceil_div(g.TB, 4) * ceil_div(g.NB, 8);
   constexpr int lds_bytes = 3 * ANR_GEMM_S * 12 * 1024;
   if (lds_bytes > 64 * 1024) (void)ensure_dynamic_lds(reinterpret_cast<const void *>(&k_gemm_lds<EPI>), lds_bytes);
@@ -1657,12 +1671,18 @@ int anr_encoder_destroy(anr_encoder *e) {
   if (!e) return ANR_OK;
   DeviceGuard g(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
+  if (e->lane1) {
+    (void)anr_encoder_destroy(e->lane1);
+    e->lane1 = nullptr;
+  }
+  if (!e->view) {
   enc_free(e->word); enc_free(e->pos); enc_free(e->type); enc_free(e->eg); enc_free(e->eb); enc_free(e->relbias);
   for (auto &l : e->layers) {
     enc_free(l.wqk); enc_free(l.wv); enc_free(l.wo); enc_free(l.w1); enc_free(l.w2);
     enc_free(l.bqk); enc_free(l.bv); enc_free(l.bo); enc_free(l.b1); enc_free(l.b2);
     enc_free(l.ln1g); enc_free(l.ln1b); enc_free(l.ln2g); enc_free(l.ln2b);
     enc_free(l.w1f); enc_free(l.f1s); enc_free(l.f1c);
+  }
   }
   enc_free(e->d_in);
   if (e->pin_in) (void)hipHostFree(e->pin_in);
@@ -1681,6 +1701,13 @@ int anr_encoder_destroy(anr_encoder *e) {
 int anr_encoder_set_tensor(anr_encoder *e, const char *name, const float *data, int64_t n) {
   if (!e || !name || !data) return fail(ANR_EINVAL, "null argument");
   DeviceGuard g(e->device);
+  {
+    std::lock_guard<std::mutex> ll(e->lane_mu);  // a lane holds copies of the weight pointers: gone with the old weights
+    if (e->lane1) {
+      (void)anr_encoder_destroy(e->lane1);
+      e->lane1 = nullptr;
+    }
+  }
   std::lock_guard<std::mutex> lk(e->mu);
   const auto &c = e->cfg;
   const int H = c.hidden, I = c.intermediate;
@@ -1835,7 +1862,7 @@ void enqueue_forward(anr_encoder *e, int B, int L, int Lp, bool use_types, int n
     // the output projection writes u = x + projection and its per-token partial sums, FFN-up consumes u through the folded
     // weights, FFN-down rebuilds LN(u) for its residual and writes the sum the second LayerNorm reads alone (EPI list above).
     int tn_o = 0;
-    const bool fold = e->fold_ln && pp_tile(e, go, &tn_o) && pp_tile(e, g1, nullptr) && pp_tile(e, g2, nullptr) &&
+    const bool fold = e->fold_ln == 1 && pp_tile(e, go, &tn_o) && pp_tile(e, g1, nullptr) && pp_tile(e, g2, nullptr) &&
                       ceil_div(go.NB, tn_o) <= kStatSlots;
     if (fold) {
       go.resid = e->act; go.stats_out = e->stats; go.stat_h = H;
@@ -1851,6 +1878,19 @@ void enqueue_forward(anr_encoder *e, int B, int L, int Lp, bool use_types, int n
       launch_layernorm(l2, st);
       continue;
     }
+    if (e->fold_ln == 2 && pp_tile(e, go, nullptr) && pp_tile(e, g2, nullptr)) {
+      // residual sums formed in the projections' epilogues: each LayerNorm reads one tensor (delta) and writes act
+      go.resid = e->act;
+      launch_gemm<EPI_RES>(e, go);
+      LnParams r1{e->delta, nullptr, TB, H, KB, l.ln1g, l.ln1b, c.ln_eps, nullptr, e->act};
+      launch_layernorm(r1, st);
+      launch_gemm<EPI_GELU>(e, g1);
+      g2.resid = e->act;
+      launch_gemm<EPI_RES>(e, g2);
+      LnParams r2{e->delta, nullptr, TB, H, KB, l.ln2g, l.ln2b, c.ln_eps, li + 1 == c.n_layers ? e->res : nullptr, e->act};
+      launch_layernorm(r2, st);
+      continue;
+    }
     launch_gemm<EPI_ACT>(e, go);
     LnParams l1{e->act, e->delta, TB, H, KB, l.ln1g, l.ln1b, c.ln_eps, nullptr, e->act};
     launch_layernorm(l1, st);
@@ -1864,9 +1904,9 @@ void enqueue_forward(anr_encoder *e, int B, int L, int Lp, bool use_types, int n
   hipLaunchKernelGGL(k_pool, dim3(B), dim3(256), 0, st, pp);
 }
 
-int forward_impl(anr_encoder *e, const int32_t *ids, const int32_t *lengths, const int32_t *type_ids, int32_t B,
-                 int32_t L, int32_t normalize, float *out_host, float *out_dev, const int32_t *out_rows) {
-  if (!e || !ids || !lengths || (!out_host && !out_dev)) return fail(ANR_EINVAL, "null argument");
+int check_forward_args(const anr_encoder *e, const int32_t *ids, const int32_t *lengths, const int32_t *type_ids, int32_t B,
+                       int32_t L) {
+  if (!e || !ids || !lengths) return fail(ANR_EINVAL, "null argument");
   if (B <= 0 || L <= 0) return fail(ANR_EINVAL, "B and L must be positive");
   const auto &c = e->cfg;
   if (L + c.pos_offset > c.max_positions) return fail(ANR_EINVAL, "sequence length %d exceeds the position table", L);
@@ -1876,6 +1916,14 @@ int forward_impl(anr_encoder *e, const int32_t *ids, const int32_t *lengths, con
     if (ids[i] < 0 || ids[i] >= c.vocab_size) return fail(ANR_EINVAL, "token id %d out of range", ids[i]);
     if (type_ids && (type_ids[i] < 0 || type_ids[i] >= c.type_vocab_size)) return fail(ANR_EINVAL, "type id out of range");
   }
+  return ANR_OK;
+}
+
+int forward_impl(anr_encoder *e, const int32_t *ids, const int32_t *lengths, const int32_t *type_ids, int32_t B,
+                 int32_t L, int32_t normalize, float *out_host, float *out_dev, const int32_t *out_rows) {
+  if (!out_host && !out_dev) return fail(ANR_EINVAL, "null argument");
+  ANR_TRY(check_forward_args(e, ids, lengths, type_ids, B, L));
+  const auto &c = e->cfg;
   DeviceGuard g(e->device);
   if (!g.ok) return fail(ANR_EHIP, "hipSetDevice failed");
   std::lock_guard<std::mutex> lk(e->mu);
@@ -1906,9 +1954,65 @@ int forward_impl(anr_encoder *e, const int32_t *ids, const int32_t *lengths, con
   if (direct_out) std::memcpy(out_host, e->pin_out, (size_t)B * c.hidden * sizeof(float));
   return ANR_OK;
 }
+
+// ---- concurrent small forwards share forwards (round 4): the queue is combine.hpp's, the forward is forward_impl ----------
 }  // namespace
 
 extern "C" {
+
+// lane 0 is the handle itself; lane 1 a view of it, made on first use
+static int shared_lane(anr_encoder *e, int lane, anr_encoder **out) {
+  *out = e;
+  if (lane == 0) return ANR_OK;
+  std::lock_guard<std::mutex> ll(e->lane_mu);
+  if (!e->lane1) {
+    DeviceGuard g(e->device);
+    anr_encoder *v = new anr_encoder();
+    v->cfg = e->cfg;
+    v->device = e->device;
+    v->n_cu = e->n_cu;
+    v->word = e->word; v->pos = e->pos; v->type = e->type; v->eg = e->eg; v->eb = e->eb;
+    v->relbias = e->relbias;
+    v->rel_span = e->rel_span;
+    for (int i = 0; i < 5; ++i) v->have_emb[i] = e->have_emb[i];
+    v->layers = e->layers;
+    v->finalized = e->finalized;
+    v->fold_ln = e->fold_ln;
+    v->view = true;
+    if (hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking) != hipSuccess) {
+      delete v;
+      return fail(ANR_EHIP, "hipStreamCreate failed");
+    }
+    e->lane1 = v;
+  }
+  *out = e->lane1;
+  return ANR_OK;
+}
+
+int anr_encoder_forward_shared(anr_encoder *e, const int32_t *ids, const int32_t *lengths, const int32_t *type_ids, int32_t B,
+                               int32_t L, int32_t normalize, float *out_host) {
+  if (!out_host) return fail(ANR_EINVAL, "null argument");
+  ANR_TRY(check_forward_args(e, ids, lengths, type_ids, B, L));  // in the caller's thread: a bad request fails alone
+  if ((int64_t)B * round_up(L, 32) > ForwardCombiner::kMaxTokens)
+    return forward_impl(e, ids, lengths, type_ids, B, L, normalize, out_host, nullptr, nullptr);
+  ForwardCombiner::Req req{ids, lengths, type_ids, B, L, normalize ? 1 : 0, out_host};
+  auto run = [e](int lane, const int32_t *i, const int32_t *l, const int32_t *t, int b, int len, int norm, float *out,
+                 std::string *err) {
+    anr_encoder *le = nullptr;
+    int rc = shared_lane(e, lane, &le);
+    if (rc == ANR_OK) rc = forward_impl(le, i, l, t, b, len, norm, out, nullptr, nullptr);
+    if (rc != ANR_OK) *err = anr_last_error();
+    return rc;
+  };
+  const int rc = e->shared.run(req, e->cfg.hidden, run);
+  return rc == ANR_OK ? ANR_OK : fail(rc, "%s", req.err.c_str());
+}
+
+int anr_encoder_shared_stats(anr_encoder *e, int64_t *forwards, int64_t *requests) {
+  if (!e) return fail(ANR_EINVAL, "null handle");
+  e->shared.stats(forwards, requests);
+  return ANR_OK;
+}
 
 int anr_encoder_forward(anr_encoder *e, const int32_t *ids, const int32_t *lengths, const int32_t *type_ids, int32_t B,
                         int32_t L, int32_t normalize, float *out_host) {

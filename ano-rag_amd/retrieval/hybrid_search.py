@@ -116,10 +116,10 @@ class HybridSearcher:
         o_cnt = np.empty((nq,), dtype=np.int32)
         lib = _lib.load()
         _lib.check(
-            lib.anr_fuse_lists(self.device, method, nq, ids.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p),
-                               offs.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p), float(self.rrf_k), pool,
-                               o_ids.ctypes.data_as(C.c_void_p), o_fin.ctypes.data_as(C.c_void_p),
-                               o_src.ctypes.data_as(C.c_void_p), o_cnt.ctypes.data_as(C.c_void_p)),
+            lib.anr_fuse_lists(self.device, method, nq, ids.ctypes.data, sc.ctypes.data,
+                               offs.ctypes.data, w.ctypes.data, float(self.rrf_k), pool,
+                               o_ids.ctypes.data, o_fin.ctypes.data,
+                               o_src.ctypes.data, o_cnt.ctypes.data),
             "anr_fuse_lists",
         )
         results: List[List[Dict[str, Any]]] = []
@@ -291,11 +291,11 @@ class HybridSearcher:
         o_fin = np.empty((1, pool), dtype=np.float64)
         o_src = np.empty((1, pool, 4), dtype=np.float64)
         o_cnt = np.empty((1,), dtype=np.int32)
-        _lib.check(_lib.load().anr_fuse_rrf_long(self.device, 1, ids.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p),
-                                                 offs.ctypes.data_as(C.c_void_p), len(names), w.ctypes.data_as(C.c_void_p),
-                                                 float(self.rrf_k), pool, o_ids.ctypes.data_as(C.c_void_p),
-                                                 o_fin.ctypes.data_as(C.c_void_p), o_src.ctypes.data_as(C.c_void_p),
-                                                 o_cnt.ctypes.data_as(C.c_void_p)), "anr_fuse_rrf_long")
+        _lib.check(_lib.load().anr_fuse_rrf_long(self.device, 1, ids.ctypes.data, sc.ctypes.data,
+                                                 offs.ctypes.data, len(names), w.ctypes.data,
+                                                 float(self.rrf_k), pool, o_ids.ctypes.data,
+                                                 o_fin.ctypes.data, o_src.ctypes.data,
+                                                 o_cnt.ctypes.data), "anr_fuse_rrf_long")
         d0, d1, d2, d3 = dicts
         res = []
         for j in range(int(o_cnt[0])):
@@ -347,7 +347,7 @@ class HybridSearcher:
                     # (the fusion refuses a count of -1 — it would otherwise read "every BM25 score is 0.0" silently)
                     rows.counts = np.maximum(rows.counts, 0).astype(np.int32)
                     _lib.check(_lib.load().anr_device_copy(rows.device, C.c_void_p(rows.count_ptr),
-                                                           rows.counts.ctypes.data_as(C.c_void_p), rows.counts.nbytes, 0),
+                                                           rows.counts.ctypes.data, rows.counts.nbytes, 0),
                                "anr_device_copy")
                 results = self.fuse_arrays(nq, dense=dense, bm25=rows, graph=graph, path=path, note_ids=note_ids)
         finally:

@@ -323,9 +323,9 @@ class EmbeddingManager:
                 raise ValueError(f"shapes {a.shape} and {b.shape} not aligned")
             sim = np.empty((a32.shape[0], b32.shape[0]), dtype=np.float64)
             code = {"cosine": 0, "dot": 1, "euclidean": 2}[metric]
-            _lib.check(_lib.load().anr_similarity_matrix(self.hip_device, a32.ctypes.data_as(C.c_void_p), a32.shape[0],
-                                                         b32.ctypes.data_as(C.c_void_p), b32.shape[0], a32.shape[1], code,
-                                                         sim.ctypes.data_as(C.c_void_p)), "anr_similarity_matrix")
+            _lib.check(_lib.load().anr_similarity_matrix(self.hip_device, a32.ctypes.data, a32.shape[0],
+                                                         b32.ctypes.data, b32.shape[0], a32.shape[1], code,
+                                                         sim.ctypes.data), "anr_similarity_matrix")
             if metric == "euclidean":
                 return sim  # scipy's cdist returns float64 whatever the inputs are (:613-616)
             sim = sim.astype(np.result_type(embeddings1.dtype, embeddings2.dtype), copy=False)

@@ -333,6 +333,15 @@ int anr_encoder_forward(anr_encoder *e, const int32_t *ids, const int32_t *lengt
  * round trip per batch.  out_dev is complete when the call returns. */
 int anr_encoder_forward_dev(anr_encoder *e, const int32_t *ids, const int32_t *lengths, const int32_t *type_ids,
                             int32_t B, int32_t L, int32_t normalize, float *out_dev, const int32_t *out_rows);
+/* anr_encoder_forward for callers that share the handle from several threads with a query or a few each (the reference's
+ * query-time pattern: main_musique.py:487-494, query/query_processor.py:2761-2766): calls that arrive while a forward is
+ * running wait in a combining queue and are merged into the next forward — same normalize flag, same use of type_ids, at most
+ * 2048 padded tokens per forward, so an embedding never depends on who else was in flight: bit-identical to
+ * anr_encoder_forward.  Larger requests run alone, as anr_encoder_forward.  anr_encoder_shared_stats: forwards run and
+ * requests served through the queue so far (either pointer may be NULL). */
+int anr_encoder_forward_shared(anr_encoder *e, const int32_t *ids, const int32_t *lengths, const int32_t *type_ids,
+                               int32_t B, int32_t L, int32_t normalize, float *out_host);
+int anr_encoder_shared_stats(anr_encoder *e, int64_t *forwards, int64_t *requests);
 
 /* ------------------------------------------------------------------------------------------------
  * BM25 scoring: SimpleBM25.get_scores / bm25_scores of utils/bm25_search.py:43-63,

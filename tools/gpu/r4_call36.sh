@@ -1,0 +1,9 @@
+set -e
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r4c36
+mkdir -p $O
+cd $R
+timeout -k 10 900 python3 -m pytest tests/test_encoder_gpu.py tests/test_dropin_gpu.py tests/test_facade_golden.py tests/test_bm25_gpu.py tests/test_fusion_gpu.py tests/test_candidate_fusion.py -x -q -m gpu > $O/tests3.txt 2>&1 || (tail -n 30 $O/tests3.txt; exit 1)
+tail -n 2 $O/tests3.txt
+timeout -k 10 600 python3 tools/query_latency.py > $O/query_latency.txt 2>&1 || (tail -n 20 $O/query_latency.txt; exit 1)
+grep -v "amdgpu\|Warning\|it/s" $O/query_latency.txt

@@ -48,9 +48,9 @@ work = qs * 2
 burst(8, work[:160])
 t1 = burst(1, work)
 t8 = burst(8, work)
-cb = em.model._combiner
+f0, s0 = em.model._enc.shared_stats()
 print(f"threads: encode_queries + search, {len(work)} questions: 1 thread {1e6*t1/len(work):.0f} us per question, 8 threads "
-      f"{1e6*t8/len(work):.0f} us per question ({t1/t8:.1f}x); {cb.served/max(1,cb.forwards):.1f} questions per forward over the run")
+      f"{1e6*t8/len(work):.0f} us per question ({t1/t8:.1f}x); {s0/max(1,f0):.1f} questions per forward over the run")
 xn = orc.preprocess_vectors(x)
 prefix = "Represent this sentence for searching relevant passages: "
 # the host path with the model loaded ONCE (oracle.encoder.encode reloads it per call): the same float32 pipeline
