@@ -76,6 +76,8 @@ cp $(ls $O/enc/*/*kernel_stats.csv | head -1) $O/${ROUND}_encoder_bge_base_256x6
 python3 $R/tools/role_times.py $O/enc > $O/${ROUND}_encoder_role_times_fused.txt 2>&1 || true
 rm -rf $O/enc
 { python3 $R/tools/enc_perf.py 256 64; python3 $R/tools/enc_perf.py 64 512; SHAPE=bge-m3 python3 $R/tools/enc_perf.py 256 64; } 2>&1 | grep TFLOP > $O/${ROUND}_encoder_forward_lines.txt
+{ for lanes in 2 1; do ANORAG_ENC_LANES=$lanes python3 $R/tools/shared_forward_perf.py 2>&1 | grep -E "lanes|threads"; done; } > $O/${ROUND}_shared_forward_lines.txt
+python3 $R/tools/query_latency.py 2>&1 | grep -v "amdgpu\|Warning\|it/s" > $O/${ROUND}_query_latency.txt
 bash $R/tools/pmc_kernel.sh "k_gemm_pp<1" SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY TCC_HIT_sum TCC_MISS_sum -- $R/tools/enc_perf.py 256 64 > $O/${ROUND}_pmc_k_gemm_pp_ffn_up.txt 2>&1
 fi
 if [[ $STEPS == *5* ]]; then
@@ -85,6 +87,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/fd -- python3 $R/tool
 cp $(ls $O/fd/*/*kernel_stats.csv | head -1) $O/${ROUND}_fuse_dense_c5_kernel_stats.csv
 rm -rf $O/fd
 { python3 $R/tools/bm25_fuse_perf.py; echo "--- rare-term queries (vocabulary ranks 1000..30000)"; QLO=1000 QHI=30000 python3 $R/tools/bm25_fuse_perf.py; } 2>&1 | grep -v amdgpu > $O/${ROUND}_bm25_fuse_pipeline_lines.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/bm -- python3 $R/tools/bm25_fuse_perf.py > /dev/null 2>&1
+cp $(ls $O/bm/*/*kernel_stats.csv | head -1) $O/${ROUND}_bm25_fuse_common_terms_kernel_stats.csv
+rm -rf $O/bm
 python3 $R/tools/gemm_yardstick.py 2>&1 | grep -v amdgpu > $O/${ROUND}_gemm_yardstick.txt
 fi
 ls -la $O >&2
