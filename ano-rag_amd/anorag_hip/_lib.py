@@ -31,6 +31,7 @@ OPT_FUSED_POST = 10
 OPT_SHADOW = 11
 OPT_SCHEDULE = 12
 OPT_STREAM_WAIT = 13
+OPT_SCAN_BITS = 14
 BATCH_LOG_FIELDS = 14
 
 

@@ -68,6 +68,7 @@ struct Workspace {
   std::vector<int> rec_lists, rec_scan, rec_dense;
   int64_t seq = 0;
   bool shadow = false;             // the batch's side kernels were the shadow-sized ones
+  bool f12 = false;                // the batch's streaming pass read the 12-bit image
   hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
   hipEvent_t ev_pre = nullptr, ev_scan = nullptr;  // role streams: ladder ready (pre -> main), scan done (main -> post)
   // the batch in flight
@@ -89,7 +90,12 @@ struct anr_index {
   float *x32 = nullptr;
   _Float16 *x16 = nullptr;
   float *rowbias = nullptr;
-  unsigned *xstat = nullptr;  // [4]
+  unsigned *xstat = nullptr;  // [4]: max ||x||, max ||x16 - x||, f16-range flag, max ||x12 - x||
+  unsigned *x12 = nullptr;    // the 12-bit image the streaming scan reads when scan_bits == 12 (index_kernels.hpp)
+  unsigned *xstat12 = nullptr;  // [2]: max ||x||, max(||x16 - x||, ||x12 - x||) — the certificate's statistics of such batches
+  int scan_bits = 0;          // ANR_OPT_SCAN_BITS: 0 auto, 12, 16
+  bool f12_suspended = false; // the corpus proved too dense for the 12-bit image (adapt_overfetch): batches read x16 again
+  int f12_strikes = 0;
   hipStream_t stream = nullptr;                        // adds, exact path, copies
   hipStream_t bstream[kWorkspaces] = {nullptr, nullptr, nullptr};  // one per in-flight batch
   std::mutex mu;
@@ -177,9 +183,11 @@ int grow_storage(anr_index *h, int64_t need_rows) {
   if (need_rows > (int64_t)0xfffffff0ll) return fail(ANR_EINVAL, "index holds at most 2^32-16 rows per device");
   float *nx32 = nullptr;
   _Float16 *nx16 = nullptr;
+  unsigned *nx12 = nullptr;
   float *nbias = nullptr;
   int rc = dev_alloc(&nx32, ncap * h->dim, false);
   if (rc == ANR_OK) rc = dev_alloc(&nx16, ncap * h->dimp, true);
+  if (rc == ANR_OK && (h->scan_bits == 12 || h->x12)) rc = dev_alloc(&nx12, ncap * h->dimp * 3 / 8, true);
   if (rc == ANR_OK && h->metric == ANR_METRIC_L2) rc = dev_alloc(&nbias, ncap, true);
   if (rc == ANR_OK && h->ntotal > 0) {
     const int64_t used = round_up(h->ntotal, kTileRows);
@@ -187,6 +195,8 @@ int grow_storage(anr_index *h, int64_t need_rows) {
                                   h->stream);
     if (e == hipSuccess)
       e = hipMemcpyAsync(nx16, h->x16, (size_t)used * h->dimp * sizeof(_Float16), hipMemcpyDeviceToDevice, h->stream);
+    if (e == hipSuccess && nx12 && h->x12)
+      e = hipMemcpyAsync(nx12, h->x12, (size_t)used * h->dimp * 3 / 2, hipMemcpyDeviceToDevice, h->stream);
     if (e == hipSuccess && nbias)
       e = hipMemcpyAsync(nbias, h->rowbias, (size_t)h->ntotal * sizeof(float), hipMemcpyDeviceToDevice, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
@@ -195,14 +205,17 @@ int grow_storage(anr_index *h, int64_t need_rows) {
   if (rc != ANR_OK) {  // the index keeps its old storage
     dev_free(nx32);
     dev_free(nx16);
+    dev_free(nx12);
     dev_free(nbias);
     return rc;
   }
   dev_free(h->x32);
   dev_free(h->x16);
+  dev_free(h->x12);
   dev_free(h->rowbias);
   h->x32 = nx32;
   h->x16 = nx16;
+  h->x12 = nx12;
   h->rowbias = nbias;
   h->cap = ncap;
   return ANR_OK;
@@ -320,7 +333,7 @@ int launch_post(int nblocks, const SelParams &sp, const PostParams &pp, hipStrea
   return ANR_OK;
 }
 
-template <bool DENSE>
+template <bool DENSE, bool F12 = false>
 int launch_scan(anr_index *h, const ScanParams &p, hipStream_t st, int max_grid, int *grid_out = nullptr) {
   if (p.n_tiles <= 0) return ANR_OK;
   const size_t lds = (size_t)2 * p.kb * 64 * 16 + kQB * kLadder * 8 + kQB * 8;
@@ -338,8 +351,8 @@ int launch_scan(anr_index *h, const ScanParams &p, hipStream_t st, int max_grid,
   const bool stream = p.tile_stride == 1 && p.n_tiles * (int64_t)p.kb * 1024 > ((int64_t)192 << 20);
 #define ANR_LAUNCH_SCAN(CHV, STRV)                                                             \
   {                                                                                            \
-    ANR_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_scan<DENSE, CHV, 768, STRV>), 160 * 1024)); \
-    hipLaunchKernelGGL((k_scan<DENSE, CHV, 768, STRV>), dim3((unsigned)grid), dim3(nt), lds, st, p); \
+    ANR_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_scan<DENSE, CHV, 768, STRV, F12>), 160 * 1024)); \
+    hipLaunchKernelGGL((k_scan<DENSE, CHV, 768, STRV, F12>), dim3((unsigned)grid), dim3(nt), lds, st, p); \
   }
   if (p.kb % 16 == 0) {
     if (stream) ANR_LAUNCH_SCAN(8, true) else ANR_LAUNCH_SCAN(8, false)
@@ -359,12 +372,40 @@ hipError_t launch_join(const JoinParams &jp, int64_t n_slots, hipStream_t st, in
   return hipGetLastError();
 }
 
-int auto_overfetch(const anr_index *h, int k) {
+int refresh_xstat(anr_index *h);
+
+constexpr int64_t kAuto12Rows = 524288;  // ANR_OPT_SCAN_BITS 0: indexes of at least this many rows scan the 12-bit image
+
+// the 12-bit image of what is stored (later adds keep it up to date); the caller has drained the pipeline or is about to
+// enqueue on a stream that follows h->stream's work
+int build_x12(anr_index *h) {
+  if (h->x12 || h->cap <= 0) return ANR_OK;
+  hipError_t e = hipMalloc(reinterpret_cast<void **>(&h->x12), (size_t)h->cap * h->dimp * 3 / 2);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    h->x12 = nullptr;
+    return fail(ANR_EHIP, "no memory for the 12-bit image: %s", hipGetErrorString(e));
+  }
+  ANR_HIP(hipMemsetAsync(h->x12, 0, (size_t)h->cap * h->dimp * 3 / 2, h->stream));
+  if (h->ntotal > 0) {
+    Build12Params bp{h->x32, h->x16, h->x12, h->ntotal, h->dim, h->kb, h->xstat};
+    hipLaunchKernelGGL(k_build12, dim3((unsigned)ceil_div(h->ntotal, kTileRows)), dim3(256), 0, h->stream, bp);
+    ANR_HIP(hipGetLastError());
+  }
+  ANR_HIP(hipStreamSynchronize(h->stream));
+  h->xstat_dirty = true;
+  return refresh_xstat(h);
+}
+
+int auto_overfetch(const anr_index *h, int k, bool f12 = false) {
   if (h->overfetch > 0) {
     int m = h->overfetch < k ? k : h->overfetch;
     return m > kMaxSel ? kMaxSel : m;
   }
   int extra = k / 2 > 32 ? k / 2 : 32;
+  // the 12-bit image's error term is ~15x the f16 one: K' = 192 for k = 100 left 2.5 % of the certificates of a 10 M-row
+  // Gaussian corpus failing, 256 none (and 320 / 384 cost more than they save: 1.737 / 1.770 / 1.776 ms per batch)
+  if (f12) extra = k > 64 ? k : 64;
   int m = (int)round_up(k + extra, 64) * h->overfetch_boost;
   return m > kMaxSel ? kMaxSel : m;
 }
@@ -374,8 +415,20 @@ int auto_overfetch(const anr_index *h, int k) {
 // a quarter of a batch's queries fail their certificate the automatic K' doubles (up to 4x, capped at 1024) —
 // an exact re-score of 1024 rows per query costs ~40 us per batch, the second scan ~300 us at a 1.25 M-row
 // shard — and it halves again after 16 consecutive batches without a failure.
-void adapt_overfetch(anr_index *h, int n_queries, int n_failed) {
-  if (h->overfetch > 0 || n_queries <= 0) return;  // the caller fixed K'
+void adapt_overfetch(anr_index *h, int n_queries, int n_failed, bool f12) {
+  if (n_queries <= 0) return;
+  // The 12-bit image widens the certificate's error term ~15x: where hundreds of rows lie that close to the k-th score
+  // (near-duplicate neighbourhoods) even the largest K' cannot certify and the lists overflow into the dense exact path.
+  // Two such batches in a row with K' at its cap (or fixed by the caller) and the index goes back to the f16 image until
+  // the option is set again or the index is reset.
+  if (f12) {
+    if (4 * n_failed > n_queries && (h->overfetch > 0 || h->overfetch_boost >= 4)) {
+      if (++h->f12_strikes >= 2) h->f12_suspended = true;
+    } else if (4 * n_failed <= n_queries) {
+      h->f12_strikes = 0;
+    }
+  }
+  if (h->overfetch > 0) return;  // the caller fixed K'
   if (4 * n_failed > n_queries) {
     if (h->overfetch_boost < 4) h->overfetch_boost *= 2;
     h->clean_batches = 0;
@@ -599,7 +652,7 @@ int retire(anr_index *h, Workspace &w) {
           h->stats.n_candidates += w.cnt_host[q];
           if (w.cnt_host[kQB + q]) h->stats.n_overflow += 1;
         }
-      adapt_overfetch(h, w.nq, (int)fallback.size());
+      adapt_overfetch(h, w.nq, (int)fallback.size(), w.sparse && w.f12);
     }
     h->stats.n_fallback += (int64_t)fallback.size();
   }
@@ -714,7 +767,15 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
     return ANR_OK;
   }
 
-  const int M = auto_overfetch(h, k);
+  // the image the streaming pass reads (ANR_OPT_SCAN_BITS; 0 = 12 bits from kAuto12Rows rows on: below, a batch is
+  // mostly its side kernels).  The sample and every recovery scan read x16; the certificate of a 12-bit batch takes the
+  // statistics of the coarser image (pp.xstat / fp.xstat below).
+  bool f12 = false;
+  if (!h->f12_suspended && (h->scan_bits == 12 || (h->scan_bits == 0 && h->ntotal >= kAuto12Rows))) {
+    if (!h->x12) (void)build_x12(h);  // (auto: stays on the f16 image when the memory is not there)
+    f12 = h->x12 != nullptr;
+  }
+  const int M = auto_overfetch(h, k, f12);
   w.M = M;
   const int64_t n_tiles = ceil_div(h->ntotal, kTileRows);
   const int64_t full_tiles = h->ntotal / kTileRows;
@@ -848,14 +909,20 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
       ANR_HIP(hipStreamWaitEvent(ms, w.ev_pre, 0));
     }
     if (w.timed) ANR_HIP(hipEventRecord(w.ev_t0, ms));
-    ANR_TRY(launch_scan<false>(h, sc, ms, scan_grid_max, &scan_grid));
+    w.f12 = f12;
+    if (f12) {
+      sc.x12 = h->x12;
+      ANR_TRY((launch_scan<false, true>(h, sc, ms, scan_grid_max, &scan_grid)));
+    } else {
+      ANR_TRY(launch_scan<false>(h, sc, ms, scan_grid_max, &scan_grid));
+    }
     w.scan_grid = scan_grid;
     if (w.timed) ANR_HIP(hipEventRecord(w.ev_t1, ms));
     if (roles) {
       ANR_HIP(hipEventRecord(w.ev_scan, ms));
       ANR_HIP(hipStreamWaitEvent(ps, w.ev_scan, 0));
     }
-    w.scan_bytes = n_tiles * kTileRows * (int64_t)h->dimp * 2;
+    w.scan_bytes = n_tiles * kTileRows * (int64_t)h->dimp * (f12 ? 3 : 4) / 2;
     // post
     sp.cand = w.cand;
     sp.cntb = w.cntb;
@@ -876,7 +943,7 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
     pp.dimp = h->dimp;
     pp.metric = h->metric;
     pp.qstat = w.qstat;
-    pp.xstat = h->xstat;
+    pp.xstat = (sparse && w.f12) ? h->xstat12 : h->xstat;
     pp.overflow = sparse ? w.ncand + kQB : nullptr;
     pp.ncand = sparse ? w.ncand : nullptr;
     pp.n_rows = h->ntotal;
@@ -934,7 +1001,7 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
   fp.sel_m = w.sel_m;
   fp.overflow = sparse ? w.ncand + kQB : nullptr;
   fp.qstat = w.qstat;
-  fp.xstat = h->xstat;
+  fp.xstat = (sparse && w.f12) ? h->xstat12 : h->xstat;
   fp.metric = h->metric;
   fp.dimp = h->dimp;
   fp.n_rows = h->ntotal;
@@ -968,6 +1035,9 @@ int refresh_xstat(anr_index *h) {
   ANR_HIP(hipStreamSynchronize(h->stream));
   ANR_HIP(hipMemcpy(host, h->xstat, sizeof host, hipMemcpyDeviceToHost));
   h->f16_unusable = host[2] != 0;
+  // (norms are floats >= 0: their bit patterns order like the values)
+  const unsigned pair[2] = {host[0], host[1] > host[3] ? host[1] : host[3]};
+  ANR_HIP(hipMemcpy(h->xstat12, pair, sizeof pair, hipMemcpyHostToDevice));
   h->xstat_dirty = false;
   return ANR_OK;
 }
@@ -1285,6 +1355,7 @@ int add_impl(anr_index *h, const float *x_dev, int64_t n, hipStream_t st) {
   ap.x16 = h->x16;
   ap.rowbias = h->rowbias;
   ap.stat = h->xstat;
+  ap.x12 = h->x12;  // (kept up to date whenever it exists)
   const int64_t t0 = h->ntotal / kTileRows, t1 = ceil_div(h->ntotal + n, kTileRows);
   hipLaunchKernelGGL(k_add, dim3((unsigned)(t1 - t0)), dim3(256), 0, st, ap);
   ANR_HIP(hipGetLastError());
@@ -1359,6 +1430,7 @@ int anr_index_create(int32_t dim, int32_t metric, int32_t normalize, int32_t dev
     }
   }
   int r = dev_alloc(&h->xstat, 4, true);
+  if (r == ANR_OK) r = dev_alloc(&h->xstat12, 2, true);
   if (r != ANR_OK) {
     anr_index_destroy(h);
     return r;
@@ -1376,6 +1448,8 @@ int anr_index_destroy(anr_index *h) {
   dev_free(h->x16);
   dev_free(h->rowbias);
   dev_free(h->xstat);
+  dev_free(h->xstat12);
+  dev_free(h->x12);
   free_workspaces(h);
   dev_free(h->xdense);
   free_largek(&h->largek);
@@ -1449,11 +1523,14 @@ int anr_index_reset(anr_index *h) {
   ANR_TRY(drain(h));
   ANR_HIP(hipStreamSynchronize(h->stream));
   if (h->x16) ANR_HIP(hipMemset(h->x16, 0, (size_t)h->cap * h->dimp * sizeof(_Float16)));
+  if (h->x12) ANR_HIP(hipMemset(h->x12, 0, (size_t)h->cap * h->dimp * 3 / 2));
   if (h->rowbias) ANR_HIP(hipMemset(h->rowbias, 0, (size_t)h->cap * sizeof(float)));
   ANR_HIP(hipMemset(h->xstat, 0, 4 * sizeof(unsigned)));
   ANR_HIP(hipStreamSynchronize(nullptr));  // the fills run on the NULL stream; later adds use the handle's own
   h->ntotal = 0;
   h->xstat_dirty = true;
+  h->f12_suspended = false;
+  h->f12_strikes = 0;
   return ANR_OK;
 }
 
@@ -1749,6 +1826,18 @@ int anr_index_set_option(anr_index *h, int32_t opt, int64_t value) {
     case ANR_OPT_SHADOW: h->shadow = value < 0 ? 0 : (value > 2 ? 2 : (int)value); break;
     case ANR_OPT_SCHEDULE: h->schedule = value != 0; break;
     case ANR_OPT_STREAM_WAIT: h->stream_wait = value != 0; break;
+    case ANR_OPT_SCAN_BITS: {
+      if (value != 0 && value != 12 && value != 16) return fail(ANR_EINVAL, "scan bits must be 0 (auto), 12 or 16");
+      h->f12_suspended = false;
+      h->f12_strikes = 0;
+      if ((int)value == h->scan_bits) break;
+      ANR_TRY(drain(h));
+      ANR_HIP(hipStreamSynchronize(h->stream));
+      h->scan_bits = (int)value;
+      if (value == 16) dev_free(h->x12);
+      if (value == 12 && !h->x12 && h->cap > 0) ANR_TRY(build_x12(h));
+      break;
+    }
     case ANR_OPT_STREAMS:
       if (value < 1 || value > kWorkspaces) return fail(ANR_EINVAL, "streams must be in 1..%d", kWorkspaces);
       h->n_streams = (int)value;

@@ -6,6 +6,12 @@
 //   x16  [cap/32][KB][64 lanes][8]     f16, "MFMA-blocked": one 1-KiB block is exactly the A operand of
 //                                      one v_mfma_f32_32x32x16_f16 for 32 rows x 16 dims, so a wave's
 //                                      16-B/lane load is one contiguous KiB and lands in operand layout;
+//   x12  [cap/32][KB][64 lanes][12 B]  optional (ANR_OPT_SCAN_BITS 12): the same blocks with every f16 rounded to its top
+//                                      12 bits (sign, 5 exponent, 6 mantissa bits) — what the streaming scan reads instead of
+//                                      x16, 25 % fewer bytes.  Per lane three words: the high bytes of elements 0-3, of
+//                                      elements 4-7, and the eight low nibbles (elements 0-3 in the low nibbles of bytes
+//                                      0-3, elements 4-7 in the high nibbles) — seven vector instructions turn them back
+//                                      into the 16-byte f16 operand (x12_unpack);
 //   q16  [2][KB][64 lanes][8]          f16, the 64 queries of a batch in the B-operand layout.
 // KB = dimp/16 with dimp = dim rounded up to 128.
 #pragma once
@@ -54,6 +60,41 @@ __global__ void k_clock(unsigned long long *out_pinned) {
   __hip_atomic_store(out_pinned, (unsigned long long)wall_clock64(), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// ---- the 12-bit image of an f16 operand block (ANR_OPT_SCAN_BITS 12) -------------------------------------------------
+// An f16 keeps its sign, exponent and the top six mantissa bits, rounded to nearest-even at bit 4 (a carry walks into the
+// exponent as IEEE intends; a value that would round up to infinity is truncated instead).  value(x12) = f16 bits (x12 << 4).
+__device__ __forceinline__ unsigned f16_to_12(_Float16 q) {
+  const unsigned b = (unsigned)__builtin_bit_cast(unsigned short, q);
+  unsigned r = (b + 7u + ((b >> 4) & 1u)) >> 4;
+  if ((r & 0x7c0u) == 0x7c0u && (b & 0x7c00u) != 0x7c00u) r = b >> 4;  // would become inf / nan: truncate
+  return r & 0xfffu;
+}
+__device__ __forceinline__ _Float16 f12_value(unsigned r) {
+  return __builtin_bit_cast(_Float16, (unsigned short)(r << 4));
+}
+struct X12 {
+  unsigned h0, h1, nib;
+};
+__device__ __forceinline__ X12 x12_pack(const unsigned (&r)[8]) {
+  X12 o;
+  o.h0 = (r[0] >> 4) | ((r[1] >> 4) << 8) | ((r[2] >> 4) << 16) | ((r[3] >> 4) << 24);
+  o.h1 = (r[4] >> 4) | ((r[5] >> 4) << 8) | ((r[6] >> 4) << 16) | ((r[7] >> 4) << 24);
+  o.nib = (r[0] & 15u) | ((r[1] & 15u) << 8) | ((r[2] & 15u) << 16) | ((r[3] & 15u) << 24) | ((r[4] & 15u) << 4) |
+          ((r[5] & 15u) << 12) | ((r[6] & 15u) << 20) | ((r[7] & 15u) << 28);
+  return o;
+}
+// -> the f16 operand (element 2 j in the low half of word j).  v_perm_b32 picks bytes 0-3 from its SECOND source and 4-7 from
+// its first: word 0 = [nl.b0, h0.b0, nl.b1, h0.b1], word 1 = [nl.b2, h0.b2, nl.b3, h0.b3], likewise h1 / nh.
+__device__ __forceinline__ uint4 x12_unpack(unsigned h0, unsigned h1, unsigned nib) {
+  const unsigned nl = (nib & 0x0f0f0f0fu) << 4, nh = nib & 0xf0f0f0f0u;
+  uint4 o;
+  o.x = __builtin_amdgcn_perm(h0, nl, 0x05010400u);
+  o.y = __builtin_amdgcn_perm(h0, nl, 0x07030602u);
+  o.z = __builtin_amdgcn_perm(h1, nh, 0x05010400u);
+  o.w = __builtin_amdgcn_perm(h1, nh, 0x07030602u);
+  return o;
+}
+
 // ------------------------------------------------------------------------------------------------
 // add: normalise (optional), store x32, convert to the blocked f16 image, track norm / error maxima
 // ------------------------------------------------------------------------------------------------
@@ -67,13 +108,15 @@ struct AddParams {
   _Float16 *x16;
   float *rowbias;     // [cap] -0.5*||x||^2 of the stored row (L2 metric) or nullptr
   unsigned *stat;     // [0] max ||x|| bits, [1] max ||x16 - x|| bits (floats >= 0, so uint order == float
-                      // order), [2] != 0 when some |x| exceeds the f16 range (scan disabled)
+                      // order), [2] != 0 when some |x| exceeds the f16 range (scan disabled), [3] max ||x12 - x|| bits
+  unsigned *x12;      // optional 12-bit image (see the top of this file)
 };
 
 // one block (256 threads) per 32-row tile that receives rows
 __global__ __launch_bounds__(256) void k_add(AddParams p) {
   __shared__ float s_scale[kTileRows];
   __shared__ float s_err[kTileRows];
+  __shared__ float s_err12[kTileRows];
   __shared__ float s_n2[kTileRows];
   __shared__ float s_x[kTileRows][132];
 
@@ -100,6 +143,7 @@ __global__ __launch_bounds__(256) void k_add(AddParams p) {
       if (p.normalize && nrm != 0.0f) scale = nrm;  // divide by the norm (vector_index.py:277-280)
       s_scale[r] = scale;
       s_err[r] = 0.0f;
+      s_err12[r] = 0.0f;
       s_n2[r] = 0.0f;
     }
   }
@@ -129,7 +173,8 @@ __global__ __launch_bounds__(256) void k_add(AddParams p) {
       const int64_t src = grow - p.row0;
       if (src >= 0 && src < p.n) {
         half8 hv;
-        float e2 = 0.0f, n2 = 0.0f;
+        unsigned r12[8];
+        float e2 = 0.0f, n2 = 0.0f, e12 = 0.0f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           float v = s_x[r][kbl * 16 + h * 8 + j];
@@ -139,9 +184,20 @@ __global__ __launch_bounds__(256) void k_add(AddParams p) {
           if (fabsf(v) > 65504.0f) atomicOr(&p.stat[2], 1u);
           e2 += d * d;
           n2 += v * v;
+          r12[j] = f16_to_12(q);
+          const float d12 = (float)f12_value(r12[j]) - v;
+          e12 += d12 * d12;
         }
         const int64_t blk = tile * p.kb + (k0 >> 4) + kbl;
         *reinterpret_cast<half8 *>(p.x16 + (blk * 64 + l) * 8) = hv;
+        if (p.x12) {
+          const X12 pk = x12_pack(r12);
+          unsigned *o = p.x12 + (blk * 64 + l) * 3;
+          o[0] = pk.h0;
+          o[1] = pk.h1;
+          o[2] = pk.nib;
+          atomicAdd(&s_err12[r], e12);
+        }
         atomicAdd(&s_err[r], e2);
         atomicAdd(&s_n2[r], n2);
       }
@@ -155,9 +211,54 @@ __global__ __launch_bounds__(256) void k_add(AddParams p) {
       // 1.0001: slack for the f32 accumulation of the partial sums above
       atomicMax(&p.stat[0], __float_as_uint(sqrtf(s_n2[tid]) * 1.0001f));
       atomicMax(&p.stat[1], __float_as_uint(sqrtf(s_err[tid]) * 1.0001f));
+      if (p.x12) atomicMax(&p.stat[3], __float_as_uint(sqrtf(s_err12[tid]) * 1.0001f));
       if (p.rowbias) p.rowbias[grow] = -0.5f * s_n2[tid];
     }
   }
+}
+
+// the 12-bit image of rows that are already stored (ANR_OPT_SCAN_BITS switched to 12 on a filled index): one block per
+// 32-row tile, from x16, the error against x32
+struct Build12Params {
+  const float *x32;
+  const _Float16 *x16;
+  unsigned *x12;
+  int64_t n_rows;
+  int dim, kb;
+  unsigned *stat;  // [3] max ||x12 - x||
+};
+__global__ __launch_bounds__(256) void k_build12(Build12Params p) {
+  __shared__ float s_err12[kTileRows];
+  const int tid = threadIdx.x;
+  const int64_t tile = blockIdx.x;
+  if (tid < kTileRows) s_err12[tid] = 0.0f;
+  __syncthreads();
+  for (int i = tid; i < p.kb * 64; i += 256) {
+    const int kbl = i >> 6, l = i & 63;
+    const int r = l & 31, h = l >> 5;
+    const int64_t grow = tile * kTileRows + r;
+    const int64_t blk = tile * p.kb + kbl;
+    const half8 hv = *reinterpret_cast<const half8 *>(p.x16 + (blk * 64 + l) * 8);
+    unsigned r12[8];
+    float e12 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      r12[j] = f16_to_12(hv[j]);
+      const int k = kbl * 16 + h * 8 + j;
+      const float v = (grow < p.n_rows && k < p.dim) ? p.x32[grow * p.dim + k] : 0.0f;
+      const float d12 = (float)f12_value(r12[j]) - v;
+      e12 += d12 * d12;
+    }
+    const X12 pk = x12_pack(r12);
+    unsigned *o = p.x12 + (blk * 64 + l) * 3;
+    o[0] = pk.h0;
+    o[1] = pk.h1;
+    o[2] = pk.nib;
+    if (grow < p.n_rows) atomicAdd(&s_err12[r], e12);
+  }
+  __syncthreads();
+  if (tid < kTileRows && tile * kTileRows + tid < p.n_rows)
+    atomicMax(&p.stat[3], __float_as_uint(sqrtf(s_err12[tid]) * 1.0001f));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -250,6 +351,7 @@ __global__ __launch_bounds__(256) void k_prepq(PrepQParams p) {
 // ------------------------------------------------------------------------------------------------
 struct ScanParams {
   const uint4 *x16;
+  const unsigned *x12;  // the 12-bit image (k_scan<.., F12 = true> reads it instead of x16)
   const uint4 *q16;
   int kb;
   int64_t n_rows;
@@ -284,37 +386,72 @@ __device__ __forceinline__ uint4 ld16(const uint4 *p) {
   return *p;
 }
 
-template <int CH, bool STREAM>
-__device__ __forceinline__ void scan_load(uint4 (&a)[CH], const uint4 *xa, int kbase) {
+// The corpus operand of the scan as it sits in registers: F12 = false, the 16-byte f16 block as loaded; F12 = true, the
+// three words of the 12-bit image, unpacked (x12_unpack) right before the block's two MFMAs.  `xa` is the lane's pointer
+// into the first k-block of the tile, in units of one lane's share of a block (a uint4, or three words).
+template <bool F12>
+struct ScanOp;
+template <>
+struct ScanOp<false> {
+  uint4 v;
+  static constexpr int kLaneBytes = 16;
+  template <bool STREAM>
+  __device__ __forceinline__ void load(const char *base, int j) {  // k-block j after `base` (this lane's share of it)
+    v = ld16<STREAM>(reinterpret_cast<const uint4 *>(base) + (int64_t)j * 64);
+  }
+  __device__ __forceinline__ half8 operand() const { return __builtin_bit_cast(half8, v); }
+};
+template <>
+struct ScanOp<true> {
+  unsigned h0, h1, nib;
+  static constexpr int kLaneBytes = 12;
+  template <bool STREAM>
+  __device__ __forceinline__ void load(const char *base, int j) {
+    const unsigned *p = reinterpret_cast<const unsigned *>(base) + (int64_t)j * 64 * 3;
+    if (STREAM) {
+      h0 = __builtin_nontemporal_load(p);
+      h1 = __builtin_nontemporal_load(p + 1);
+      nib = __builtin_nontemporal_load(p + 2);
+    } else {
+      h0 = p[0];
+      h1 = p[1];
+      nib = p[2];
+    }
+  }
+  __device__ __forceinline__ half8 operand() const { return __builtin_bit_cast(half8, x12_unpack(h0, h1, nib)); }
+};
+
+template <int CH, bool STREAM, bool F12>
+__device__ __forceinline__ void scan_load(ScanOp<F12> (&a)[CH], const char *base) {
 #pragma unroll
-  for (int j = 0; j < CH; ++j) a[j] = ld16<STREAM>(xa + (int64_t)(kbase + j) * 64);
+  for (int j = 0; j < CH; ++j) a[j].template load<STREAM>(base, j);
 }
 
-template <int CH>
-__device__ __forceinline__ void scan_mfma(const uint4 (&a)[CH], const uint4 *ldsq0, const uint4 *ldsq1,
+template <int CH, bool F12>
+__device__ __forceinline__ void scan_mfma(const ScanOp<F12> (&a)[CH], const uint4 *ldsq0, const uint4 *ldsq1,
                                           int kbase, floatx16 &acc0, floatx16 &acc1) {
 #pragma unroll
   for (int j = 0; j < CH; ++j) {
     const uint4 b0 = ldsq0[(kbase + j) * 64];
     const uint4 b1 = ldsq1[(kbase + j) * 64];
-    const half8 av = __builtin_bit_cast(half8, a[j]);
+    const half8 av = a[j].operand();
     acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(half8, b0), acc0, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(half8, b1), acc1, 0, 0, 0);
   }
 }
 
 // same, and re-fills each operand register from `next` as soon as its two MFMAs have issued
-template <int CH, bool STREAM>
-__device__ __forceinline__ void scan_mfma_refill(uint4 (&a)[CH], const uint4 *next, const uint4 *ldsq0,
+template <int CH, bool STREAM, bool F12>
+__device__ __forceinline__ void scan_mfma_refill(ScanOp<F12> (&a)[CH], const char *next, const uint4 *ldsq0,
                                                  const uint4 *ldsq1, int kbase, floatx16 &acc0, floatx16 &acc1) {
 #pragma unroll
   for (int j = 0; j < CH; ++j) {
     const uint4 b0 = ldsq0[(kbase + j) * 64];
     const uint4 b1 = ldsq1[(kbase + j) * 64];
-    const half8 av = __builtin_bit_cast(half8, a[j]);
+    const half8 av = a[j].operand();
     acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(half8, b0), acc0, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(half8, b1), acc1, 0, 0, 0);
-    a[j] = ld16<STREAM>(next + (int64_t)j * 64);
+    a[j].template load<STREAM>(next, j);
   }
 }
 
@@ -367,7 +504,7 @@ __device__ __forceinline__ void scan_emit(const floatx16 &acc, float tau, int lv
 #else
 #define ANR_SCAN_ATTR
 #endif
-template <bool DENSE, int CH, int NT, bool STREAM>
+template <bool DENSE, int CH, int NT, bool STREAM, bool F12 = false>
 __global__ __launch_bounds__(NT) ANR_SCAN_ATTR void k_scan(ScanParams p) {
   // LDS: Q operand image [2][kb][64] | ladder [64][L] | list lengths [64] | level [64] | pending [64][L]
   extern __shared__ uint4 lds[];
@@ -404,15 +541,17 @@ __global__ __launch_bounds__(NT) ANR_SCAN_ATTR void k_scan(ScanParams p) {
 
   // the first chunk of a wave's next tile is requested before the current tile's epilogue, so the wave
   // always has loads in flight (the epilogue would otherwise be a bubble in its share of the stream)
-  uint4 aA[CH], aB[CH];
-  if (wglobal < p.n_tiles) scan_load<CH, STREAM>(aA, p.x16 + (p.tile0 + wglobal * p.tile_stride) * p.kb * 64 + lane, 0);
+  ScanOp<F12> aA[CH], aB[CH];
+  // the lane's share of one k-block is LB bytes (16: f16 image, 12: 12-bit image); a tile is kb such blocks of 64 lanes
+  constexpr int64_t LB = ScanOp<F12>::kLaneBytes, BLK = 64 * LB;
+  const char *xlane = (F12 ? reinterpret_cast<const char *>(p.x12) : reinterpret_cast<const char *>(p.x16)) + lane * LB;
+  if (wglobal < p.n_tiles) scan_load<CH, STREAM, F12>(aA, xlane + (p.tile0 + wglobal * p.tile_stride) * p.kb * BLK);
   for (int64_t i = wglobal; i < p.n_tiles; i += wtotal) {
     const int64_t tile = p.tile0 + i * p.tile_stride;
-    const uint4 *xa = p.x16 + tile * p.kb * 64 + lane;
+    const char *xa = xlane + tile * p.kb * BLK;
     // no next tile: re-request this tile's last chunk instead (an L2 hit), which keeps the loop free of
     // conditional loads so the compiler can count the outstanding loads exactly
-    const uint4 *xn = (i + wtotal < p.n_tiles) ? xa + wtotal * p.tile_stride * p.kb * 64
-                                               : xa + (int64_t)(p.kb - CH) * 64;
+    const char *xn = (i + wtotal < p.n_tiles) ? xa + wtotal * p.tile_stride * p.kb * BLK : xa + (int64_t)(p.kb - CH) * BLK;
     floatx16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -420,11 +559,11 @@ __global__ __launch_bounds__(NT) ANR_SCAN_ATTR void k_scan(ScanParams p) {
       acc1[r] = 0.0f;
     }
     for (int c = 0; c < nch; c += 2) {
-      scan_load<CH, STREAM>(aB, xa, (c + 1) * CH);
+      scan_load<CH, STREAM, F12>(aB, xa + (int64_t)(c + 1) * CH * BLK);
       __builtin_amdgcn_sched_barrier(0);
-      scan_mfma_refill<CH, STREAM>(aA, (c + 2 < nch) ? xa + (int64_t)(c + 2) * CH * 64 : xn, ldsq0, ldsq1, c * CH, acc0, acc1);
+      scan_mfma_refill<CH, STREAM, F12>(aA, (c + 2 < nch) ? xa + (int64_t)(c + 2) * CH * BLK : xn, ldsq0, ldsq1, c * CH, acc0, acc1);
       __builtin_amdgcn_sched_barrier(0);
-      scan_mfma<CH>(aB, ldsq0, ldsq1, (c + 1) * CH, acc0, acc1);
+      scan_mfma<CH, F12>(aB, ldsq0, ldsq1, (c + 1) * CH, acc0, acc1);
     }
 
     const int64_t row_base = tile * kTileRows + 4 * half;
@@ -542,7 +681,8 @@ __global__ __launch_bounds__(256) void k_sample(SampleParams p) {
     for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
     // CH operand registers: each is re-filled with the block CH k-steps ahead as soon as its MFMA has issued
     uint4 a[CH];
-    scan_load<CH, false>(a, xa, 0);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) a[j] = xa[(int64_t)j * 64];
     // ONE loop over the k-steps (a nest of slice and step loops doubled the accumulator registers); at a slice boundary
     // the workgroup swaps the LDS slice
     for (int kc = 0, c = p.kbs; kc < p.kb; kc += CH, c += CH) {

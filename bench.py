@@ -7,15 +7,16 @@ batch of 64 queries answered end to end (query prep, scan, select, exact re-scor
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
 
-N = 1: the whole corpus sits on one MI355X (fp32 rows + blocked f16 image = 46 GB).
+N = 1: the whole corpus sits on one MI355X (fp32 rows + blocked f16 image + its 12-bit image = 57.6 GB).
 N > 1 (launched by torch.distributed.run, one rank per GPU): the corpus is row-sharded, every rank
 scans its shard for the same batch, the [64,100] partial top-k (score f32 + global id i64) of two consecutive
 batches are all-gathered over RCCL in one collective and merged — each batch only after anr_index_wait() has made it
 final on its shard (certificate recovery included); strong scaling (total corpus fixed).
 
 Rank 0 prints ONE JSON line.  `value` = queries/s of the whole job with the corpus resident in HBM.
-`roofline` is for the dominant kernel (k_scan): algorithmic bytes = rows x 768 x 2 B (the f16 image
-actually streamed) per launch / that kernel's duration.  The duration is taken with HIP events around the
+`roofline` is for the dominant kernel (k_scan): algorithmic bytes = rows x 768 x 1.5 B (the image actually streamed:
+every stored f16 rounded to its top 12 bits, ANR_OPT_SCAN_BITS — 2 B with --scan-bits 16; the figure is the library's own
+`scan_bytes` statistic) per launch / that kernel's duration.  The duration is taken with HIP events around the
 launch on its own stream in a leg of SERIALISED batches right after the timed region (one batch in flight,
 so the events bracket the kernel and nothing else): inside the timed region three batches are in flight on
 three streams and the same events also span the wait for the previous batch's scan to leave the CUs (that
@@ -47,6 +48,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+SCAN_BITS = 0  # ANR_OPT_SCAN_BITS of every index this file builds (--scan-bits; 0 = the library's default: 12 bits from 524 288 rows on)
 
 
 def parse():
@@ -66,6 +68,9 @@ def parse():
     ap.add_argument("--serial-launches", type=int, default=20,
                     help="serialised batches after the timed region from which the kernel-only scan time is taken")
     ap.add_argument("--no-facade", action="store_true", help="skip the VectorIndex.search (host in, dicts out) leg")
+    ap.add_argument("--scan-bits", type=int, default=SCAN_BITS, choices=(0, 12, 16),
+                    help="ANR_OPT_SCAN_BITS: the image the streaming pass reads (12: every f16 rounded to its top 12 bits, 25 %% "
+                         "fewer bytes per row; the certificate accounts for it, results stay exact)")
     ap.add_argument("--in-flight", type=int, default=3,
                     help="batches left in flight (default 3).  1: every batch is retired before the next is enqueued — the form "
                          "the rocprofv3 kernel statistics are taken on: with batches in flight the NEXT scan's workgroups "
@@ -239,8 +244,9 @@ def pipeline_leg(rows, dim, batch, k, dev, seed, steps=60, warmup=10, serial=20,
     batch) says where a slow batch lost its time: the largest host gap between two enqueues and the largest
     scan-start-to-scan-start period on the device, per segment."""
     from anorag_hip import FlatIndex, METRIC_IP
-    from anorag_hip._lib import OPT_OVERFETCH
+    from anorag_hip._lib import OPT_OVERFETCH, OPT_SCAN_BITS
     idx = FlatIndex(dim, METRIC_IP, normalize=True, device=dev.index)
+    idx.set_option(OPT_SCAN_BITS, SCAN_BITS)
     idx.reserve(rows)
     for xb in gen_shard(rows, dim, seed, dev, centroids=centroids, sigma=sigma):
         torch.cuda.synchronize()
@@ -515,7 +521,9 @@ def facade_leg(idx, args, q_host):
 
 
 def main():
+    global SCAN_BITS
     args = parse()
+    SCAN_BITS = args.scan_bits
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -549,6 +557,8 @@ def main():
     my_rows = max(0, min(per, rows_total - row0))
 
     idx = FlatIndex(args.dim, METRIC_IP, normalize=True, device=local_rank)
+    from anorag_hip._lib import OPT_SCAN_BITS
+    idx.set_option(OPT_SCAN_BITS, SCAN_BITS)
     idx.reserve(my_rows)
     for xb in gen_shard(my_rows, args.dim, rank, dev):
         torch.cuda.synchronize()
@@ -725,6 +735,9 @@ def main():
         consistent = bool(ms_launch is not None and ms_launch <= ms_step * 1.005)
         if not consistent:
             print(f"bench.py: kernel time per launch {ms_launch:.4f} ms exceeds the step time {ms_step:.4f} ms", file=sys.stderr)
+        bpl = ker_bytes if ker_ms else scan_bytes / max(1, args.steps)
+        bytes_per_value = bpl / max(1.0, float(-(-per // 32) * 32) * args.dim)
+        twelve = bytes_per_value < 1.75
         out = {
             "metric": "queries/sec + recall@k vs CPU ref, 10M×768 corpus, batch-64 top-100",
             "value": qps,
@@ -736,7 +749,9 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f16 scan (MFMA, f32 accumulate) + f32 rows re-scored in f64",
+            "dtype": ("f16 scan (MFMA f16 x f16, f32 accumulate; the scanned image keeps the top 12 bits of every stored f16 — "
+                      "ANR_OPT_SCAN_BITS) + f32 rows re-scored in f64" if twelve else
+                      "f16 scan (MFMA, f32 accumulate) + f32 rows re-scored in f64"),
             "data": "synthetic",
             "config": {
                 "workload": f"{rows_total} x {args.dim} unit-norm Gaussian corpus, batch-{args.batch} top-{args.k} "
@@ -762,7 +777,8 @@ def main():
                 "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
                 "traffic": traffic,
                 "traffic_note": "; ".join(tnotes),
-                "bytes_per_launch": ker_bytes if ker_ms else scan_bytes / max(1, args.steps),
+                "bytes_per_launch": bpl,
+                "bytes_per_stored_value": round(bytes_per_value, 3),
                 "ms_per_launch": ms_launch,
                 "launches_timed": n_serial if ker_ms else args.steps,
                 "timing": ("HIP events around the launch on its stream, serialised batches after the timed region"

@@ -377,7 +377,7 @@ def test_sparse_producer_and_consumer_refuse_what_they_cannot_hold():
     assert fuse_dense("linear", w0, 60.0, 5, 1, {"dense": dl, "bm25": ok})[3][0] == 5
     ok.free()
     w = {"dense": 1.0, "bm25": 0.5, "graph": 0.5, "path": 0.1}
-    big = SparseRows(1, 100_000, 8193)             # beyond the fusion's 8192 entries per row
+    big = SparseRows(1, 100_000, 65537)            # beyond the fusion's 65 536 entries per row
     with pytest.raises(_lib.AnoragError):
         fuse_dense("linear", w, 60.0, 10, 1, {"bm25": big})
     big.free()

@@ -673,3 +673,92 @@ def test_pipelined_batches_with_failed_certificates_recover_beside_the_pipeline(
     Dr, Ir = orc.flat_search(qn, xn, k, "ip")
     assert orc.near_tie_equal(ref[nb - 1][1], Ir, orc.exact_scores(qn, xn, "ip"), k, 1e-6)
     idx.close()
+
+
+@pytest.mark.parametrize("when", ["before_add", "after_add"])
+def test_twelve_bit_scan_image_gives_the_exact_top_k(when):
+    """ANR_OPT_SCAN_BITS 12: the streaming pass reads every stored f16 rounded to its top 12 bits (25 % fewer bytes); the
+    certificate takes the coarser image's error norm, so the answers stay the exact top-k of the float32 rows — Gaussian
+    rows, a ragged row count, cosine / raw inner product / L2, the option set before the rows arrive (k_add writes both
+    images) and on a filled index (k_build12), incremental adds after the switch, and tight clusters whose certificates
+    fail (recovery from the lists, theta re-scan)."""
+    from anorag_hip import FlatIndex, METRIC_IP, METRIC_L2
+    from anorag_hip._lib import OPT_SCAN_BITS
+    n, d, nq, k = 200_001, 768, 64, 100
+    x, q = _data(n, d, nq, seed=77, qseed=78)
+    for metric, name, normalize in ((METRIC_IP, "ip", True), (METRIC_IP, "ip", False), (METRIC_L2, "l2", False)):
+        idx = FlatIndex(d, metric, normalize=normalize)
+        if when == "before_add":
+            idx.set_option(OPT_SCAN_BITS, 12)
+        idx.add(x[:150_000])
+        if when == "after_add":
+            idx.set_option(OPT_SCAN_BITS, 12)
+        idx.add(x[150_000:])                       # rows appended after the switch land in both images
+        D, I, Dr, Ir = _check(idx, x, q, k, name, normalize)
+        st = idx.last_stats()
+        assert st["sample_rows"] > 0 and st["n_dense_exact"] == 0, st
+        tiles = -(-n // 32)
+        assert st["scan_bytes"] == tiles * 32 * 768 * 3 // 2, st      # 1.5 bytes per stored value
+        if name == "ip" and normalize:
+            idx.set_option(OPT_SCAN_BITS, 16)      # and back: the f16 image, the same answers
+            D16, I16 = idx.search(q, k)
+            assert np.array_equal(I16, I) and np.array_equal(D16, D)
+            assert idx.last_stats()["scan_bytes"] == tiles * 32 * 768 * 2
+        idx.close()
+    rng = np.random.default_rng(11)
+    n, d, nq, k = 150_000, 256, 64, 50
+    cent = rng.standard_normal((300, d)).astype(np.float32)
+    x = (cent[rng.integers(0, 300, n)] + 0.02 * rng.standard_normal((n, d))).astype(np.float32)
+    q = (cent[rng.integers(0, 300, nq)] + 0.02 * rng.standard_normal((nq, d))).astype(np.float32)
+    idx = FlatIndex(d, METRIC_IP, normalize=True)
+    if when == "before_add":
+        idx.set_option(OPT_SCAN_BITS, 12)
+    idx.add(x)
+    idx.set_option(OPT_SCAN_BITS, 12)
+    # near-duplicate neighbourhoods: hundreds of rows within the 12-bit error bound of the k-th score — exact answers from the
+    # first batch on (lists, theta re-scan, dense exact path), and after two batches that failed at the largest K' the index
+    # goes back to the f16 image by itself
+    seen = []
+    for _ in range(8):
+        _check(idx, x, q, k, "ip", True)
+        st = idx.last_stats()
+        seen.append((st["scan_bytes"], st["n_fallback"], st["n_dense_exact"]))
+    tiles = -(-n // 32)
+    assert seen[0][0] == tiles * 32 * 256 * 3 // 2 and seen[-1][0] == tiles * 32 * 256 * 2, seen
+    assert seen[-1][1] < nq // 2, seen             # as the f16 image does on this data at its largest K' (test_tight_clusters_...)
+    idx.reset()                                    # an emptied index keeps the option (and tries the 12-bit image again)
+    idx.add(x[:40_000])
+    _check(idx, x[:40_000], q, k, "ip", True)
+    idx.close()
+
+
+def test_twelve_bit_scan_pipelined_batches_equal_the_sixteen_bit_ones():
+    """the asynchronous pipeline with the 12-bit image: three batches in flight, results identical to the f16 image's"""
+    import torch
+    from anorag_hip import FlatIndex, METRIC_IP
+    from anorag_hip._lib import OPT_SCAN_BITS
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    n, d, nb, B, k = 400_000, 768, 9, 64, 100
+    idx = FlatIndex(d, METRIC_IP, normalize=True)
+    idx.reserve(n)
+    for _ in range(4):
+        xb = torch.randn((n // 4, d), generator=g, device=dev)
+        torch.cuda.synchronize()
+        idx.add_device(xb.data_ptr(), xb.shape[0])
+    Q = torch.randn((nb, B, d), generator=g, device=dev)
+    out = {}
+    for bits in (16, 12):
+        idx.set_option(OPT_SCAN_BITS, bits)
+        D = torch.empty((nb, B, k), device=dev)
+        I = torch.empty((nb, B, k), device=dev, dtype=torch.int64)
+        torch.cuda.synchronize()
+        for b in range(nb):
+            idx.search_device_async(Q[b].data_ptr(), B, k, D[b].data_ptr(), I[b].data_ptr(), 0)
+        idx.sync()
+        torch.cuda.synchronize()
+        out[bits] = (D.cpu().numpy(), I.cpu().numpy())
+    assert np.array_equal(out[12][1], out[16][1])
+    assert np.array_equal(out[12][0], out[16][0])      # the scores are the exact re-scored ones either way
+    idx.close()
