@@ -423,7 +423,12 @@ void adapt_overfetch(anr_index *h, int n_queries, int n_failed, bool f12) {
   // the option is set again or the index is reset.
   if (f12) {
     if (4 * n_failed > n_queries && (h->overfetch > 0 || h->overfetch_boost >= 4)) {
-      if (++h->f12_strikes >= 2) h->f12_suspended = true;
+      if (++h->f12_strikes >= 2) {
+        h->f12_suspended = true;
+        if (h->overfetch == 0) h->overfetch_boost = 1;  // the boost answered the 12-bit image's failures: the f16 image starts over
+        h->clean_batches = 0;
+        return;
+      }
     } else if (4 * n_failed <= n_queries) {
       h->f12_strikes = 0;
     }

@@ -183,7 +183,7 @@ def recall_from_partials(parts, I_gpu, k):
     return hits / float(ref.shape[0] * k)
 
 
-def pmc_traffic(rows_per_gpu, dim, notes):
+def pmc_traffic(rows_per_gpu, dim, notes, bytes_per_value=None):
     """HBM bytes per k_scan launch from the committed PMC passes (profiles/*_pmc_traffic_k_scan.json: FETCH_SIZE
     doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE, separate --pmc runs), scaled by rows when the
     shard differs.  The file records the sha256 of the k_scan region of csrc/index_kernels.hpp it was measured on
@@ -210,6 +210,10 @@ def pmc_traffic(rows_per_gpu, dim, notes):
         return None
     if p["dim"] != dim:
         notes.append("PMC profile taken at another dim")
+        return None
+    if bytes_per_value is not None and abs(p.get("bytes_per_stored_value", 2.0) - bytes_per_value) > 0.1:
+        notes.append(f"PMC profile taken on the {p.get('bytes_per_stored_value', 2.0)}-byte image, this run scanned the "
+                     f"{bytes_per_value:.2f}-byte one: traffic not reported")
         return None
     notes.append(f"STORED measurement, not read in this run: {os.path.basename(files[-1])} (rocprofv3 --pmc passes on the same "
                  f"kernel source, sha256 checked), scaled by rows")
@@ -723,7 +727,8 @@ def main():
 
     if rank == 0:
         tnotes = []
-        traffic = pmc_traffic(per, args.dim, tnotes)
+        _bpl = ker_bytes if ker_ms else scan_bytes / max(1, args.steps)
+        traffic = pmc_traffic(per, args.dim, tnotes, _bpl / max(1.0, float(-(-per // 32) * 32) * args.dim))
         qps = args.batch * args.steps / dt
         ms_step = dt / args.steps * 1e3
         if ker_ms:

@@ -46,18 +46,20 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         w = csv.DictWriter(o, fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(rows)
 fetch = sum(out["FETCH_SIZE"]) / len(out["FETCH_SIZE"]); write = sum(out["WRITE_SIZE"]) / len(out["WRITE_SIZE"])
 rows_n, dim = 10_000_000, 768
+bpv = 1.5 if ", true, true>" in kernel else 2.0   # k_scan<DENSE, CH, NT, STREAM, F12>: the 12-bit image
 traffic = (2 * fetch + write) * 1024
 sys.path.insert(0, f"{R}/tools")
 from scan_source_hash import scan_source_sha256
 json.dump({"kernel": kernel.replace("void anr::", "").split("(")[0], "rows": rows_n, "dim": dim,
-           "algorithmic_bytes_per_launch": rows_n * dim * 2, "FETCH_SIZE_KiB_per_launch": fetch,
+           "bytes_per_stored_value": bpv,
+           "algorithmic_bytes_per_launch": rows_n * dim * bpv, "FETCH_SIZE_KiB_per_launch": fetch,
            "WRITE_SIZE_KiB_per_launch": write,
            "correction": "gfx950: FETCH_SIZE counts half of a wide coalesced stream -> doubled (MI355X_MICROARCH.md HBM section); WRITE_SIZE exact; unit KiB",
-           "traffic_bytes_per_launch": traffic, "traffic_over_algorithmic": traffic / (rows_n * dim * 2),
+           "traffic_bytes_per_launch": traffic, "traffic_over_algorithmic": traffic / (rows_n * dim * bpv),
            "kernel_source_sha256": scan_source_sha256(), "kernel_source_region": "k_scan",
            "command": "rocprofv3 --pmc <counter> --kernel-trace --output-format csv -- python3 tools/scan_perf.py --rows 10000000 --steps 4 --mode sync (one pass per counter; tools/refresh_profiles.sh)"},
           open(f"{O}/{ROUND}_pmc_traffic_k_scan.json", "w"), indent=1)
-print("traffic/algorithmic", traffic / (rows_n * dim * 2))
+print("traffic/algorithmic", traffic / (rows_n * dim * bpv), "bytes per value", bpv)
 PY
 rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
 fi
