@@ -51,3 +51,13 @@ def test_shadow_kernels_fit_beside_a_scan_workgroup(md, needle):
         assert _alloc(k) <= free_regs, (name, k[".vgpr_count"], free_regs)
         assert k[".group_segment_fixed_size"] <= SHADOW_LDS_CAP, name  # static LDS; the dynamic part is bounded in index.hip
         assert k.get(".private_segment_fixed_size", 0) == 0, name      # no scratch: a spill would sit in the scan's HBM stream
+
+
+def test_the_twelve_bit_scan_keeps_three_waves_per_simd_without_scratch(md):
+    """k_scan<.., F12 = true> (ANR_OPT_SCAN_BITS 12: the image the 10 M-row headline streams) unpacks its operand in
+    registers; it must still fit three waves per SIMD (<= 168 registers) and spill nothing"""
+    picked = {n: k for n, k in _pick(md, "k_scanILb0ELi8ELi768").items() if n.endswith("ELb1EEEvNS_10ScanParamsE")}
+    assert len(picked) == 2          # streaming (non-temporal) and cache-resident loads
+    for name, k in picked.items():
+        assert _alloc(k) <= 168, (name, k[".vgpr_count"])
+        assert k.get(".private_segment_fixed_size", 0) == 0 and k.get(".vgpr_spill_count", 0) == 0, name
