@@ -23,6 +23,7 @@
 #include <cstdint>
 #include <cstring>
 #include <deque>
+#include <exception>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -97,31 +98,36 @@ class ForwardCombiner {
       lk.unlock();
       int rc = 0;
       std::string msg;
-      if (part.size() == 1) {
-        Req *r = part[0];
-        rc = fwd(lane, r->ids, r->lens, r->types, r->B, r->L, r->normalize, r->out, &msg);
-      } else {
-        ids.assign((size_t)rows * Lmax, 0);  // padding: any valid token (masked by the lengths)
-        if (typed) types.assign((size_t)rows * Lmax, 0);
-        lens.resize(rows);
-        out.resize((size_t)rows * hidden);
-        int a = 0;
-        for (Req *r : part) {
-          for (int b = 0; b < r->B; ++b) {
-            std::memcpy(ids.data() + (size_t)(a + b) * Lmax, r->ids + (size_t)b * r->L, (size_t)r->L * sizeof(int32_t));
-            if (typed)
-              std::memcpy(types.data() + (size_t)(a + b) * Lmax, r->types + (size_t)b * r->L, (size_t)r->L * sizeof(int32_t));
-            lens[a + b] = r->lens[b];
-          }
-          a += r->B;
-        }
-        rc = fwd(lane, ids.data(), lens.data(), typed ? types.data() : nullptr, rows, Lmax, first_norm, out.data(), &msg);
-        a = 0;
-        if (rc == 0)
+      try {
+        if (part.size() == 1) {
+          Req *r = part[0];
+          rc = fwd(lane, r->ids, r->lens, r->types, r->B, r->L, r->normalize, r->out, &msg);
+        } else {
+          ids.assign((size_t)rows * Lmax, 0);  // padding: any valid token (masked by the lengths)
+          if (typed) types.assign((size_t)rows * Lmax, 0);
+          lens.resize(rows);
+          out.resize((size_t)rows * hidden);
+          int a = 0;
           for (Req *r : part) {
-            std::memcpy(r->out, out.data() + (size_t)a * hidden, (size_t)r->B * hidden * sizeof(float));
+            for (int b = 0; b < r->B; ++b) {
+              std::memcpy(ids.data() + (size_t)(a + b) * Lmax, r->ids + (size_t)b * r->L, (size_t)r->L * sizeof(int32_t));
+              if (typed)
+                std::memcpy(types.data() + (size_t)(a + b) * Lmax, r->types + (size_t)b * r->L, (size_t)r->L * sizeof(int32_t));
+              lens[a + b] = r->lens[b];
+            }
             a += r->B;
           }
+          rc = fwd(lane, ids.data(), lens.data(), typed ? types.data() : nullptr, rows, Lmax, first_norm, out.data(), &msg);
+          a = 0;
+          if (rc == 0)
+            for (Req *r : part) {
+              std::memcpy(r->out, out.data() + (size_t)a * hidden, (size_t)r->B * hidden * sizeof(float));
+              a += r->B;
+            }
+        }
+      } catch (const std::exception &ex) {  // (allocation failure while merging: the round's callers get the error, the lane lives on)
+        rc = -4;
+        msg = ex.what();
       }
       lk.lock();
       forwards_ += 1;
