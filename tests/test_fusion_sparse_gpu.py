@@ -153,11 +153,15 @@ def test_sparse_source_in_the_dense_and_graph_slots_and_argument_errors():
 
 
 def _corpus(rng, n_docs, n_vocab, max_len):
+    """Zipf-distributed words, 0 .. max_len - 1 per note (all tokens drawn at once: a draw per note took minutes at 150 k notes)"""
     vocab = [f"w{i}" for i in range(n_vocab)]
     probs = 1.0 / np.arange(1, n_vocab + 1)
     probs /= probs.sum()
-    notes = [{"title": "", "content": " ".join(rng.choice(vocab, size=rng.integers(0, max_len), p=probs))}
-             for _ in range(n_docs)]
+    lens = rng.integers(0, max_len, size=n_docs)
+    toks = rng.choice(n_vocab, size=int(lens.sum()), p=probs)
+    words = np.array(vocab, dtype=object)
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    notes = [{"title": "", "content": " ".join(words[toks[offs[i]:offs[i + 1]]])} for i in range(n_docs)]
     return vocab, probs, notes
 
 
