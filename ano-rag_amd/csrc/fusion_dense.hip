@@ -765,9 +765,15 @@ __device__ __forceinline__ void fd_scan_chunk(const FdParams &p, SH &sh, FsState
   };
   // lanes whose entry e is non-zero or NaN.  rrf ranks by the raw array value, so the test runs on the raw bits (integer
   // operations instead of a float64 compare per entry); linear tests the fused value
+  // (rrf: the eight masks are formed ONCE per chunk — the rank bookkeeping and the row loop below both read them)
+  unsigned long long nzm1[kFdPer];
+  if (METHOD == 1) {
+#pragma unroll
+    for (int e = 0; e < kFdPer; ++e)
+      nzm1[e] = DT0 == 0 ? __ballot((raw[e] & 0x7fffffffffffffffull) != 0ull) : __ballot(((unsigned)raw[e] & 0x7fffffffu) != 0u);
+  }
   auto nz_mask = [&](int e) -> unsigned long long {
-    if (METHOD == 1)
-      return DT0 == 0 ? __ballot((raw[e] & 0x7fffffffffffffffull) != 0ull) : __ballot(((unsigned)raw[e] & 0x7fffffffu) != 0u);
+    if (METHOD == 1) return nzm1[e];
     return __ballot(!(f[e] == 0.0));
   };
   // an all-zero row holds no NaN: its valid lanes are the ones inside the array
@@ -800,10 +806,15 @@ __device__ __forceinline__ void fd_scan_chunk(const FdParams &p, SH &sh, FsState
     st.zc = c + 1;
     nzid = pb_z1 - pb_z0;
     if (nzid > 0) sid0 = (int64_t)sh.sk_id[pb_z0];
+    if (!FREE) {
 #pragma unroll
-    for (int e = 0; e < kFdPer; ++e) wtotal += (unsigned)__popcll(nz_mask(e));
+      for (int e = 0; e < kFdPer; ++e) wtotal += (unsigned)__popcll(nz_mask(e));
+    }
   }
-  const bool defer = wtotal <= (unsigned)kFsPushMax;  // a sparse wave defers its searches to its own LDS segment
+  // a sparse wave defers its searches to its own LDS segment; the barrier-free pass searches in place (no workgroup waits
+  // for the wave, and the pending lists' bookkeeping was a tenth of its instructions)
+  const bool defer = !FREE && wtotal <= (unsigned)kFsPushMax;
+  unsigned pend_free = 0;  // FREE: bit e = this lane's entry e wants its rank searched
   const int wstart = tid & ~63;
   // zero entries zb of entry row e: their rank counts, all in scalar registers unless two or more ids fall in the chunk
   auto add_zeros = [&](int e, unsigned long long zb) {
@@ -834,6 +845,7 @@ __device__ __forceinline__ void fd_scan_chunk(const FdParams &p, SH &sh, FsState
     if (ranks) {
       add_zeros(e, ok & ~nzm);
       const unsigned long long nb = ok & nzm;
+      if (FREE) pend_free |= (unsigned)((nb >> lane) & 1ull) << e;
       if (nb && defer) {
         if ((nb >> lane) & 1ull) {
           const unsigned pos = (unsigned)(tid >> 6) * kFsPendW + st.pw + (unsigned)__popcll(nb & lt_mask);
@@ -897,11 +909,13 @@ __device__ __forceinline__ void fd_scan_chunk(const FdParams &p, SH &sh, FsState
       if (lane == 0) sh.pw_n[tid >> 6] = 0;
     }
     if (!defer) {  // a dense wave: one search per round while any lane still has one
-      unsigned pend = 0;
+      unsigned pend = pend_free;
+      if (!FREE) {
 #pragma unroll
-      for (int e = 0; e < kFdPer; ++e) {
-        const unsigned long long nb = valid_mask(e) & nz_mask(e);
-        pend |= (unsigned)((nb >> lane) & 1ull) << e;
+        for (int e = 0; e < kFdPer; ++e) {
+          const unsigned long long nb = valid_mask(e) & nz_mask(e);
+          pend |= (unsigned)((nb >> lane) & 1ull) << e;
+        }
       }
       while (__any(pend != 0)) {
         const int e = pend ? __ffs(pend) - 1 : -1;
