@@ -762,3 +762,21 @@ def test_twelve_bit_scan_pipelined_batches_equal_the_sixteen_bit_ones():
     assert np.array_equal(out[12][1], out[16][1])
     assert np.array_equal(out[12][0], out[16][0])      # the scores are the exact re-scored ones either way
     idx.close()
+
+
+@pytest.mark.parametrize("d,n,nq,k", [(100, 120_000, 7, 10), (384, 150_000, 33, 20), (1024, 70_000, 64, 5)])
+def test_twelve_bit_scan_at_other_widths(d, n, nq, k):
+    """the 12-bit loader's other instantiations: padded dimensions (100 -> 128), the four-block operand buffers (384: 24
+    k-blocks), a wide row (1024); forced with ANR_OPT_SCAN_BITS 12 on corpora below the automatic threshold"""
+    from anorag_hip import FlatIndex, METRIC_IP
+    from anorag_hip._lib import OPT_SCAN_BITS
+    x, q = _data(n, d, nq, seed=d, qseed=d + 1)
+    idx = FlatIndex(d, METRIC_IP, normalize=True)
+    idx.set_option(OPT_SCAN_BITS, 12)
+    idx.add(x)
+    _check(idx, x, q, k, "ip", True)
+    st = idx.last_stats()
+    dimp = -(-d // 128) * 128
+    assert st["sample_rows"] > 0, st                                    # the threshold-gated pipeline, not the small-corpus path
+    assert st["scan_bytes"] == -(-n // 32) * 32 * dimp * 3 // 2, st     # ... reading the 12-bit image
+    idx.close()
