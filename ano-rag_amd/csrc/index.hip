@@ -339,7 +339,7 @@ int launch_scan(anr_index *h, const ScanParams &p, hipStream_t st, int max_grid,
   const size_t lds = (size_t)2 * p.kb * 64 * 16 + kQB * kLadder * 8 + kQB * 8;
   // 12 waves per block (3 per SIMD: 168 VGPRs each, room for two 8-KiB operand buffers without spills;
   // measured faster than 16 waves at 128 VGPRs; the 12-bit loader with 12 blocks per buffer instead of 8 — 168
-  // registers, half again the bytes in flight — measured no faster: 1.747-1.770 vs 1.696-1.739 ms per 10 M-row scan) when there is enough work for every CU, else smaller
+  // registers, half again the bytes in flight — measured no faster: 1.747-1.770 vs 1.696-1.739 ms per 10 M-row scan; 16 waves of 118 registers with 4-block buffers: 1.781) when there is enough work for every CU, else smaller
   // blocks on more CUs
   int nwaves = 12;
   if (ceil_div(p.n_tiles, nwaves) < max_grid) nwaves = 8;
