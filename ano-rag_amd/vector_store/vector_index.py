@@ -89,8 +89,16 @@ class VectorIndex:
     def _new_index(self, dim: int, metric: int, normalize: bool):
         if len(self.devices) > 1:
             from anorag_hip.sharded import ShardedFlatIndex
-            return ShardedFlatIndex(dim, metric, normalize=normalize, devices=self.devices)
-        return FlatIndex(dim, metric, normalize=normalize, device=self.devices[0])
+            idx = ShardedFlatIndex(dim, metric, normalize=normalize, devices=self.devices)
+        else:
+            idx = FlatIndex(dim, metric, normalize=normalize, device=self.devices[0])
+        # anorag_hip.scan_bits: 0 (default: the library decides — a 12-bit image of the corpus for the streaming pass from
+        # 524 288 rows on), 12 or 16 (ANR_OPT_SCAN_BITS; the results are the exact top-k either way)
+        bits = int(config.get("anorag_hip.scan_bits", 0) or 0)
+        if bits:
+            from anorag_hip._lib import OPT_SCAN_BITS
+            idx.set_option(OPT_SCAN_BITS, bits)
+        return idx
 
     def create_index(self, index_type: str = None) -> bool:
         index_type = index_type or self.index_type
