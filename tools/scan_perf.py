@@ -19,6 +19,7 @@ ap.add_argument("--streams", type=int, default=0)
 ap.add_argument("--no-timing", action="store_true", help="do not record the per-scan HIP events (ANR_OPT_TIMING)")
 ap.add_argument("--mode", default="both")
 ap.add_argument("--scan-bits", type=int, default=0)
+ap.add_argument("--fused-post", type=int, default=-1, help="ANR_OPT_FUSED_POST: 0 three launches, 1 automatic (default), 2 always fused")
 ap.add_argument("--clustered", action="store_true", help="1024 Gaussian centroids, sigma 0.3 (SURVEY 8d)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -39,6 +40,9 @@ while done < a.rows:
 if a.scan_bits != 0:
     from anorag_hip._lib import OPT_SCAN_BITS
     idx.set_option(OPT_SCAN_BITS, a.scan_bits)
+if a.fused_post >= 0:
+    from anorag_hip._lib import OPT_FUSED_POST
+    idx.set_option(OPT_FUSED_POST, a.fused_post)
 idx.set_option(OPT_TIMING, 0 if a.no_timing else 1)
 if a.sample: idx.set_option(OPT_SAMPLE_ROWS, a.sample)
 if a.overfetch: idx.set_option(OPT_OVERFETCH, a.overfetch)
