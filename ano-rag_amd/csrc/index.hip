@@ -69,6 +69,7 @@ struct Workspace {
   int64_t seq = 0;
   bool shadow = false;             // the batch's side kernels were the shadow-sized ones
   bool f12 = false;                // the batch's streaming pass read the 12-bit image
+  int f12_level = 0;               // ... at this level of the K' ladder
   hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
   hipEvent_t ev_pre = nullptr, ev_scan = nullptr;  // role streams: ladder ready (pre -> main), scan done (main -> post)
   // the batch in flight
@@ -96,6 +97,8 @@ struct anr_index {
   int scan_bits = 0;          // ANR_OPT_SCAN_BITS: 0 auto, 12, 16
   bool f12_suspended = false; // the corpus proved too dense for the 12-bit image (adapt_overfetch): batches read x16 again
   int f12_strikes = 0;
+  // K' of the 12-bit batches: its own ladder of quarter steps (kF12Steps) and a step-down that backs off
+  int f12_level = 0, f12_clean = 0, f12_hold = 64, f12_lowered = 0;
   hipStream_t stream = nullptr;                        // adds, exact path, copies
   hipStream_t bstream[kWorkspaces] = {nullptr, nullptr, nullptr};  // one per in-flight batch
   std::mutex mu;
@@ -398,6 +401,10 @@ int build_x12(anr_index *h) {
   return refresh_xstat(h);
 }
 
+// K' of a 12-bit batch = the base (256 at k = 100) x kF12Steps[level] / 4
+constexpr int kF12Steps[] = {4, 6, 8, 10, 12, 16};
+constexpr int kF12Levels = 6;
+
 int auto_overfetch(const anr_index *h, int k, bool f12 = false) {
   if (h->overfetch > 0) {
     int m = h->overfetch < k ? k : h->overfetch;
@@ -406,7 +413,11 @@ int auto_overfetch(const anr_index *h, int k, bool f12 = false) {
   int extra = k / 2 > 32 ? k / 2 : 32;
   // the 12-bit image's error term is ~15x the f16 one: K' = 192 for k = 100 left 2.5 % of the certificates of a 10 M-row
   // Gaussian corpus failing, 256 none (and 320 / 384 cost more than they save: 1.737 / 1.770 / 1.776 ms per batch)
-  if (f12) extra = k > 64 ? k : 64;
+  if (f12) {
+    extra = k > 64 ? k : 64;
+    const int m = (int)round_up((round_up(k + extra, 64) * kF12Steps[h->f12_level]) / 4, 64);
+    return m > kMaxSel ? kMaxSel : m;
+  }
   int m = (int)round_up(k + extra, 64) * h->overfetch_boost;
   return m > kMaxSel ? kMaxSel : m;
 }
@@ -416,23 +427,52 @@ int auto_overfetch(const anr_index *h, int k, bool f12 = false) {
 // a quarter of a batch's queries fail their certificate the automatic K' doubles (up to 4x, capped at 1024) —
 // an exact re-score of 1024 rows per query costs ~40 us per batch, the second scan ~300 us at a 1.25 M-row
 // shard — and it halves again after 16 consecutive batches without a failure.
-void adapt_overfetch(anr_index *h, int n_queries, int n_failed, bool f12) {
+void adapt_overfetch(anr_index *h, int n_queries, int n_failed, bool f12, int batch_level = 0) {
   if (n_queries <= 0) return;
-  // The 12-bit image widens the certificate's error term ~15x: where hundreds of rows lie that close to the k-th score
-  // (near-duplicate neighbourhoods) even the largest K' cannot certify and the lists overflow into the dense exact path.
-  // Two such batches in a row with K' at its cap (or fixed by the caller) and the index goes back to the f16 image until
-  // the option is set again or the index is reset.
   if (f12) {
-    if (4 * n_failed > n_queries && (h->overfetch > 0 || h->overfetch_boost >= 4)) {
+    // (batches are retired up to three behind the front: one that ran at an older level says nothing about the current one —
+    // counting it made three failing batches in flight climb three levels at once)
+    if (h->overfetch == 0 && batch_level != h->f12_level) return;
+    // The 12-bit image widens the certificate's error term ~15x, so the K' a corpus needs depends on how many rows lie that
+    // close to the k-th score: 256 on a Gaussian corpus, ~640 on SURVEY 8d's clustered one (1024 centres, sigma 0.3: 0.294 ms
+    // per 1.25 M-row batch there against 0.320 from the f16 image; the doubling ladder below bounced between 512, where
+    // 39 % of the certificates fail, and 1024: 0.318).  Its own ladder in quarter steps of the base: one step up when more
+    // than a quarter of a batch fails, one step down after `hold` (64, …) clean batches — and a step down that fails straight away
+    // doubles `hold`, so the level settles instead of oscillating.  Failing at the top level (or at a K' the caller fixed) in
+    // two batches running — near-duplicate neighbourhoods: the lists overflow into the dense exact path — sends the index
+    // back to the f16 image until the option is set again or the index is reset.
+    const bool failing = 4 * n_failed > n_queries;
+    if (h->f12_lowered > 0) --h->f12_lowered;
+    if (failing && (h->overfetch > 0 || h->f12_level >= kF12Levels - 1)) {
       if (++h->f12_strikes >= 2) {
         h->f12_suspended = true;
-        if (h->overfetch == 0) h->overfetch_boost = 1;  // the boost answered the 12-bit image's failures: the f16 image starts over
+        h->f12_level = h->f12_clean = 0;
+        h->f12_hold = 64;
+        // a corpus this dense defeats the f16 image's first K' as well (tests: tight clusters need 4x): start there, the
+        // f16 ladder steps down by itself after 16 clean batches
+        if (h->overfetch == 0) h->overfetch_boost = 4;
         h->clean_batches = 0;
-        return;
       }
-    } else if (4 * n_failed <= n_queries) {
-      h->f12_strikes = 0;
+      return;
     }
+    if (!failing) h->f12_strikes = 0;
+    if (h->overfetch > 0) return;
+    if (failing) {
+      // (three quarters of the batch failing: the level is far off — two steps)
+      h->f12_level = std::min(kF12Levels - 1, h->f12_level + (4 * n_failed >= 3 * n_queries && h->f12_lowered == 0 ? 2 : 1));
+      if (h->f12_lowered > 0 && h->f12_hold < 4096) h->f12_hold *= 2;  // the last step down was a mistake: try again later
+      h->f12_lowered = 0;
+      h->f12_clean = 0;
+    } else if (n_failed == 0) {
+      if (h->f12_level > 0 && ++h->f12_clean >= h->f12_hold) {
+        --h->f12_level;
+        h->f12_clean = 0;
+        h->f12_lowered = 4;
+      }
+    } else {
+      h->f12_clean = 0;
+    }
+    return;
   }
   if (h->overfetch > 0) return;  // the caller fixed K'
   if (4 * n_failed > n_queries) {
@@ -658,7 +698,7 @@ int retire(anr_index *h, Workspace &w) {
           h->stats.n_candidates += w.cnt_host[q];
           if (w.cnt_host[kQB + q]) h->stats.n_overflow += 1;
         }
-      adapt_overfetch(h, w.nq, (int)fallback.size(), w.sparse && w.f12);
+      adapt_overfetch(h, w.nq, (int)fallback.size(), w.sparse && w.f12, w.f12_level);
     }
     h->stats.n_fallback += (int64_t)fallback.size();
   }
@@ -781,8 +821,6 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
     if (!h->x12) (void)build_x12(h);  // (auto: stays on the f16 image when the memory is not there)
     f12 = h->x12 != nullptr;
   }
-  const int M = auto_overfetch(h, k, f12);
-  w.M = M;
   const int64_t n_tiles = ceil_div(h->ntotal, kTileRows);
   const int64_t full_tiles = h->ntotal / kTileRows;
   // threshold sample: ~1/64 of the rows, between 4K and 16K (more rows -> tighter first threshold)
@@ -791,8 +829,18 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
   // S = 27 sqrt(N)
   const int64_t auto_sample = round_up(
       std::min<int64_t>(262144, std::max<int64_t>(4096, (int64_t)(27.0 * std::sqrt((double)h->ntotal)))), 1024);
-  int64_t sample_tiles = (h->sample_rows > 0 ? h->sample_rows : auto_sample) / kTileRows;
-  if (sample_tiles < 2 * M) sample_tiles = 2 * M;  // tile maxima: the M-th largest is backed by M distinct rows
+  const int64_t sample_want = (h->sample_rows > 0 ? h->sample_rows : auto_sample) / kTileRows;
+  // tile maxima: the M-th largest is backed by M distinct rows -> at least 2 M sample tiles; the threshold-gated pipeline
+  // needs a corpus of eight samples.  A 12-bit batch's larger K' can push a mid-sized corpus below that: it then runs as an
+  // f16 batch (the small-corpus path scores every row from x16) with the f16 K'.
+  int M = auto_overfetch(h, k, f12);
+  if (f12 && full_tiles < 8 * std::max<int64_t>(sample_want, 2 * (int64_t)M)) {
+    f12 = false;
+    M = auto_overfetch(h, k, false);
+  }
+  w.M = M;
+  int64_t sample_tiles = sample_want;
+  if (sample_tiles < 2 * M) sample_tiles = 2 * M;
   const bool sparse = full_tiles >= 8 * sample_tiles;
   w.sparse = sparse;
   // k_post runs ONE workgroup per query: a batch of a few queries leaves its select and re-score to a handful of CUs
@@ -916,6 +964,7 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
     }
     if (w.timed) ANR_HIP(hipEventRecord(w.ev_t0, ms));
     w.f12 = f12;
+    w.f12_level = h->f12_level;
     if (f12) {
       sc.x12 = h->x12;
       ANR_TRY((launch_scan<false, true>(h, sc, ms, scan_grid_max, &scan_grid)));
@@ -1536,7 +1585,8 @@ int anr_index_reset(anr_index *h) {
   h->ntotal = 0;
   h->xstat_dirty = true;
   h->f12_suspended = false;
-  h->f12_strikes = 0;
+  h->f12_strikes = h->f12_level = h->f12_clean = h->f12_lowered = 0;
+  h->f12_hold = 64;
   return ANR_OK;
 }
 
@@ -1835,7 +1885,8 @@ int anr_index_set_option(anr_index *h, int32_t opt, int64_t value) {
     case ANR_OPT_SCAN_BITS: {
       if (value != 0 && value != 12 && value != 16) return fail(ANR_EINVAL, "scan bits must be 0 (auto), 12 or 16");
       h->f12_suspended = false;
-      h->f12_strikes = 0;
+      h->f12_strikes = h->f12_level = h->f12_clean = h->f12_lowered = 0;
+      h->f12_hold = 64;
       if ((int)value == h->scan_bits) break;
       ANR_TRY(drain(h));
       ANR_HIP(hipStreamSynchronize(h->stream));

@@ -712,7 +712,7 @@ def main():
                          ("shard_1250k_clustered", lambda: pipeline_leg(shard_rows, args.dim, args.batch, args.k, dev, 13,
                                                                         centroids=1024, sigma=0.3)),
                          ("shard_1250k_tight_clusters", lambda: pipeline_leg(shard_rows, args.dim, args.batch, args.k, dev, 14,
-                                                                             steps=30, warmup=6, serial=6, centroids=1024, sigma=0.02)),
+                                                                             steps=30, warmup=14, serial=6, centroids=1024, sigma=0.02)),
                          ("c1_10k", lambda: c1_leg(dev)), ("c4", lambda: c4_leg(dev)), ("c5", lambda: c5_leg(dev))):
             try:
                 legs[name] = fn()

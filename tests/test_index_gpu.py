@@ -716,16 +716,20 @@ def test_twelve_bit_scan_image_gives_the_exact_top_k(when):
     idx.add(x)
     idx.set_option(OPT_SCAN_BITS, 12)
     # near-duplicate neighbourhoods: hundreds of rows within the 12-bit error bound of the k-th score — exact answers from the
-    # first batch on (lists, theta re-scan, dense exact path), and after two batches that failed at the largest K' the index
-    # goes back to the f16 image by itself
+    # first batch on (lists, theta re-scan, dense exact path); K' climbs its ladder, and after two batches that failed at the
+    # largest K' the index goes back to the f16 image by itself (whose own K' then adapts as in test_tight_clusters_...)
     seen = []
-    for _ in range(8):
+    for _ in range(14):
         _check(idx, x, q, k, "ip", True)
         st = idx.last_stats()
-        seen.append((st["scan_bytes"], st["n_fallback"], st["n_dense_exact"]))
+        seen.append((st["scan_bytes"], st["n_fallback"], st["n_dense_exact"], st["overfetch"], st["n_from_lists"]))
     tiles = -(-n // 32)
-    assert seen[0][0] == tiles * 32 * 256 * 3 // 2 and seen[-1][0] == tiles * 32 * 256 * 2, seen
-    assert seen[-1][1] < nq // 2, seen             # as the f16 image does on this data at its largest K' (test_tight_clusters_...)
+    b12, b16 = tiles * 32 * 256 * 3 // 2, tiles * 32 * 256 * 2
+    # (either outcome is sound: the ladder finds a K' at which most certificates hold on the 12-bit image, or two batches
+    # fail at the top level and the f16 image takes over; what must hold is that the failures die down)
+    assert seen[0][0] == b12 and seen[-1][0] in (b12, b16), seen
+    assert seen[-1][1] < nq // 2, [t[1:] for t in seen]   # as the f16 image does on this data at its largest K' (test_tight_clusters_...)
+    assert any(a[1] > b[1] for a, b in zip(seen, seen[1:])), seen
     idx.reset()                                    # an emptied index keeps the option (and tries the 12-bit image again)
     idx.add(x[:40_000])
     _check(idx, x[:40_000], q, k, "ip", True)
