@@ -784,3 +784,27 @@ def test_twelve_bit_scan_at_other_widths(d, n, nq, k):
     assert st["sample_rows"] > 0, st                                    # the threshold-gated pipeline, not the small-corpus path
     assert st["scan_bytes"] == -(-n // 32) * 32 * dimp * 3 // 2, st     # ... reading the 12-bit image
     idx.close()
+
+
+def test_twelve_bit_scan_on_low_rank_embeddings():
+    """rows that live near a 48-dimensional subspace with a few dominant directions (what sentence embeddings look like more
+    than an isotropic Gaussian does): scores bunch up near the top, the 12-bit batches climb their K' ladder or hand over to
+    the f16 image — and every answer is the exact top-k"""
+    from anorag_hip import FlatIndex, METRIC_IP
+    from anorag_hip._lib import OPT_SCAN_BITS
+    rng = np.random.default_rng(5)
+    n, d, nq, k = 180_000, 768, 64, 100
+    basis = rng.standard_normal((48, d)).astype(np.float32) * (1.0 / np.sqrt(np.arange(1, 49)))[:, None].astype(np.float32)
+    x = (rng.standard_normal((n, 48)).astype(np.float32) @ basis + 0.05 * rng.standard_normal((n, d)).astype(np.float32))
+    q = (rng.standard_normal((nq, 48)).astype(np.float32) @ basis + 0.05 * rng.standard_normal((nq, d)).astype(np.float32))
+    idx = FlatIndex(d, METRIC_IP, normalize=True)
+    idx.set_option(OPT_SCAN_BITS, 12)
+    idx.add(x)
+    seen = []
+    for _ in range(6):
+        _check(idx, x, q, k, "ip", True)
+        st = idx.last_stats()
+        seen.append((st["scan_bytes"] * 2 // (-(-n // 32) * 32 * d), st["n_fallback"], st["overfetch"]))
+    assert seen[0][0] == 3, seen                    # started on the 12-bit image (3 half-bytes... 1.5 bytes per value)
+    assert seen[-1][1] <= seen[0][1], seen          # the failures do not grow
+    idx.close()
