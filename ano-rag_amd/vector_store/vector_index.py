@@ -93,7 +93,7 @@ class VectorIndex:
         else:
             idx = FlatIndex(dim, metric, normalize=normalize, device=self.devices[0])
         # anorag_hip.scan_bits: 0 (default: the library decides — a 12-bit image of the corpus for the streaming pass from
-        # 524 288 rows on), 12 or 16 (ANR_OPT_SCAN_BITS; the results are the exact top-k either way)
+        # 262 144 rows on), 12 or 16 (ANR_OPT_SCAN_BITS; the results are the exact top-k either way)
         bits = int(config.get("anorag_hip.scan_bits", 0) or 0)
         if bits:
             from anorag_hip._lib import OPT_SCAN_BITS

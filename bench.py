@@ -48,7 +48,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-SCAN_BITS = 0  # ANR_OPT_SCAN_BITS of every index this file builds (--scan-bits; 0 = the library's default: 12 bits from 524 288 rows on)
+SCAN_BITS = 0  # ANR_OPT_SCAN_BITS of every index this file builds (--scan-bits; 0 = the library's default: 12 bits from 262 144 rows on)
 
 
 def parse():

@@ -157,7 +157,7 @@ int anr_index_set_option(anr_index *h, int32_t opt, int64_t value);
 #define ANR_OPT_SCAN_BITS 14      /* the image of the corpus the streaming pass reads: 16 = the f16 image; 12 = a second image
                                      with every stored f16 rounded to its top 12 bits (6 mantissa bits), 25 % fewer bytes per
                                      row — the pass is HBM-bound, so it is that much shorter; 0 (default) = 12 for indexes of
-                                     524 288 rows and more (built at the first such search), 16 below.  The certificate takes
+                                     262 144 rows and more (built at the first such search), 16 below.  The certificate takes
                                      the coarser image's error norm (tracked per index like the f16 one) and K' grows from 192
                                      to 256 at k = 100: the results stay the exact top-k of the float32 rows.  A corpus whose
                                      certificates keep failing at the largest K' (near-duplicate neighbourhoods) goes back to
