@@ -97,6 +97,7 @@ struct anr_index {
   int scan_bits = 0;          // ANR_OPT_SCAN_BITS: 0 auto, 12, 16
   bool f12_suspended = false; // the corpus proved too dense for the 12-bit image (adapt_overfetch): batches read x16 again
   int f12_strikes = 0;
+  bool x12_no_memory = false; // the 12-bit image could not be allocated: not tried again until rows are added or the option is set
   // K' of the 12-bit batches: its own ladder of quarter steps (kF12Steps) and a step-down that backs off
   int f12_level = 0, f12_clean = 0, f12_hold = 64, f12_lowered = 0;
   hipStream_t stream = nullptr;                        // adds, exact path, copies
@@ -820,7 +821,7 @@ int enqueue_batch(anr_index *h, const float *q_dev, int nq, int k, int64_t out_o
   // statistics of the coarser image (pp.xstat / fp.xstat below).
   bool f12 = false;
   if (!h->f12_suspended && (h->scan_bits == 12 || (h->scan_bits == 0 && h->ntotal >= kAuto12Rows))) {
-    if (!h->x12) (void)build_x12(h);  // (auto: stays on the f16 image when the memory is not there)
+    if (!h->x12 && !h->x12_no_memory && build_x12(h) != ANR_OK) h->x12_no_memory = true;  // (stays on the f16 image)
     f12 = h->x12 != nullptr;
   }
   const int64_t n_tiles = ceil_div(h->ntotal, kTileRows);
@@ -1418,6 +1419,7 @@ int add_impl(anr_index *h, const float *x_dev, int64_t n, hipStream_t st) {
   ANR_HIP(hipGetLastError());
   h->ntotal += n;
   h->xstat_dirty = true;
+  h->x12_no_memory = false;
   return ANR_OK;
 }
 
@@ -1887,6 +1889,7 @@ int anr_index_set_option(anr_index *h, int32_t opt, int64_t value) {
     case ANR_OPT_SCAN_BITS: {
       if (value != 0 && value != 12 && value != 16) return fail(ANR_EINVAL, "scan bits must be 0 (auto), 12 or 16");
       h->f12_suspended = false;
+      h->x12_no_memory = false;
       h->f12_strikes = h->f12_level = h->f12_clean = h->f12_lowered = 0;
       h->f12_hold = 64;
       if ((int)value == h->scan_bits) break;
