@@ -121,6 +121,9 @@ SIGNATURES = {
     ),
     "anr_index_set_option": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64]),
     "anr_index_last_stats": (C.c_int, [C.c_void_p, C.POINTER(SearchStats)]),
+    "anr_index_reconstruct_scan_image": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p]),
+    "anr_index_scan_image_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                             C.POINTER(C.c_float)]),
     "anr_index_batch_log": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "anr_normalize_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32]),
     "anr_merge_topk_dev": (

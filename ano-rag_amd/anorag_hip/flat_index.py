@@ -132,6 +132,20 @@ class FlatIndex:
                    "anr_index_reconstruct")
         return out
 
+    def reconstruct_scan_image(self, bits: int, i0: int, n: int):
+        """rows [i0, i0 + n) of the image the streaming scan reads (16: the f16 image, 12: the 12-bit one), as float32"""
+        out = np.empty((n, self.d), dtype=np.float32)
+        _lib.check(self._lib.anr_index_reconstruct_scan_image(self._h, int(bits), int(i0), int(n), out.ctypes.data),
+                   "anr_index_reconstruct_scan_image")
+        return out
+
+    def scan_image_stats(self) -> dict:
+        """{'bits': image batches scan now, 'max_norm', 'max_err16', 'max_err12'}: the statistics the certificate uses"""
+        b, a, e16, e12 = C.c_int32(0), C.c_float(0), C.c_float(0), C.c_float(0)
+        _lib.check(self._lib.anr_index_scan_image_stats(self._h, C.byref(b), C.byref(a), C.byref(e16), C.byref(e12)),
+                   "anr_index_scan_image_stats")
+        return {"bits": int(b.value), "max_norm": float(a.value), "max_err16": float(e16.value), "max_err12": float(e12.value)}
+
     # -- device-pointer surface (torch tensors are only carriers of device memory) --------------
     def reserve(self, n: int) -> None:
         _lib.check(self._lib.anr_index_reserve(self._h, int(n)), "anr_index_reserve")

@@ -1604,6 +1604,47 @@ int anr_index_reconstruct(anr_index *h, int64_t i0, int64_t n, float *out_host) 
   return ANR_OK;
 }
 
+int anr_index_reconstruct_scan_image(anr_index *h, int32_t bits, int64_t i0, int64_t n, float *out_host) {
+  if (!h || !out_host || i0 < 0 || n < 0 || i0 + n > h->ntotal) return fail(ANR_EINVAL, "row range out of bounds");
+  if (bits != 12 && bits != 16) return fail(ANR_EINVAL, "bits must be 12 or 16");
+  if (bits == 12 && !h->x12) return fail(ANR_ESTATE, "the index keeps no 12-bit image (ANR_OPT_SCAN_BITS)");
+  if (n == 0) return ANR_OK;
+  DeviceGuard g(h->device);
+  std::lock_guard<std::mutex> lk(h->mu);
+  ANR_TRY(drain(h));
+  float *d = nullptr;
+  ANR_TRY(dev_alloc(&d, n * h->dim, false));
+  ImageRowsParams ip{h->x16, bits == 12 ? h->x12 : nullptr, i0, n, h->dim, h->kb, d};
+  hipLaunchKernelGGL(k_image_rows, dim3((unsigned)ceil_div(n * h->kb * 2, 256)), dim3(256), 0, h->stream, ip);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (e == hipSuccess) e = hipMemcpy(out_host, d, (size_t)n * h->dim * sizeof(float), hipMemcpyDeviceToHost);
+  dev_free(d);
+  if (e != hipSuccess) return fail(ANR_EHIP, "reading the scan image failed: %s", hipGetErrorString(e));
+  return ANR_OK;
+}
+
+int anr_index_scan_image_stats(anr_index *h, int32_t *bits_in_use, float *max_norm, float *max_err16, float *max_err12) {
+  if (!h) return fail(ANR_EINVAL, "null handle");
+  DeviceGuard g(h->device);
+  std::lock_guard<std::mutex> lk(h->mu);
+  ANR_TRY(drain(h));
+  unsigned host[4] = {0, 0, 0, 0};
+  ANR_HIP(hipStreamSynchronize(h->stream));
+  ANR_HIP(hipMemcpy(host, h->xstat, sizeof host, hipMemcpyDeviceToHost));
+  auto f = [](unsigned u) {
+    float v;
+    std::memcpy(&v, &u, 4);
+    return v;
+  };
+  const bool f12 = h->x12 && !h->f12_suspended && (h->scan_bits == 12 || (h->scan_bits == 0 && h->ntotal >= kAuto12Rows));
+  if (bits_in_use) *bits_in_use = f12 ? 12 : 16;
+  if (max_norm) *max_norm = f(host[0]);
+  if (max_err16) *max_err16 = f(host[1]);
+  if (max_err12) *max_err12 = h->x12 ? f(host[3]) : 0.0f;
+  return ANR_OK;
+}
+
 int anr_index_search(anr_index *h, const float *q_host, int64_t nq, int32_t k, float *D, int64_t *I) {
   return search_impl(h, q_host, true, nq, k, D, I, true, nullptr);
 }

@@ -261,6 +261,38 @@ __global__ __launch_bounds__(256) void k_build12(Build12Params p) {
     atomicMax(&p.stat[3], __float_as_uint(sqrtf(s_err12[tid]) * 1.0001f));
 }
 
+// the image the streaming scan reads, decoded back to float32 rows (anr_index_reconstruct_scan_image: how the tests pin the
+// 12-bit image and its tracked error norm against the oracle's restatement).  One thread per (row, 8 values).
+struct ImageRowsParams {
+  const _Float16 *x16;
+  const unsigned *x12;  // nullptr: decode the f16 image
+  int64_t i0, n;
+  int dim, kb;
+  float *out;           // [n][dim]
+};
+__global__ __launch_bounds__(256) void k_image_rows(ImageRowsParams p) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int groups = p.kb * 2;  // 8-value groups per row
+  if (t >= p.n * groups) return;
+  const int64_t row = p.i0 + t / groups;
+  const int gidx = (int)(t % groups), kbl = gidx >> 1, h = gidx & 1;
+  const int64_t tile = row / kTileRows;
+  const int l = (int)(row % kTileRows) + 32 * h;
+  const int64_t blk = tile * p.kb + kbl;
+  half8 hv;
+  if (p.x12) {
+    const unsigned *w = p.x12 + (blk * 64 + l) * 3;
+    hv = __builtin_bit_cast(half8, x12_unpack(w[0], w[1], w[2]));
+  } else {
+    hv = *reinterpret_cast<const half8 *>(p.x16 + (blk * 64 + l) * 8);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = kbl * 16 + h * 8 + j;
+    if (k < p.dim) p.out[(row - p.i0) * p.dim + k] = (float)hv[j];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // prepq: one block per query slot: normalise, keep f32 copy, build the blocked f16 B operand
 // ------------------------------------------------------------------------------------------------

@@ -65,6 +65,13 @@ int anr_index_reset(anr_index *h);
 /* copy the stored (already preprocessed) float32 rows [i0, i0+n) back to the host */
 int anr_index_reconstruct(anr_index *h, int64_t i0, int64_t n, float *out_host);
 
+/* Diagnostics of the image the streaming scan reads (what pins ANR_OPT_SCAN_BITS 12 in the tests): rows [i0, i0 + n) of the
+ * f16 image (bits = 16) or of the 12-bit image (bits = 12; ANR_ESTATE when the index keeps none) decoded to float32, and the
+ * statistics the certificate uses — the largest row norm and the largest ||image row - stored float32 row|| of either image
+ * (max_err12 = 0 without a 12-bit image) — with the image batches currently scan (12 or 16).  Any pointer may be NULL. */
+int anr_index_reconstruct_scan_image(anr_index *h, int32_t bits, int64_t i0, int64_t n, float *out_host);
+int anr_index_scan_image_stats(anr_index *h, int32_t *bits_in_use, float *max_norm, float *max_err16, float *max_err12);
+
 /* Search nq queries for the k best rows (vector_index.py:223).  D[nq*k] scores best-first (inner
  * product, or squared L2), I[nq*k] row ids, padded with -1 (and -FLT_MAX / +FLT_MAX scores) when
  * k > ntotal, the faiss convention vector_index.py:234 relies on.  Ties in score are ordered by

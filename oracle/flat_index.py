@@ -171,3 +171,28 @@ def shape_results(D: np.ndarray, I: np.ndarray, similarity_metric: str = "cosine
     if len(results) == 1:
         return results[0]
     return results
+
+
+def scan_image(x32: np.ndarray, bits: int = 12) -> np.ndarray:
+    """The image of stored float32 rows that the device's streaming scan reads (test infrastructure: restates
+    csrc/index_kernels.hpp f16_to_12 / k_add, nothing in the reference — faiss scans float32; the image only NOMINATES
+    candidates, the float32 rows decide).  bits = 16: the rows rounded to float16 (round-to-nearest-even).  bits = 12: that
+    float16 rounded again, to nearest-even, to its top 12 bits (sign, 5 exponent bits, 6 mantissa bits); a value that would
+    round up to infinity is truncated instead.  Returned as float32."""
+    h = np.asarray(x32, dtype=np.float32).astype(np.float16)
+    if bits == 16:
+        return h.astype(np.float32)
+    if bits != 12:
+        raise ValueError("bits must be 12 or 16")
+    b = h.view(np.uint16).astype(np.uint32)
+    r = (b + 7 + ((b >> 4) & 1)) >> 4
+    would_overflow = ((r & 0x7C0) == 0x7C0) & ((b & 0x7C00) != 0x7C00)
+    r = np.where(would_overflow, b >> 4, r) & 0xFFF
+    return (r << 4).astype(np.uint16).view(np.float16).astype(np.float32)
+
+
+def scan_image_error(x32: np.ndarray, bits: int = 12) -> float:
+    """max over the rows of || image row - row || (float64): the quantity the device tracks for its certificate"""
+    x = np.asarray(x32, dtype=np.float32)
+    d = scan_image(x, bits).astype(np.float64) - x.astype(np.float64)
+    return float(np.sqrt((d * d).sum(axis=1)).max()) if len(x) else 0.0

@@ -808,3 +808,40 @@ def test_twelve_bit_scan_on_low_rank_embeddings():
     assert seen[0][0] == 3, seen                    # started on the 12-bit image (3 half-bytes... 1.5 bytes per value)
     assert seen[-1][1] <= seen[0][1], seen          # the failures do not grow
     idx.close()
+
+
+@pytest.mark.parametrize("d,normalize", [(768, True), (100, False)])
+def test_the_scan_images_and_their_error_norms_equal_the_oracles(d, normalize):
+    """what the certificate of a 12-bit batch rests on: the device's 12-bit image is, bit for bit, the oracle's restatement
+    (float16 of the stored row, rounded to nearest-even to its top 12 bits), and the error norm the index tracks for it
+    bounds the true one from above by at most the 1e-4 slack of its float32 accumulation — rows written by k_add (before the
+    switch: k_build12 converts them) and after it, large values near the float16 range included"""
+    from anorag_hip import FlatIndex, METRIC_IP
+    from anorag_hip._lib import AnoragError, OPT_SCAN_BITS
+    rng = np.random.default_rng(3)
+    n = 6_000
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    if not normalize:
+        x[:50] *= 1.0e3                      # values up to a few thousand
+        x[50, :8] = [65504.0, -65504.0, 65500.0, 65472.0, -65488.0, 6.1e-5, -5.9e-8, 0.0]   # the float16 edges
+    idx = FlatIndex(d, METRIC_IP, normalize=normalize)
+    with pytest.raises(AnoragError):
+        idx.add(x[:10]) or idx.reconstruct_scan_image(12, 0, 10)     # no 12-bit image yet
+    idx.add(x[10:3000])
+    idx.set_option(OPT_SCAN_BITS, 12)        # k_build12 for the 3000 rows stored so far
+    idx.add(x[3000:])                        # k_add for the rest
+    stored = idx.reconstruct_n(0, n)         # the float32 rows the index keeps (normalised on the device)
+    for bits in (16, 12):
+        img = idx.reconstruct_scan_image(bits, 0, n)
+        ref = orc.scan_image(stored, bits)
+        assert img.tobytes() == ref.tobytes(), bits
+    st = idx.scan_image_stats()
+    assert st["bits"] == 12
+    for bits, key in ((16, "max_err16"), (12, "max_err12")):
+        true = orc.scan_image_error(stored, bits)
+        assert true <= st[key] <= true * 1.0003 + 1e-12, (bits, true, st[key])
+    norm = float(np.sqrt((stored.astype(np.float64) ** 2).sum(axis=1)).max())
+    assert norm <= st["max_norm"] <= norm * 1.0003
+    part = idx.reconstruct_scan_image(12, 2990, 37)    # a range that straddles tiles and the two writers
+    assert part.tobytes() == orc.scan_image(stored[2990:3027], 12).tobytes()
+    idx.close()
